@@ -1,0 +1,126 @@
+"""ctypes loader for libcrx.so (the C ABI declared in include/crx.h)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class CrxError(RuntimeError):
+    pass
+
+
+class EkfParams(C.Structure):
+    _fields_ = [("dt", C.c_double)]
+
+
+class LqrParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("L", C.c_double), ("eps", C.c_float), ("maxiter", C.c_int)]
+
+
+class MpcParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in (
+        "dt", "wb", "max_steer", "max_accel", "max_speed", "min_speed", "r_a", "r_delta", "rd_a",
+        "rd_delta", "q_x", "q_y", "q_yaw", "q_v", "tol")] + [("max_iter", C.c_int)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+# name -> (restype, argtypes); every symbol include/crx.h declares.
+_SIGNATURES = {
+    "crx_version": (_I, []),
+    "crx_device_count": (_I, []),
+    "crx_last_error": (C.c_char_p, []),
+    "crx_ekf_default_params": (None, [C.POINTER(EkfParams)]),
+    "crx_lqr_default_params": (None, [C.POINTER(LqrParams)]),
+    "crx_mpc_default_params": (None, [C.POINTER(MpcParams)]),
+    "crx_motion_model_batch": (_I, [_I, _P, _P, _P, C.POINTER(EkfParams)]),
+    "crx_motion_model_batch_dev": (_I, [_I, _P, _P, _P, C.POINTER(EkfParams), _P]),
+    "crx_jacobF_batch": (_I, [_I, _P, _P, _P, C.POINTER(EkfParams)]),
+    "crx_jacobF_batch_dev": (_I, [_I, _P, _P, _P, C.POINTER(EkfParams), _P]),
+    "crx_observation_model_batch": (_I, [_I, _P, _P]),
+    "crx_observation_model_batch_dev": (_I, [_I, _P, _P, _P]),
+    "crx_jacobH": (_I, [_P]),
+    "crx_ekf_step_batch": (_I, [_I, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams)]),
+    "crx_ekf_step_batch_dev": (_I, [_I, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams), _P]),
+    "crx_ekf_run_batch": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams)]),
+    "crx_ekf_run_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams), _P]),
+    "crx_ekf_simulate_inputs_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                         C.POINTER(EkfParams), _P]),
+    "crx_dare_batch": (_I, [_I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "crx_dare_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
+    "crx_dare_from_v_batch": (_I, [_I, _I, _P, C.POINTER(LqrParams), _P, _P, _P]),
+    "crx_dare_from_v_batch_dev": (_I, [_I, _I, _P, C.POINTER(LqrParams), _P, _P, _P, _P]),
+    "crx_mpc_solve_batch": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P]),
+    "crx_mpc_solve_batch_dev": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libcrx.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load libcrx.so once.  torch is imported first so that the library binds to the HIP
+    runtime torch already mapped (same soname, libamdhip64.so.7) — one runtime per process."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CrxError(
+            f"{path} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C cpprobotics_amd/csrc`). "
+            "crx has no CPU fallback.")
+    import torch  # noqa: F401  (maps torch's libamdhip64 first)
+    l = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise CrxError(f"libcrx.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return l
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().crx_last_error().decode("utf-8", "replace")
+        raise CrxError(f"{what} failed with status {rc}: {msg}")
+
+
+def require_cuda(*tensors):
+    import torch
+    if not torch.cuda.is_available():
+        raise CrxError("no HIP device visible: crx has no CPU fallback")
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CrxError("crx *_dev entry points need device tensors")
+        if not t.is_contiguous():
+            raise CrxError("crx needs contiguous tensors")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_floats(values, n):
+    import numpy as np
+    a = np.ascontiguousarray(np.asarray(values, dtype=np.float32).reshape(-1))
+    if a.size != n:
+        raise CrxError(f"expected {n} floats, got {a.size}")
+    return a

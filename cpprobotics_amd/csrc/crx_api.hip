@@ -1,0 +1,379 @@
+// crx_api.hip — the C ABI (include/crx.h) over the gfx950 kernels.  Host side is thin on purpose:
+// argument checks, launch geometry, and (for the host-pointer variants) staging copies.
+// There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/crx.h"
+#include "dare_kernels.hip.h"
+#include "ekf_kernels.hip.h"
+#include "mpc_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const char* what) { g_err = what; return code; }
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return CRX_ERR_HIP;
+}
+
+#define CRX_HIP(call)                                        \
+  do {                                                       \
+    hipError_t e__ = (call);                                 \
+    if (e__ != hipSuccess) return hip_fail(e__, #call);      \
+  } while (0)
+
+int check_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(CRX_ERR_NO_DEVICE, "no HIP device available (crx has no CPU fallback)");
+  }
+  return CRX_OK;
+}
+
+inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+crx::EkfConsts make_consts(const float* Q, const float* R, const crx_ekf_params* prm) {
+  crx::EkfConsts k;
+  std::memcpy(k.Q, Q, sizeof(k.Q));
+  std::memcpy(k.R, R, sizeof(k.R));
+  k.dt = prm ? prm->dt : 0.1;
+  return k;
+}
+
+// RAII device scratch for the host-pointer entry points.
+struct DevBuf {
+  void* p = nullptr;
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+#define CRX_ALLOC(buf, bytes)                                               \
+  do {                                                                      \
+    hipError_t e__ = (buf).alloc(bytes);                                    \
+    if (e__ != hipSuccess) { hip_fail(e__, "hipMalloc"); return CRX_ERR_ALLOC; } \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int crx_version(void) { return 100; }  // 0.1.0
+
+int crx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+const char* crx_last_error(void) { return g_err.c_str(); }
+
+void crx_ekf_default_params(crx_ekf_params* p) { if (p) p->dt = 0.1; }
+
+void crx_lqr_default_params(crx_lqr_params* p) {
+  if (!p) return;
+  p->dt = 0.1; p->L = 0.5; p->eps = 0.01f; p->maxiter = 150;
+}
+
+void crx_mpc_default_params(crx_mpc_params* p) {
+  if (!p) return;
+  p->dt = 0.2; p->wb = 2.5;
+  p->max_steer = 45.0 / 180 * 3.14159265358979323846;
+  p->max_accel = 1.0;
+  p->max_speed = 55.0 / 3.6; p->min_speed = -20.0 / 3.6;
+  p->r_a = 0.01; p->r_delta = 0.01; p->rd_a = 0.01; p->rd_delta = 1.0;
+  p->q_x = 1.0; p->q_y = 1.0; p->q_yaw = 0.5; p->q_v = 0.5;
+  p->tol = 1e-9; p->max_iter = 50;
+}
+
+// ---------------------------------------------------------------------------------------------
+// EKF
+// ---------------------------------------------------------------------------------------------
+int crx_motion_model_batch_dev(int n, const float* x, const float* u, float* x_out,
+                               const crx_ekf_params* prm, void* stream) {
+  if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::motion_model_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, x, u, x_out, prm ? prm->dt : 0.1);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_jacobF_batch_dev(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm,
+                         void* stream) {
+  if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::jacobF_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n, x, u, jF, prm ? prm->dt : 0.1);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_observation_model_batch_dev(int n, const float* x, float* z_out, void* stream) {
+  if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::observation_model_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, x, z_out);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_jacobH(float* jH_out) {
+  if (!jH_out) return fail(CRX_ERR_INVALID, "jacobH: NULL output");
+  // column-major 2x4: [[1,0,0,0],[0,1,0,0]]  — a constant; no arithmetic involved
+  const float h[8] = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+  std::memcpy(jH_out, h, sizeof(h));
+  return CRX_OK;
+}
+
+int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const float* u, const float* Q,
+                           const float* R, const crx_ekf_params* prm, void* stream) {
+  if (n < 0 || !Q || !R || (n && (!x || !P || !z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_step: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  hipLaunchKernelGGL(crx::ekf_step_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n, x, P, z, u, k);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u,
+                          float* x_hist, float* P_hist, const float* Q, const float* R,
+                          const crx_ekf_params* prm, void* stream) {
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  const dim3 grid(blocks_for(n, 64)), block(64);
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int D = 8;
+  if (x_hist && P_hist)
+    hipLaunchKernelGGL((crx::ekf_run_kernel<D, true, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
+  else if (x_hist)
+    hipLaunchKernelGGL((crx::ekf_run_kernel<D, true, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
+  else if (P_hist)
+    hipLaunchKernelGGL((crx::ekf_run_kernel<D, false, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
+  else
+    hipLaunchKernelGGL((crx::ekf_run_kernel<D, false, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue, float* xDR,
+                                const float* w, float* z, float* ud, float* xTrue_hist,
+                                float* xDR_hist, const float qsim[2], const float rsim[2],
+                                const crx_ekf_params* prm, void* stream) {
+  if (n < 0 || T < 0 || !qsim || !rsim || (n && (!u_true || !xTrue || !xDR)) || (n && T && (!w || !z || !ud)))
+    return fail(CRX_ERR_INVALID, "ekf_simulate_inputs: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const dim3 grid(blocks_for(n, 64)), block(64);
+  const double dt = prm ? prm->dt : 0.1;
+  if (xTrue_hist || xDR_hist)
+    hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<true>), grid, block, 0, (hipStream_t)stream, n, T,
+                       u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  else
+    hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<false>), grid, block, 0, (hipStream_t)stream, n, T,
+                       u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// ---- host-pointer variants (stage, launch, copy back, synchronise) ----------------------------
+int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out, const crx_ekf_params* prm) {
+  if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  DevBuf dx, du;
+  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(du, sizeof(float) * 2 * n);
+  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(du.p, u, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  if (int rc = crx_motion_model_batch_dev(n, dx.as<float>(), du.as<float>(), dx.as<float>(), prm, nullptr)) return rc;
+  CRX_HIP(hipMemcpy(x_out, dx.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm) {
+  if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  DevBuf dx, du, dj;
+  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(du, sizeof(float) * 2 * n); CRX_ALLOC(dj, sizeof(float) * 16 * n);
+  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(du.p, u, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  if (int rc = crx_jacobF_batch_dev(n, dx.as<float>(), du.as<float>(), dj.as<float>(), prm, nullptr)) return rc;
+  CRX_HIP(hipMemcpy(jF, dj.p, sizeof(float) * 16 * n, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_observation_model_batch(int n, const float* x, float* z_out) {
+  if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  DevBuf dx, dz;
+  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(dz, sizeof(float) * 2 * n);
+  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
+  if (int rc = crx_observation_model_batch_dev(n, dx.as<float>(), dz.as<float>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(z_out, dz.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_ekf_step_batch(int n, float* x, float* P, const float* z, const float* u, const float* Q,
+                       const float* R, const crx_ekf_params* prm) {
+  return crx_ekf_run_batch(n, 1, x, P, z, u, nullptr, nullptr, Q, R, prm);
+}
+
+int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
+                      float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const size_t nn = (size_t)n, tt = (size_t)T;
+  DevBuf dx, dP, dz, du, dxh, dPh;
+  CRX_ALLOC(dx, 16 * nn); CRX_ALLOC(dP, 64 * nn); CRX_ALLOC(dz, 8 * nn * tt); CRX_ALLOC(du, 8 * nn * tt);
+  if (x_hist) CRX_ALLOC(dxh, 16 * nn * tt);
+  if (P_hist) CRX_ALLOC(dPh, 64 * nn * tt);
+  CRX_HIP(hipMemcpy(dx.p, x, 16 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dP.p, P, 64 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dz.p, z, 8 * nn * tt, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(du.p, u, 8 * nn * tt, hipMemcpyHostToDevice));
+  int rc;
+  if (T == 1 && !x_hist && !P_hist)
+    rc = crx_ekf_step_batch_dev(n, dx.as<float>(), dP.as<float>(), dz.as<float>(), du.as<float>(), Q, R, prm, nullptr);
+  else
+    rc = crx_ekf_run_batch_dev(n, T, dx.as<float>(), dP.as<float>(), dz.as<float>(), du.as<float>(),
+                               x_hist ? dxh.as<float>() : nullptr, P_hist ? dPh.as<float>() : nullptr, Q, R, prm, nullptr);
+  if (rc) return rc;
+  CRX_HIP(hipMemcpy(x, dx.p, 16 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipMemcpy(P, dP.p, 64 * nn, hipMemcpyDeviceToHost));
+  if (x_hist) CRX_HIP(hipMemcpy(x_hist, dxh.p, 16 * nn * tt, hipMemcpyDeviceToHost));
+  if (P_hist) CRX_HIP(hipMemcpy(P_hist, dPh.p, 64 * nn * tt, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DARE / dlqr
+// ---------------------------------------------------------------------------------------------
+int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
+                       float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
+  if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
+    return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const dim3 grid(blocks_for(n, 64)), block(64);
+  if (dim == 5)
+    hipLaunchKernelGGL((crx::dare_dense_kernel<5>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
+  else
+    hipLaunchKernelGGL((crx::dare_dense_kernel<4>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                              int* iters, void* stream) {
+  if (n < 0 || (dim != 4 && dim != 5) || (n && !v))
+    return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_lqr_params p;
+  if (prm) p = *prm; else crx_lqr_default_params(&p);
+  const dim3 grid(blocks_for(n, 64)), block(64);
+  if (dim == 5)
+    hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+  else
+    hipLaunchKernelGGL((crx::dare_from_v_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* Q, const float* R, float eps,
+                   int maxiter, float* X, float* K, int* iters) {
+  if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
+    return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = n, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim;
+  DevBuf dA, dB, dQ, dR, dX, dK, dI;
+  CRX_ALLOC(dA, 4 * d2 * nn); CRX_ALLOC(dB, 4 * dim * m * nn); CRX_ALLOC(dQ, 4 * d2 * nn); CRX_ALLOC(dR, 4 * m * m * nn);
+  CRX_ALLOC(dX, 4 * d2 * nn); CRX_ALLOC(dK, 4 * dim * m * nn); CRX_ALLOC(dI, 4 * nn);
+  CRX_HIP(hipMemcpy(dA.p, A, 4 * d2 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dB.p, B, 4 * dim * m * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dQ.p, Q, 4 * d2 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dR.p, R, 4 * m * m * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_dare_batch_dev(n, dim, dA.as<float>(), dB.as<float>(), dQ.as<float>(), dR.as<float>(), eps, maxiter,
+                                  dX.as<float>(), dK.as<float>(), dI.as<int>(), nullptr)) return rc;
+  if (X) CRX_HIP(hipMemcpy(X, dX.p, 4 * d2 * nn, hipMemcpyDeviceToHost));
+  if (K) CRX_HIP(hipMemcpy(K, dK.p, 4 * dim * m * nn, hipMemcpyDeviceToHost));
+  if (iters) CRX_HIP(hipMemcpy(iters, dI.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipDeviceSynchronize());
+  return CRX_OK;
+}
+
+int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K, int* iters) {
+  if (n < 0 || (dim != 4 && dim != 5) || (n && !v))
+    return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = n, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim;
+  DevBuf dv, dX, dK, dI;
+  CRX_ALLOC(dv, 4 * nn); CRX_ALLOC(dX, 4 * d2 * nn); CRX_ALLOC(dK, 4 * dim * m * nn); CRX_ALLOC(dI, 4 * nn);
+  CRX_HIP(hipMemcpy(dv.p, v, 4 * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_dare_from_v_batch_dev(n, dim, dv.as<float>(), prm, dX.as<float>(), dK.as<float>(), dI.as<int>(), nullptr)) return rc;
+  if (X) CRX_HIP(hipMemcpy(X, dX.p, 4 * d2 * nn, hipMemcpyDeviceToHost));
+  if (K) CRX_HIP(hipMemcpy(K, dK.p, 4 * dim * m * nn, hipMemcpyDeviceToHost));
+  if (iters) CRX_HIP(hipMemcpy(iters, dI.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipDeviceSynchronize());
+  return CRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MPC
+// ---------------------------------------------------------------------------------------------
+int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                            float* sol, int* status, double* cost, void* stream) {
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream) == hipSuccess
+             ? CRX_OK
+             : hip_fail(hipGetLastError(), "mpc launch");
+}
+
+int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                        int* status, double* cost) {
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  DevBuf dx0, dxr, dsol, dst, dc;
+  CRX_ALLOC(dx0, 16 * nn); CRX_ALLOC(dxr, 16 * T * nn); CRX_ALLOC(dsol, 4 * nv * nn); CRX_ALLOC(dst, 4 * nn); CRX_ALLOC(dc, 8 * nn);
+  CRX_HIP(hipMemcpy(dx0.p, x0, 16 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dxr.p, xref, 16 * T * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_mpc_solve_batch_dev(n, T, dx0.as<float>(), dxr.as<float>(), prm, dsol.as<float>(), dst.as<int>(),
+                                       dc.as<double>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(sol, dsol.p, 4 * nv * nn, hipMemcpyDeviceToHost));
+  if (status) CRX_HIP(hipMemcpy(status, dst.p, 4 * nn, hipMemcpyDeviceToHost));
+  if (cost) CRX_HIP(hipMemcpy(cost, dc.p, 8 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipDeviceSynchronize());
+  return CRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// crx_trig.h — single-precision sine/cosine for the crx engine (host + gfx950 device).
+//
+// The reference evaluates std::cos(float)/std::sin(float) through glibc's libm
+// (/root/reference/src/extended_kalman_filter.cpp:30-31,42-45).  OCML's device sinf/cosf
+// round differently from glibc's in last-ulp cases, which would break bit parity between
+// the HIP path and the CPU oracle.  This header therefore carries ONE implementation of the
+// published algorithm glibc >= 2.28 uses for sinf/cosf (Szabolcs Nagy / Wilco Dijkstra,
+// "optimized-routines": double-precision minimax polynomials on [-pi/4, pi/4] after a
+// one-multiply range reduction; 192-bit 2/pi table for |x| >= 120).
+//
+// Flavour.  On x86-64 glibc dispatches sinf/cosf at run time (ifunc) to a build with FMA
+// contraction on every FMA-capable CPU, and to a plain SSE2 build otherwise; the two differ
+// on 34 of the 2^32 inputs.  This header writes the contraction out with explicit fma()
+// calls (CRX_TRIG_FMA=1, default; independent of -ffp-contract) and is bit-identical to
+// glibc 2.35's FMA variant on ALL 2^32 float inputs; with CRX_TRIG_FMA=0 it is bit-identical
+// to the SSE2 variant on all 2^32 inputs (tests/tools/trig_exhaustive.cpp walks the full
+// domain; tests/test_trig.py runs a strided subset plus the 34 discriminating inputs).
+//
+// Nothing in here touches memory besides two small constant tables.
+#pragma once
+#include <stdint.h>
+
+#ifndef CRX_TRIG_FMA
+#define CRX_TRIG_FMA 1
+#endif
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define CRX_HD __host__ __device__ __forceinline__
+#else
+#define CRX_HD static inline
+#endif
+
+namespace crx {
+
+// a*b + c with the glibc-variant's rounding: one rounding (fma) or two (mul then add).
+CRX_HD double mad_(double a, double b, double c) {
+#if CRX_TRIG_FMA
+  return __builtin_fma(a, b, c);
+#else
+  return a * b + c;
+#endif
+}
+
+CRX_HD uint32_t f32_bits(float x) {
+  union { float f; uint32_t u; } v; v.f = x; return v.u;
+}
+CRX_HD uint32_t abstop12(float x) { return (f32_bits(x) >> 20) & 0x7ffu; }
+
+// Polynomial / reduction constants (doubles written as hex literals so host and device
+// see the same bits).
+struct SinCosConsts {
+  // cosine polynomial c0..c4 in x^2, sine polynomial s1..s3 (x + x^3*s1 + x^5*s2 + x^7*s3)
+  static constexpr double c0 = 0x1p0;
+  static constexpr double c1 = -0x1.ffffffd0c621cp-2;
+  static constexpr double c2 = 0x1.55553e1068f19p-5;
+  static constexpr double c3 = -0x1.6c087e89a359dp-10;
+  static constexpr double c4 = 0x1.99343027bf8c3p-16;
+  static constexpr double s1 = -0x1.555545995a603p-3;
+  static constexpr double s2 = 0x1.1107605230bc4p-7;
+  static constexpr double s3 = -0x1.994eb3774cf24p-13;
+  static constexpr double hpi_inv = 0x1.45F306DC9C883p+23;  // 2/pi * 2^24
+  static constexpr double hpi = 0x1.921FB54442D18p0;        // pi/2
+  static constexpr double pi63 = 0x1.921FB54442D18p-62;     // 2*pi * 2^-64
+};
+
+// Evaluate sin (quadrant even) or cos (quadrant odd) polynomial; `neg` selects the negated
+// cosine polynomial (quadrants 2,3), exactly as negating every coefficient does.
+CRX_HD float sincos_poly(double x, double x2, int n, bool neg) {
+  typedef SinCosConsts C;
+  if ((n & 1) == 0) {
+    double x3 = x * x2;
+    double s1 = mad_(x2, C::s3, C::s2);
+    double x7 = x3 * x2;
+    double s = mad_(x3, C::s1, x);
+    return (float)mad_(x7, s1, s);
+  } else {
+    const double k0 = neg ? -C::c0 : C::c0;
+    const double k1 = neg ? -C::c1 : C::c1;
+    const double k2 = neg ? -C::c2 : C::c2;
+    const double k3 = neg ? -C::c3 : C::c3;
+    const double k4 = neg ? -C::c4 : C::c4;
+    double x4 = x2 * x2;
+    double c2 = mad_(x2, k4, k3);
+    double c1 = mad_(x2, k1, k0);
+    double x6 = x4 * x2;
+    double c = mad_(x4, k2, c1);
+    return (float)mad_(x6, c2, c);
+  }
+}
+
+CRX_HD double reduce_fast(double x, int* np) {
+  typedef SinCosConsts C;
+  double r = x * C::hpi_inv;
+  int n = ((int32_t)r + 0x800000) >> 24;
+  *np = n;
+  return mad_(-(double)n, C::hpi, x);
+}
+
+// 2/pi to 192 bits, 8 new bits per entry (entry i = 32-bit window ending at byte i).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const uint32_t kInvPio4[24] = {
+  0x000000a2u, 0x0000a2f9u, 0x00a2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u,
+  0x6e4e4415u, 0x4e441529u, 0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u,
+  0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u, 0x34ddc0dbu, 0xddc0db62u,
+  0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+
+CRX_HD double reduce_large(uint32_t xi, int* np) {
+  const uint32_t* arr = &kInvPio4[(xi >> 26) & 15];
+  int shift = (xi >> 23) & 7;
+  uint64_t n, res0, res1, res2;
+  xi = (xi & 0xffffffu) | 0x800000u;
+  xi <<= shift;
+  res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+  res1 = (uint64_t)xi * arr[4];
+  res2 = (uint64_t)xi * arr[8];
+  res0 = (res2 >> 32) | (res0 << 32);
+  res0 += res1;
+  n = (res0 + (1ULL << 61)) >> 62;
+  res0 -= n << 62;
+  double x = (double)(int64_t)res0;
+  *np = (int)n;
+  return x * SinCosConsts::pi63;
+}
+
+CRX_HD double quadrant_sign(int q) {  // {1,-1,-1,1}[q&3]
+  q &= 3;
+  return (q == 1 || q == 2) ? -1.0 : 1.0;
+}
+
+CRX_HD float sinf_(float y) {
+  double x = (double)y;
+  int n;
+  if (abstop12(y) < 0x3f4u) {                 // |y| < pi/4 (top12 of 0x1.921FB6p-1f)
+    double s = x * x;
+    if (abstop12(y) < 0x398u) return y;       // |y| < 2^-12
+    return sincos_poly(x, s, 0, false);
+  } else if (abstop12(y) < 0x42fu) {          // |y| < 120
+    x = reduce_fast(x, &n);
+    double s = quadrant_sign(n);
+    return sincos_poly(x * s, x * x, n, (n & 2) != 0);
+  } else if (abstop12(y) < 0x7f8u) {          // finite
+    uint32_t xi = f32_bits(y);
+    int sign = (int)(xi >> 31);
+    x = reduce_large(xi, &n);
+    double s = quadrant_sign(n + sign);
+    return sincos_poly(x * s, x * x, n, ((n + sign) & 2) != 0);
+  }
+  return y - y;                               // inf/nan -> nan
+}
+
+CRX_HD float cosf_(float y) {
+  double x = (double)y;
+  int n;
+  if (abstop12(y) < 0x3f4u) {
+    double x2 = x * x;
+    if (abstop12(y) < 0x398u) return 1.0f;
+    return sincos_poly(x, x2, 1, false);
+  } else if (abstop12(y) < 0x42fu) {
+    x = reduce_fast(x, &n);
+    double s = quadrant_sign(n);
+    return sincos_poly(x * s, x * x, n ^ 1, (n & 2) != 0);
+  } else if (abstop12(y) < 0x7f8u) {
+    uint32_t xi = f32_bits(y);
+    int sign = (int)(xi >> 31);
+    x = reduce_large(xi, &n);
+    double s = quadrant_sign(n + sign);
+    return sincos_poly(x * s, x * x, n ^ 1, ((n + sign) & 2) != 0);
+  }
+  return y - y;
+}
+
+// Both at once (shares the range reduction); results are identical to sinf_/cosf_.
+CRX_HD void sincosf_(float y, float* sp, float* cp) {
+  double x = (double)y;
+  int n;
+  bool neg;
+  double xs, x2;
+  if (abstop12(y) < 0x3f4u) {
+    if (abstop12(y) < 0x398u) { *sp = y; *cp = 1.0f; return; }
+    n = 0; neg = false; xs = x; x2 = x * x;
+  } else if (abstop12(y) < 0x42fu) {
+    x = reduce_fast(x, &n);
+    neg = (n & 2) != 0; xs = x * quadrant_sign(n); x2 = x * x;
+  } else if (abstop12(y) < 0x7f8u) {
+    uint32_t xi = f32_bits(y);
+    int sign = (int)(xi >> 31);
+    x = reduce_large(xi, &n);
+    neg = ((n + sign) & 2) != 0; xs = x * quadrant_sign(n + sign); x2 = x * x;
+  } else { *sp = y - y; *cp = y - y; return; }
+  *sp = sincos_poly(xs, x2, n, neg);
+  *cp = sincos_poly(xs, x2, n ^ 1, neg);
+}
+
+}  // namespace crx

@@ -1,0 +1,163 @@
+/* crx.h — C ABI of the crx engine: batched EKF / DARE-LQR / MPC for MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the hot path of onlytailei/CppRobotics.  The reference
+ * exposes no library and no FFI; its "API" for this path is a set of free functions living in
+ * the same translation unit as main().  Every entry point below names the reference function
+ * it replaces (paths relative to the reference checkout).  include/crx_dropin.hpp re-creates
+ * the reference's exact C++ signatures on top of this header.
+ *
+ * Conventions
+ *   - All matrices are column-major and densely packed, exactly what Eigen's fixed-size
+ *     `.data()` returns: M(i,j) = m[i + rows*j].
+ *   - "batch" = n independent agents.  Agent k's 4-vector starts at x + 4*k, its 4x4 at
+ *     P + 16*k, and so on (array-of-structures, i.e. a std::vector<Eigen::Matrix4f>).
+ *   - Functions ending in `_dev` take DEVICE pointers for all batched arrays and a HIP stream
+ *     (`void* stream` is a hipStream_t; NULL = the null stream); they only enqueue work.
+ *     Functions without the suffix take HOST pointers, copy in/out, and synchronise.
+ *   - Small per-launch constants (Q, R, params structs) are always HOST pointers.
+ *   - Return value: 0 on success, a negative crx_status otherwise (the reference has no error
+ *     channel at all; singular matrices silently produce inf/NaN there and here alike).
+ *   - There is no CPU fallback.  Without a HIP device every compute entry point returns
+ *     CRX_ERR_NO_DEVICE.
+ */
+#ifndef CRX_H_
+#define CRX_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum crx_status {
+  CRX_OK = 0,
+  CRX_ERR_INVALID = -1,    /* bad argument (n < 0, NULL pointer, unsupported dim, ...) */
+  CRX_ERR_NO_DEVICE = -2,  /* no HIP device / HIP runtime error at init               */
+  CRX_ERR_HIP = -3,        /* a HIP call failed; see crx_last_error()                 */
+  CRX_ERR_ALLOC = -4
+} crx_status;
+
+/* ---- runtime ------------------------------------------------------------------------- */
+int crx_version(void);                 /* 10000*major + 100*minor + patch                 */
+int crx_device_count(void);            /* number of HIP devices visible (0 if none)       */
+const char* crx_last_error(void);      /* thread-local, never NULL                        */
+
+/* ---- EKF localisation (src/extended_kalman_filter.cpp) --------------------------------- */
+typedef struct crx_ekf_params {
+  double dt;   /* `#define DT 0.1` (src/extended_kalman_filter.cpp:17); double on purpose:   */
+               /* the reference forms DT*cos(yaw) etc. in double before rounding to float.   */
+} crx_ekf_params;
+void crx_ekf_default_params(crx_ekf_params* p);
+
+/* motion_model(x,u)  src/extended_kalman_filter.cpp:22-36.  x_out may alias x. */
+int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out,
+                           const crx_ekf_params* prm);
+int crx_motion_model_batch_dev(int n, const float* x, const float* u, float* x_out,
+                               const crx_ekf_params* prm, void* stream);
+/* jacobF(x,u)  src/extended_kalman_filter.cpp:38-47.  jF: n x 16 col-major. */
+int crx_jacobF_batch(int n, const float* x, const float* u, float* jF,
+                     const crx_ekf_params* prm);
+int crx_jacobF_batch_dev(int n, const float* x, const float* u, float* jF,
+                         const crx_ekf_params* prm, void* stream);
+/* observation_model(x)  src/extended_kalman_filter.cpp:50-55.  z_out: n x 2. */
+int crx_observation_model_batch(int n, const float* x, float* z_out);
+int crx_observation_model_batch_dev(int n, const float* x, float* z_out, void* stream);
+/* jacobH()  src/extended_kalman_filter.cpp:57-62.  Writes the constant 2x4 (col-major, 8 floats). */
+int crx_jacobH(float* jH_out);
+
+/* ekf_estimation(xEst,PEst,z,u,Q,R)  src/extended_kalman_filter.cpp:64-78, n agents, one step.
+ * x (n x 4) and P (n x 16) are updated in place; z, u are n x 2; Q is 4x4, R is 2x2 (shared). */
+int crx_ekf_step_batch(int n, float* x, float* P, const float* z, const float* u,
+                       const float* Q, const float* R, const crx_ekf_params* prm);
+int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const float* u,
+                           const float* Q, const float* R, const crx_ekf_params* prm,
+                           void* stream);
+
+/* T consecutive ekf_estimation() calls per agent in ONE launch — the body of the reference's
+ * `while(time <= SIM_TIME)` loop (src/extended_kalman_filter.cpp:171-188) minus RNG/drawing.
+ * z, u are time-major [T][n][2]; x_hist (may be NULL) receives xEst after every step,
+ * time-major [T][n][4] (the reference's `hxEst.push_back(xEst)`, :187).
+ * P_hist (may be NULL) receives PEst after every step, [T][n][16]. */
+int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const float* u,
+                      float* x_hist, float* P_hist, const float* Q, const float* R,
+                      const crx_ekf_params* prm);
+int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u,
+                          float* x_hist, float* P_hist, const float* Q, const float* R,
+                          const crx_ekf_params* prm, void* stream);
+
+/* The input side of the reference's simulation loop (src/extended_kalman_filter.cpp:174-181):
+ *   ud = u + w[0:2]*diag(Qsim) ; xTrue = motion_model(xTrue,u) ; xDR = motion_model(xDR,ud) ;
+ *   z  = xTrue[0:2] + w[2:4]*diag(Rsim)
+ * with the caller supplying the standard-normal draws w [T][n][4] (the reference seeds from
+ * std::random_device, so no draw sequence of its own can be reproduced).
+ * u_true: n x 2.  xTrue, xDR: n x 4, updated in place.  Outputs z, ud: [T][n][2].
+ * xTrue_hist / xDR_hist ([T][n][4]) may be NULL.  qsim[2], rsim[2] are the diagonal entries
+ * Qsim(0,0),Qsim(1,1),Rsim(0,0),Rsim(1,1) (:154-161) as floats. */
+int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue, float* xDR,
+                                const float* w, float* z, float* ud, float* xTrue_hist,
+                                float* xDR_hist, const float qsim[2], const float rsim[2],
+                                const crx_ekf_params* prm, void* stream);
+
+/* ---- LQR: DARE fixed point + gain ------------------------------------------------------- */
+/* solve_DARE / dlqr, 5x5 state, 2 inputs: src/lqr_speed_steer_control.cpp:85-100, 102-106.
+ * solve_DARE / dlqr, 4x4 state, 1 input : src/lqr_steer_control.cpp:75-90, 92-96.
+ * dim selects the variant (5 -> B is 5x2, R is 2x2, K is 2x5; 4 -> B is 4x1, R is 1x1, K is 1x4).
+ * A: n x dim*dim, B: n x dim*m, Q: n x dim*dim, R: n x m*m  (per-agent matrices).
+ * Outputs (any may be NULL): X n x dim*dim, K n x m*dim, iters n (number of fixed-point
+ * evaluations performed; == maxiter when the cap was hit — the reference returns the most
+ * recent iterate in that case too, silently).
+ * eps / maxiter are the reference's locals `eps = 0.01`, `maxiter = 150`. */
+int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* Q,
+                   const float* R, float eps, int maxiter, float* X, float* K, int* iters);
+int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q,
+                       const float* R, float eps, int maxiter, float* X, float* K, int* iters,
+                       void* stream);
+
+typedef struct crx_lqr_params {
+  double dt;     /* `#define DT 0.1`  src/lqr_speed_steer_control.cpp:20 */
+  double L;      /* `#define L 0.5`   src/lqr_speed_steer_control.cpp:21 */
+  float eps;     /* 0.01              src/lqr_speed_steer_control.cpp:88 */
+  int maxiter;   /* 150               src/lqr_speed_steer_control.cpp:87 */
+} crx_lqr_params;
+void crx_lqr_default_params(crx_lqr_params* p);
+
+/* Same solve, but A and B are built on the fly from the vehicle speed exactly as
+ * lqr_steering_control() builds them (src/lqr_speed_steer_control.cpp:116-129 for dim 5,
+ * src/lqr_steer_control.cpp:104-115 for dim 4), with Q = I, R = I.  v: n floats. */
+int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X,
+                          float* K, int* iters);
+int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_params* prm,
+                              float* X, float* K, int* iters, void* stream);
+
+/* ---- MPC speed + steer (src/model_predictive_control.cpp) ------------------------------- */
+typedef struct crx_mpc_params {
+  double dt;         /* `#define DT 0.2`            :26 */
+  double wb;         /* `#define WB 2.5`            :36 */
+  double max_steer;  /* 45 deg                      :27 */
+  double max_accel;  /* 1.0                         :39 */
+  double max_speed;  /* 55/3.6                      :37 */
+  double min_speed;  /* -20/3.6                     :38 */
+  double r_a, r_delta;    /* 0.01, 0.01   input cost      :203-204 */
+  double rd_a, rd_delta;  /* 0.01, 1.0    input-rate cost :208-209 */
+  double q_x, q_y, q_yaw, q_v; /* 1, 1, 0.5, 0.5  tracking cost :247-250 */
+  double tol;        /* stop when the projected-gradient norm and the step are below tol */
+  int max_iter;      /* outer iteration cap (the reference: IPOPT max_iter 50, :326)     */
+} crx_mpc_params;
+void crx_mpc_default_params(crx_mpc_params* p);
+
+/* mpc_solve(State x0, M_XREF traj_ref)  src/model_predictive_control.cpp:255-346 for n agents.
+ * T = number of knot points (the reference's `#define T 6`; BASELINE's "N=20" is T = 21).
+ * x0: n x 4 (x,y,yaw,v).  xref: n x (4*T), each agent's block a column-major 4 x T matrix
+ * (Eigen::Matrix<float,NX,T>::data()).
+ * sol: n x (4T + 2(T-1)) floats in the reference's variable layout
+ *      [x(T) | y(T) | yaw(T) | v(T) | delta(T-1) | a(T-1)]   (:54-60, :341-345).
+ * status (may be NULL): per agent, bit0 = converged to tol, bit1 = speed bound was active
+ * (see DESIGN.md), bits 8.. = iterations used.  cost (may be NULL): final objective (double). */
+int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref,
+                        const crx_mpc_params* prm, float* sol, int* status, double* cost);
+int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,
+                            const crx_mpc_params* prm, float* sol, int* status, double* cost,
+                            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRX_H_ */

@@ -1,10 +1,416 @@
-// placeholder — replaced by the real solver below in this round
+// mpc_kernels.hip.h — batched speed+steer MPC horizon solve for gfx950 (one agent per lane, fp64).
+//
+// Replaces, for n independent agents at once, mpc_solve() of the reference
+//   (/root/reference/src/model_predictive_control.cpp:255-346), i.e. the NLP that FG_EVAL (:199-252)
+// defines: variables [x|y|yaw|v|delta|a], bicycle-model equality constraints (:242-245), input
+// and input-rate costs (:203-209), tracking cost (:247-250), box bounds (:288-301).
+// The reference hands that NLP to CppAD+IPOPT (double precision); crx solves the same NLP with a
+// solver of its own, built for one-problem-per-lane execution:
+//
+//   * single shooting — the equality constraints are eliminated by rolling the model forward,
+//     leaving the 2(T-1) controls as unknowns with their box bounds;
+//   * stage-wise Newton (control-limited DDP): a backward Riccati sweep over the T-1 stages on the
+//     state augmented by the previous control (the input-rate cost couples consecutive controls),
+//     exact second derivatives of the dynamics once Gauss-Newton steps have brought the iterate
+//     close, a 2-variable box QP per stage solved in closed form by enumerating its candidate
+//     minimisers, and a backtracking forward rollout;
+//   * all arithmetic in fp64 (IPOPT's precision), result rounded to float like the reference's
+//     `(float)solution.x[i]` (:343).
+//
+// The structure of the stage matrices is used throughout: with s = (x,y,yaw,v | d_prev,a_prev),
+//   F_s = [A 0; 0 0],  A = I + {a02,a03,a12,a13,a23},   F_u = [B; I],  B = {b_delta at (2,0), dt at (3,1)}
+// so no dense 6x6 product is ever formed.  oracle/mpc_ref.cpp is the plainly written dense CPU
+// twin of this algorithm; tests require agreement to 1e-6 and check optimality against scipy.
+//
+// Memory: trajectories, feed-forward and feedback gains of the lane's problem live in private
+// (scratch) memory, which the hardware interleaves across the 64 lanes, i.e. every access below
+// is a coalesced 512-byte wave access served from L1/L2; inputs are read once, the solution is
+// written once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/crx.h"
+
 #define CRX_MPC_MAX_T 64
+
 namespace crx {
-inline hipError_t mpc_launch(int, int, const float*, const float*, const crx_mpc_params&, float*, int*, double*, hipStream_t) {
-  return hipErrorNotSupported;
+
+struct MpcP {
+  double dt, wb, max_steer, max_accel, max_speed, min_speed;
+  double r_a, r_d, rd_a, rd_d, qx, qy, qyaw, qv, tol;
+  int max_iter;
+};
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// min 1/2 k'Hk + g'k over the box, H = [h00 hod; hod h11] possibly indefinite.  See file header.
+__device__ __forceinline__ void boxqp2(double h00, double hod, double h11, double g0, double g1, double lo0,
+                                       double hi0, double lo1, double hi1, double& k0, double& k1, bool& f0,
+                                       bool& f1) {
+  const double tiny = 1e-12;
+  const double det = h00 * h11 - hod * hod;
+  if (h00 > tiny && det > tiny * h00) {
+    const double a = -(h11 * g0 - hod * g1) / det;
+    const double b = -(-hod * g0 + h00 * g1) / det;
+    if (a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1) { k0 = a; k1 = b; f0 = true; f1 = true; return; }
+  }
+  double best = 1e300;
+  k0 = 0.0; k1 = 0.0; f0 = false; f1 = false;
+  auto consider = [&](double a, double b, bool fa, bool fb) {
+    const double obj = 0.5 * (h00 * a * a + 2.0 * hod * a * b + h11 * b * b) + g0 * a + g1 * b;
+    if (obj < best) { best = obj; k0 = a; k1 = b; f0 = fa; f1 = fb; }
+  };
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const double c0 = b ? hi0 : lo0;
+    if (h11 > tiny) {
+      const double t = -(g1 + hod * c0) / h11;
+      if (t >= lo1 && t <= hi1) consider(c0, t, false, true);
+    }
+    const double c1 = b ? hi1 : lo1;
+    if (h00 > tiny) {
+      const double t = -(g0 + hod * c1) / h00;
+      if (t >= lo0 && t <= hi0) consider(t, c1, true, false);
+    }
+  }
+#pragma unroll
+  for (int b0 = 0; b0 < 2; ++b0)
+#pragma unroll
+    for (int b1 = 0; b1 < 2; ++b1) consider(b0 ? hi0 : lo0, b1 ? hi1 : lo1, false, false);
 }
+
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+           float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  const size_t agent = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = agent < (size_t)n;
+  const size_t ag = live ? agent : 0;
+  const int N = T - 1;
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + ag * (size_t)T;
+
+  // per-lane problem storage (private memory)
+  double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
+  double U[2][MAXT][2];   // stages: delta, a
+  double kf[MAXT][2];     // feed-forward
+  double Kf[MAXT][12];    // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev)
+
+  const double dt = p.dt, wb = p.wb;
+  const double lb0 = -p.max_steer, ub0 = p.max_steer, lb1 = -p.max_accel, ub1 = p.max_accel;
+
+  // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
+  // rolls controls U[c] from x0 and returns fg[0]
+  auto track = [&](const double* s, int i) -> double {
+    const float4 r = xr4[i];
+    const double e0 = (double)r.x - s[0], e1 = (double)r.y - s[1], e2 = (double)r.z - s[2], e3 = (double)r.w - s[3];
+    return p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
+  };
+  auto ctrl = [&](int c, int i) -> double {
+    const double d = U[c][i][0], a = U[c][i][1];
+    double v = p.r_d * d * d + p.r_a * a * a;
+    if (i >= 1) {
+      const double dd = d - U[c][i - 1][0], da = a - U[c][i - 1][1];
+      v += p.rd_d * dd * dd + p.rd_a * da * da;
+    }
+    return v;
+  };
+  auto step = [&](const double* s, double d, double a, double* sn) {
+    double sn_, cs_;
+    sincos(s[2], &sn_, &cs_);
+    sn[0] = s[0] + s[3] * cs_ * dt;
+    sn[1] = s[1] + s[3] * sn_ * dt;
+    sn[2] = s[2] + s[3] * tan(d) / wb * dt;
+    sn[3] = s[3] + a * dt;
+  };
+
+  int cur = 0;
+  {
+    const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
+    S[0][0][0] = S[1][0][0] = (double)xi.x;
+    S[0][0][1] = S[1][0][1] = (double)xi.y;
+    S[0][0][2] = S[1][0][2] = (double)xi.z;
+    S[0][0][3] = S[1][0][3] = (double)xi.w;
+  }
+  double J = 0.0;
+  for (int i = 0; i < N; ++i) {          // zero initial guess (:266-269), rolled out
+    U[0][i][0] = 0.0; U[0][i][1] = 0.0;
+    J += ctrl(0, i);
+    if (i >= 1) J += track(S[0][i], i);
+    step(S[0][i], 0.0, 0.0, S[0][i + 1]);
+  }
+  J += track(S[0][N], N);
+
+  double mu = 0.0;
+  const double mu_min = 1e-6, mu_max = 1e10;
+  const int n_gn = 2;
+  int gn_left = n_gn;
+  int status = 0, it = 0;
+  bool done = !live;
+
+  for (int iter = 0; iter < p.max_iter; ++iter) {
+    if (__all(done)) break;
+    if (done) continue;
+    it = iter;
+    const bool exact = gn_left <= 0;
+    // ------------------------------------------------------------------ backward sweep
+    double lx[4], lp0, lp1;          // V_s
+    double Wxx[4][4], Wxp[4][2], Wpp00, Wpp01, Wpp11;  // V_ss (symmetric)
+    {
+      const float4 r = xr4[N];
+      const double* s = S[cur][N];
+      lx[0] = -2.0 * p.qx * ((double)r.x - s[0]);
+      lx[1] = -2.0 * p.qy * ((double)r.y - s[1]);
+      lx[2] = -2.0 * p.qyaw * ((double)r.z - s[2]);
+      lx[3] = -2.0 * p.qv * ((double)r.w - s[3]);
+      lp0 = 0.0; lp1 = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Wxx[a][b] = 0.0;
+        Wxp[a][0] = 0.0; Wxp[a][1] = 0.0;
+      }
+      Wxx[0][0] = 2.0 * p.qx; Wxx[1][1] = 2.0 * p.qy; Wxx[2][2] = 2.0 * p.qyaw; Wxx[3][3] = 2.0 * p.qv;
+      Wpp00 = 0.0; Wpp01 = 0.0; Wpp11 = 0.0;
+    }
+    double dV1 = 0.0, dV2 = 0.0, gnorm = 0.0;
+    for (int i = N - 1; i >= 0; --i) {
+      const double* s = S[cur][i];
+      const double ud = U[cur][i][0], ua = U[cur][i][1];
+      const bool inner = i >= 1;
+      const double pd = inner ? U[cur][i - 1][0] : 0.0, pa = inner ? U[cur][i - 1][1] : 0.0;
+      double sn_, cs_;
+      sincos(s[2], &sn_, &cs_);
+      const double v = s[3];
+      const double tn = tan(ud), sec2 = 1.0 + tn * tn;
+      const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn / wb * dt;
+      const double bd = v * sec2 / wb * dt;
+      // stage cost derivatives
+      double l_x[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
+      double l_u0 = 2.0 * p.r_d * ud, l_u1 = 2.0 * p.r_a * ua;
+      double l_uu0 = 2.0 * p.r_d, l_uu1 = 2.0 * p.r_a;
+      double l_p0 = 0.0, l_p1 = 0.0, l_pp0 = 0.0, l_pp1 = 0.0, l_up0 = 0.0, l_up1 = 0.0;
+      if (inner) {
+        const float4 r = xr4[i];
+        q2[0] = 2.0 * p.qx; q2[1] = 2.0 * p.qy; q2[2] = 2.0 * p.qyaw; q2[3] = 2.0 * p.qv;
+        l_x[0] = -q2[0] * ((double)r.x - s[0]);
+        l_x[1] = -q2[1] * ((double)r.y - s[1]);
+        l_x[2] = -q2[2] * ((double)r.z - s[2]);
+        l_x[3] = -q2[3] * ((double)r.w - s[3]);
+        const double dd = ud - pd, da = ua - pa;
+        l_u0 += 2.0 * p.rd_d * dd; l_u1 += 2.0 * p.rd_a * da;
+        l_p0 = -2.0 * p.rd_d * dd; l_p1 = -2.0 * p.rd_a * da;
+        l_uu0 += 2.0 * p.rd_d; l_uu1 += 2.0 * p.rd_a;
+        l_pp0 = 2.0 * p.rd_d; l_pp1 = 2.0 * p.rd_a;
+        l_up0 = -2.0 * p.rd_d; l_up1 = -2.0 * p.rd_a;
+      }
+      // Q_s, Q_u
+      double Qx[4];
+      Qx[0] = l_x[0] + lx[0];
+      Qx[1] = l_x[1] + lx[1];
+      Qx[2] = l_x[2] + (a02 * lx[0] + a12 * lx[1] + lx[2]);
+      Qx[3] = l_x[3] + (a03 * lx[0] + a13 * lx[1] + a23 * lx[2] + lx[3]);
+      const double Qp0 = l_p0, Qp1 = l_p1;
+      const double Qu0 = l_u0 + bd * lx[2] + lp0;
+      const double Qu1 = l_u1 + dt * lx[3] + lp1;
+      // M = Wxx*A ; Qxx = l_xx + A'*M
+      double M[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        M[a][0] = Wxx[a][0];
+        M[a][1] = Wxx[a][1];
+        M[a][2] = Wxx[a][0] * a02 + Wxx[a][1] * a12 + Wxx[a][2];
+        M[a][3] = Wxx[a][0] * a03 + Wxx[a][1] * a13 + Wxx[a][2] * a23 + Wxx[a][3];
+      }
+      double Qxx[4][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        Qxx[0][b] = M[0][b];
+        Qxx[1][b] = M[1][b];
+        Qxx[2][b] = a02 * M[0][b] + a12 * M[1][b] + M[2][b];
+        Qxx[3][b] = a03 * M[0][b] + a13 * M[1][b] + a23 * M[2][b] + M[3][b];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) Qxx[a][a] += q2[a];
+      // G = B'*Wxx + Wpx ; Qux = G*A ; Quu = l_uu + G*B + B'*Wxp + Wpp
+      double G[2][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        G[0][b] = bd * Wxx[2][b] + Wxp[b][0];
+        G[1][b] = dt * Wxx[3][b] + Wxp[b][1];
+      }
+      double Qux[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        Qux[a][0] = G[a][0];
+        Qux[a][1] = G[a][1];
+        Qux[a][2] = G[a][0] * a02 + G[a][1] * a12 + G[a][2];
+        Qux[a][3] = G[a][0] * a03 + G[a][1] * a13 + G[a][2] * a23 + G[a][3];
+      }
+      double Quu00 = l_uu0 + G[0][2] * bd + bd * Wxp[2][0] + Wpp00;
+      double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
+      double Quu10 = G[1][2] * bd + dt * Wxp[3][0] + Wpp01;
+      double Quu11 = l_uu1 + G[1][3] * dt + dt * Wxp[3][1] + Wpp11;
+      if (exact) {   // V_s . d2F
+        Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
+        const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
+        Qxx[2][3] += cross; Qxx[3][2] += cross;
+        Qux[0][3] += lx[2] * sec2 / wb * dt;
+        Quu00 += lx[2] * v / wb * dt * 2.0 * tn * sec2;
+      }
+      const double hod = 0.5 * (Quu01 + Quu10);
+      const double h00 = Quu00 + mu, h11 = Quu11 + mu;
+      double k0, k1; bool f0, f1;
+      boxqp2(h00, hod, h11, Qu0, Qu1, lb0 - ud, ub0 - ud, lb1 - ua, ub1 - ua, k0, k1, f0, f1);
+      // feedback K = -H_ff^-1 Q_us,f  over the 6 columns [Qux | l_up on the diagonal]
+      double Qus[2][6];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { Qus[0][b] = Qux[0][b]; Qus[1][b] = Qux[1][b]; }
+      Qus[0][4] = l_up0; Qus[0][5] = 0.0; Qus[1][4] = 0.0; Qus[1][5] = l_up1;
+      double K[2][6];
+      if (f0 && f1) {
+        const double det = h00 * h11 - hod * hod;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          K[0][b] = -(h11 * Qus[0][b] - hod * Qus[1][b]) / det;
+          K[1][b] = -(-hod * Qus[0][b] + h00 * Qus[1][b]) / det;
+        }
+      } else if (f0) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { K[0][b] = -Qus[0][b] / h00; K[1][b] = 0.0; }
+      } else if (f1) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { K[0][b] = 0.0; K[1][b] = -Qus[1][b] / h11; }
+      } else {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { K[0][b] = 0.0; K[1][b] = 0.0; }
+      }
+      kf[i][0] = k0; kf[i][1] = k1;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = K[0][b]; Kf[i][2 * b + 1] = K[1][b]; }
+      gnorm = fmax(gnorm, fmax(fabs(k0), fabs(k1)));
+      // expected change and value function (unregularised, symmetrised Quu)
+      const double Quuk0 = Quu00 * k0 + hod * k1, Quuk1 = hod * k0 + Quu11 * k1;
+      dV1 += k0 * Qu0 + k1 * Qu1;
+      dV2 += 0.5 * (k0 * Quuk0 + k1 * Quuk1);
+      double QuuK[2][6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        QuuK[0][b] = Quu00 * K[0][b] + hod * K[1][b];
+        QuuK[1][b] = hod * K[0][b] + Quu11 * K[1][b];
+      }
+      const double t0 = Quuk0 + Qu0, t1 = Quuk1 + Qu1;
+      double Vs[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const double qs = (b < 4) ? Qx[b < 4 ? b : 0] : (b == 4 ? Qp0 : Qp1);
+        Vs[b] = qs + (K[0][b] * t0 + K[1][b] * t1) + (Qus[0][b] * k0 + Qus[1][b] * k1);
+      }
+      double Vss[6][6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+          double qss;
+          if (a < 4 && b < 4) qss = 0.5 * (Qxx[a < 4 ? a : 0][b < 4 ? b : 0] + Qxx[b < 4 ? b : 0][a < 4 ? a : 0]);
+          else if (a == 4 && b == 4) qss = l_pp0;
+          else if (a == 5 && b == 5) qss = l_pp1;
+          else qss = 0.0;
+          const double tab = (K[0][a] * QuuK[0][b] + K[1][a] * QuuK[1][b]) + (K[0][a] * Qus[0][b] + K[1][a] * Qus[1][b]) +
+                             (Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b]);
+          const double tba = (K[0][b] * QuuK[0][a] + K[1][b] * QuuK[1][a]) + (K[0][b] * Qus[0][a] + K[1][b] * Qus[1][a]) +
+                             (Qus[0][b] * K[0][a] + Qus[1][b] * K[1][a]);
+          Vss[a][b] = qss + 0.5 * (tab + tba);
+        }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        lx[a] = Vs[a];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Wxx[a][b] = (a <= b) ? Vss[a][b] : Vss[b][a];
+        Wxp[a][0] = Vss[a][4]; Wxp[a][1] = Vss[a][5];
+      }
+      lp0 = Vs[4]; lp1 = Vs[5];
+      Wpp00 = Vss[4][4]; Wpp01 = Vss[4][5]; Wpp11 = Vss[5][5];
+    }
+    if (gnorm < p.tol && mu == 0.0) { status |= 1; done = true; continue; }
+    // ------------------------------------------------------------------ forward rollout + line search
+    const double aJ = fabs(J);
+    const double noise = 1e-12 * (aJ > 1.0 ? aJ : 1.0);
+    const bool trust = -(dV1 + dV2) < noise;
+    bool accepted = false;
+    double alpha = 1.0;
+    const int nxt = cur ^ 1;
+    for (int ls = 0; ls < 10; ++ls) {
+      double Jn = 0.0;
+      for (int i = 0; i < N; ++i) {
+        const double* s = S[cur][i];
+        double* sn = S[nxt][i];
+        const double d0 = sn[0] - s[0], d1 = sn[1] - s[1], d2 = sn[2] - s[2], d3 = sn[3] - s[3];
+        const double d4 = (i >= 1) ? U[nxt][i - 1][0] - U[cur][i - 1][0] : 0.0;
+        const double d5 = (i >= 1) ? U[nxt][i - 1][1] - U[cur][i - 1][1] : 0.0;
+        const double* Kc = Kf[i];
+        double du0 = alpha * kf[i][0];
+        du0 += Kc[0] * d0; du0 += Kc[2] * d1; du0 += Kc[4] * d2; du0 += Kc[6] * d3; du0 += Kc[8] * d4; du0 += Kc[10] * d5;
+        double du1 = alpha * kf[i][1];
+        du1 += Kc[1] * d0; du1 += Kc[3] * d1; du1 += Kc[5] * d2; du1 += Kc[7] * d3; du1 += Kc[9] * d4; du1 += Kc[11] * d5;
+        const double nd = clampd(U[cur][i][0] + du0, lb0, ub0);
+        const double na = clampd(U[cur][i][1] + du1, lb1, ub1);
+        U[nxt][i][0] = nd; U[nxt][i][1] = na;
+        Jn += ctrl(nxt, i);
+        if (i >= 1) Jn += track(sn, i);
+        step(sn, nd, na, S[nxt][i + 1]);
+      }
+      Jn += track(S[nxt][N], N);
+      if (Jn < J || (trust && Jn <= J + noise)) { J = Jn; accepted = true; break; }
+      alpha *= 0.5;
+    }
+    if (accepted) {
+      cur = nxt;
+      if (gn_left > 0) gn_left--;
+      if (alpha == 1.0) mu *= 0.1;
+      if (mu < mu_min) mu = 0.0;
+    } else if (exact) {
+      gn_left = n_gn;
+    } else {
+      mu = (mu * 10.0 > 1e-3) ? mu * 10.0 : 1e-3;
+      if (mu > mu_max) done = true;
+    }
+    if (iter == p.max_iter - 1) it = p.max_iter;
+  }
+  if (!live) return;
+  if (!(status & 1) && !done) it = p.max_iter;
+
+  const size_t nv = 4 * (size_t)T + 2 * (size_t)N;
+  float* __restrict__ so = solg + agent * nv;
+  for (int i = 0; i < T; ++i) {
+    const double v = S[cur][i][3];
+    if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
+    so[i] = (float)S[cur][i][0];
+    so[T + i] = (float)S[cur][i][1];
+    so[2 * T + i] = (float)S[cur][i][2];
+    so[3 * T + i] = (float)v;
+  }
+  for (int i = 0; i < N; ++i) {
+    so[4 * T + i] = (float)U[cur][i][0];
+    so[4 * T + N + i] = (float)U[cur][i][1];
+  }
+  if (statusg) statusg[agent] = status | (it << 8);
+  if (costg) costg[agent] = J;
 }
+
+inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                             int* status, double* cost, hipStream_t stream) {
+  MpcP p;
+  p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
+  p.max_speed = q.max_speed; p.min_speed = q.min_speed;
+  p.r_a = q.r_a; p.r_d = q.r_delta; p.rd_a = q.rd_a; p.rd_d = q.rd_delta;
+  p.qx = q.q_x; p.qy = q.q_y; p.qyaw = q.q_yaw; p.qv = q.q_v; p.tol = q.tol; p.max_iter = q.max_iter;
+  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  if (T <= 8)
+    hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  else if (T <= 24)
+    hipLaunchKernelGGL((mpc_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  else
+    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
+}
+
+}  // namespace crx

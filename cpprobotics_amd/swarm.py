@@ -1,0 +1,55 @@
+"""Multi-GPU sharding of a swarm of independent agents (one process per GPU, torch.distributed).
+
+Agents never read each other's state (reference: src/extended_kalman_filter.cpp:64-78,
+src/lqr_speed_steer_control.cpp:85-151, src/model_predictive_control.cpp:255-346), so the data
+path needs no collective: rank r owns the contiguous agent range shard_range(n, r, world).  The
+only exchange the system adds is the concatenation of per-rank results (estimated trajectories /
+final states) — one all-gather (RCCL over xGMI on GPUs; gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """Contiguous balanced partition: the first n % world ranks get one extra agent."""
+    base, rem = divmod(int(n), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_sizes(n, world):
+    return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+
+
+def gather_agents(local, n_total, group=None):
+    """All-gather per-agent rows.  `local` is [n_local, ...] on this rank (agent-major); returns
+    [n_total, ...] in global agent order on every rank.  Equal shards use one
+    all_gather_into_tensor (a single RCCL all-gather); ragged shards pad to the largest shard."""
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_total, world)
+    assert local.shape[0] == sizes[dist.get_rank(group)]
+    tail = tuple(local.shape[1:])
+    if len(set(sizes)) == 1:
+        out = torch.empty((n_total,) + tail, dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    m = max(sizes)
+    padded = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    buf = torch.empty((world * m,) + tail, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    return torch.cat([buf[r * m: r * m + sizes[r]] for r in range(world)], dim=0)
+
+
+def gather_time_major(local, n_total, group=None):
+    """All-gather a time-major history [T, n_local, C] into [T, n_total, C] (global agent order).
+    The wire format is the rank-major block layout [world][T][n_local][C] that a single
+    all-gather produces; the permutation back to time-major is a local copy."""
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_total, world)
+    T, nl, Cc = local.shape
+    if len(set(sizes)) != 1:
+        return gather_agents(local.transpose(0, 1).contiguous(), n_total, group).transpose(0, 1).contiguous()
+    buf = torch.empty((world, T, nl, Cc), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
+    return buf.permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()

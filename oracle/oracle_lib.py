@@ -146,3 +146,45 @@ def dare(A, B, Q, R, eps=0.01, maxiter=150, sum_order=0, agents=None):
                            _I(sum_order), _I(a0), _I(a1))
     assert rc == 0
     return X, K, it
+
+
+# ---- MPC ---------------------------------------------------------------------------------------
+import math as _math
+
+MPC_DEFAULTS = dict(dt=0.2, wb=2.5, max_steer=45.0 / 180 * _math.pi, max_accel=1.0, max_speed=55.0 / 3.6,
+                    min_speed=-20.0 / 3.6, r_a=0.01, r_delta=0.01, rd_a=0.01, rd_delta=1.0, q_x=1.0, q_y=1.0,
+                    q_yaw=0.5, q_v=0.5, tol=1e-9)
+_MPC_ORDER = ("dt", "wb", "max_steer", "max_accel", "max_speed", "min_speed", "r_a", "r_delta", "rd_a", "rd_delta",
+              "q_x", "q_y", "q_yaw", "q_v", "tol")
+
+
+def _mpc_params(overrides):
+    d = dict(MPC_DEFAULTS)
+    d.update(overrides or {})
+    return np.array([d[k] for k in _MPC_ORDER], dtype=np.float64)
+
+
+def mpc_solve(x0, xref, T, params=None, max_iter=50, agents=None):
+    """CPU twin of the engine's MPC solver.  Returns sol [n, 4T+2(T-1)], status [n], cost [n]."""
+    x0, xref = _f32(x0), _f32(xref)
+    n = x0.shape[0]
+    nv = 4 * T + 2 * (T - 1)
+    sol = np.zeros((n, nv), dtype=np.float32)
+    status = np.zeros((n,), dtype=np.int32)
+    cost = np.zeros((n,), dtype=np.float64)
+    pp = _mpc_params(params)
+    a0, a1 = (0, n) if agents is None else agents
+    lib().oracle_mpc_solve(_I(n), _I(T), _p(x0), _p(xref), _p(pp), _I(max_iter), _p(sol), _p(status), _p(cost), _I(a0), _I(a1))
+    return sol, status, cost
+
+
+def mpc_cost(x0, xref, T, U, params=None):
+    """NLP objective of ONE agent for controls U [(T-1),2] (delta, a); returns (J, S [(T),6])."""
+    x0, xref = _f32(x0), _f32(xref)
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    S = np.zeros((T, 6), dtype=np.float64)
+    pp = _mpc_params(params)
+    f = lib().oracle_mpc_cost
+    f.restype = _D
+    J = f(_I(T), _p(x0), _p(xref), _p(pp), _p(U), _p(S))
+    return float(J), S

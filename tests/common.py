@@ -53,3 +53,66 @@ def floored_rel_err(a, b, floor):
 def bit_equal(a, b):
     """Equality as IEEE values (+0 == -0), NaN never equal — the parity bar for fp32 paths."""
     return bool(np.array_equal(np.asarray(a), np.asarray(b)))
+
+
+# ---- MPC workload (C4) -----------------------------------------------------------------------------
+def natural_cubic_spline(s, y):
+    """Coefficients of the natural cubic spline the reference's Spline class builds
+    (/root/reference/include/cubic_spline.h:53-65, 95-116), in float64."""
+    s = np.asarray(s, dtype=np.float64); y = np.asarray(y, dtype=np.float64)
+    nx = len(s); h = np.diff(s)
+    A = np.zeros((nx, nx)); B = np.zeros(nx)
+    A[0, 0] = 1.0
+    for i in range(nx - 1):
+        if i != nx - 2:
+            A[i + 1, i + 1] = 2.0 * (h[i] + h[i + 1])
+        A[i + 1, i] = h[i]; A[i, i + 1] = h[i]
+    A[0, 1] = 0.0; A[nx - 1, nx - 2] = 0.0; A[nx - 1, nx - 1] = 1.0
+    for i in range(nx - 2):
+        B[i + 1] = 3.0 * (y[i + 2] - y[i + 1]) / h[i + 1] - 3.0 * (y[i + 1] - y[i]) / h[i]
+    c = np.linalg.solve(A, B)
+    d = (c[1:] - c[:-1]) / (3.0 * h)
+    b = (y[1:] - y[:-1]) / h - h * (c[1:] + 2.0 * c[:-1]) / 3.0
+    return s, y, b, c, d
+
+
+def _spline_eval(sp, t):
+    s, a, b, c, d = sp
+    i = np.clip(np.searchsorted(s, t, side="right") - 1, 0, len(s) - 2)
+    dx = t - s[i]
+    val = a[i] + b[i] * dx + c[i] * dx ** 2 + d[i] * dx ** 3
+    d1 = b[i] + 2 * c[i] * dx + 3 * d[i] * dx ** 2
+    return val, d1
+
+
+def mpc_course(ds=1.0):
+    """The reference's MPC course: Spline2D through its waypoints, sampled every ds
+    (/root/reference/src/model_predictive_control.cpp:469-486), speed profile 10 km/h (:488)."""
+    wx = [0.0, 60.0, 125.0, 50.0, 75.0, 35.0, -10.0]
+    wy = [0.0, 0.0, 50.0, 65.0, 30.0, 50.0, -20.0]
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(wx), np.diff(wy)))])
+    sx, sy = natural_cubic_spline(s, wx), natural_cubic_spline(s, wy)
+    t = np.arange(0.0, s[-1], ds)
+    cx, dx = _spline_eval(sx, t); cy, dy = _spline_eval(sy, t)
+    cyaw = np.unwrap(np.arctan2(dy, dx))                      # smooth_yaw (:172-185)
+    sp = np.full_like(cx, 10.0 / 3.6)
+    return cx, cy, cyaw, sp
+
+
+def mpc_problem(n, T, seed, dt=0.2, dl=1.0):
+    """n independent MPC problems: x0 = a course point + perturbation (lateral ~N(0,0.3 m), yaw ~N(0,5 deg),
+    v ~ U(0,4) m/s); xref by the calc_ref_trajectory rule (:130-170): xref(:,i) = course[ind + round(travel_i/dl)],
+    travel_i = (i+1)*|v|*DT, clamped to the last course point.  Returns x0 [n,4], xref [n,4*T] (column-major 4xT)."""
+    cx, cy, cyaw, sp = mpc_course(dl)
+    rng = np.random.default_rng(seed)
+    nc = len(cx)
+    ind = rng.integers(0, nc - 5, n)
+    lat = rng.normal(0.0, 0.3, n); dyaw = rng.normal(0.0, math.radians(5.0), n); v = rng.uniform(0.0, 4.0, n)
+    x0 = np.stack([cx[ind] - lat * np.sin(cyaw[ind]), cy[ind] + lat * np.cos(cyaw[ind]), cyaw[ind] + dyaw, v], axis=1)
+    x0 = x0.astype(np.float32)
+    xref = np.zeros((n, T, 4), dtype=np.float32)
+    for i in range(T):
+        travel = (i + 1) * np.abs(x0[:, 3].astype(np.float64)) * dt
+        j = np.minimum(ind + np.round(travel / dl).astype(np.int64), nc - 1)
+        xref[:, i, 0] = cx[j]; xref[:, i, 1] = cy[j]; xref[:, i, 2] = cyaw[j]; xref[:, i, 3] = sp[j]
+    return x0, xref.reshape(n, 4 * T)

@@ -50,6 +50,6 @@ def gather_time_major(local, n_total, group=None):
     T, nl, Cc = local.shape
     if len(set(sizes)) != 1:
         return gather_agents(local.transpose(0, 1).contiguous(), n_total, group).transpose(0, 1).contiguous()
-    buf = torch.empty((world, T, nl, Cc), dtype=local.dtype, device=local.device)
+    buf = torch.empty((world * T, nl, Cc), dtype=local.dtype, device=local.device)   # rank-major blocks
     dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
-    return buf.permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()
+    return buf.view(world, T, nl, Cc).permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()

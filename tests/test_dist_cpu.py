@@ -1,0 +1,80 @@
+"""World-size-2 (and 3, ragged) gloo tests of the swarm sharding / gather path on CPU.
+
+The per-shard compute here is the CPU oracle (test infrastructure) standing in for the HIP launch:
+what is under test is the partitioning and the collective — sharded result == unsharded result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, T, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from common import ekf_QR, ekf_agents, ekf_noise
+    from cpprobotics_amd import swarm
+    Q, R = ekf_QR()
+    u, x0, P0 = ekf_agents(n, 7)                 # global problem, keyed by global agent id
+    w = ekf_noise(T, n, 8)
+    lo, hi = swarm.shard_range(n, rank, world)
+    z, ud, _, _, _, _ = oracle.ekf_simulate_inputs(u[lo:hi], x0[lo:hi], x0[lo:hi], np.ascontiguousarray(w[:, lo:hi]))
+    x, P, xh, _ = oracle.ekf_run(x0[lo:hi], P0[lo:hi], z, ud, Q, R)
+    xg = swarm.gather_agents(torch.from_numpy(x), n)
+    hg = swarm.gather_time_major(torch.from_numpy(xh), n)
+    if rank == 0:
+        q.put((xg.numpy(), hg.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 33), (3, 50)])
+def test_sharded_equals_unsharded(world, n, oracle_mod):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import ekf_QR, ekf_agents, ekf_noise
+    T = 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    xg, hg = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    Q, R = ekf_QR()
+    u, x0, P0 = ekf_agents(n, 7)
+    w = ekf_noise(T, n, 8)
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
+    x, P, xh, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
+    assert np.array_equal(xg, x) and np.array_equal(hg, xh)
+
+
+def test_shard_range_partitions():
+    from cpprobotics_amd import swarm
+    for n in (0, 1, 7, 64, 65536, 1048576):
+        for world in (1, 2, 3, 8):
+            r = [swarm.shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1 and sizes == swarm.shard_sizes(n, world)

@@ -1,0 +1,119 @@
+"""Pinning the MPC twin by optimality: it must solve the reference's NLP (FG_EVAL, :199-252 with the
+bounds of :277-317) — checked against scipy.optimize on that NLP exactly as the reference poses it
+(simultaneous form: states and controls as variables, dynamics as equality constraints)."""
+import os
+
+import numpy as np
+import pytest
+
+from common import floored_rel_err, mpc_problem
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _slsqp(oracle_mod, x0, xref, T):
+    from scipy.optimize import minimize
+    P = oracle_mod.oracle_lib.MPC_DEFAULTS
+    N = T - 1
+    nv = 4 * T + 2 * N
+    xr = xref.reshape(T, 4).astype(np.float64)
+    dt, wb = P["dt"], P["wb"]
+    un = lambda z: (z[0:T], z[T:2 * T], z[2 * T:3 * T], z[3 * T:4 * T], z[4 * T:4 * T + N], z[4 * T + N:])
+
+    def pred(z):
+        x, y, yaw, v, d, a = un(z)
+        return (x[:-1] + v[:-1] * np.cos(yaw[:-1]) * dt, y[:-1] + v[:-1] * np.sin(yaw[:-1]) * dt,
+                yaw[:-1] + v[:-1] * np.tan(d) / wb * dt, v[:-1] + a * dt)
+
+    def f(z):
+        x, y, yaw, v, d, a = un(z)
+        px, py, pyaw, pv = pred(z)
+        return (0.01 * np.sum(a ** 2) + 0.01 * np.sum(d ** 2) + 0.01 * np.sum(np.diff(a) ** 2) + np.sum(np.diff(d) ** 2)
+                + np.sum((xr[1:, 0] - px) ** 2) + np.sum((xr[1:, 1] - py) ** 2)
+                + 0.5 * np.sum((xr[1:, 2] - pyaw) ** 2) + 0.5 * np.sum((xr[1:, 3] - pv) ** 2))
+
+    def g(z):
+        x, y, yaw, v, d, a = un(z)
+        px, py, pyaw, pv = pred(z)
+        return np.concatenate([[x[0] - x0[0], y[0] - x0[1], yaw[0] - x0[2], v[0] - x0[3]],
+                               x[1:] - px, y[1:] - py, yaw[1:] - pyaw, v[1:] - pv])
+    z0 = np.zeros(nv)
+    z0[0], z0[T], z0[2 * T], z0[3 * T] = x0
+    b = ([(-1e7, 1e7)] * (3 * T) + [(P["min_speed"], P["max_speed"])] * T
+         + [(-P["max_steer"], P["max_steer"])] * N + [(-P["max_accel"], P["max_accel"])] * N)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return minimize(f, z0, method="SLSQP", bounds=b, constraints=[{"type": "eq", "fun": g}],
+                        options=dict(maxiter=400, ftol=1e-14))
+
+
+def test_twin_solves_the_reference_nlp(oracle_mod):
+    """Reference horizon T=6: same optimum as SLSQP on the NLP as the reference writes it."""
+    T = 6
+    x0, xref = mpc_problem(8, T, seed=11)
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref, T)
+    assert np.all(st & 1)
+    for k in range(8):
+        r = _slsqp(oracle_mod, x0[k].astype(np.float64), xref[k], T)
+        assert abs(r.fun - cost[k]) <= 1e-8 * max(1.0, abs(cost[k]))
+        assert floored_rel_err(sol[k], r.x, 1.0) < 2e-5     # SLSQP uses finite-difference gradients
+
+
+def test_twin_long_horizon_cost_not_worse_than_slsqp(oracle_mod):
+    T = 21
+    x0, xref = mpc_problem(2, T, seed=12)
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref, T)
+    for k in range(2):
+        r = _slsqp(oracle_mod, x0[k].astype(np.float64), xref[k], T)
+        assert cost[k] <= r.fun + 1e-7 * max(1.0, abs(r.fun))
+
+
+def test_stationarity_and_bounds(oracle_mod):
+    """Projected gradient of the shooting objective (central differences on oracle_mpc_cost) vanishes at
+    the returned controls; controls respect their boxes; returned states are the rollout."""
+    T = 21
+    n = 40
+    x0, xref = mpc_problem(n, T, seed=13)
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref, T)
+    N = T - 1
+    lo = np.array([-np.pi / 4, -1.0]); hi = -lo
+    checked = 0
+    for k in range(n):
+        if not (st[k] & 1):
+            continue
+        U = np.stack([sol[k, 4 * T:4 * T + N], sol[k, 4 * T + N:]], axis=1).astype(np.float64)
+        # float32 rounding of the returned controls limits how stationary they can look
+        J0, S = oracle_mod.mpc_cost(x0[k], xref[k], T, U)
+        assert abs(J0 - cost[k]) < 1e-4 * max(1.0, cost[k])
+        assert np.allclose(S[:, 0], sol[k, :T], atol=2e-4) and np.allclose(S[:, 3], sol[k, 3 * T:4 * T], atol=1e-5)
+        gmax = 0.0
+        for i in range(N):
+            for j in range(2):
+                h = 1e-5
+                Up, Um = U.copy(), U.copy()
+                Up[i, j] += h; Um[i, j] -= h
+                gij = (oracle_mod.mpc_cost(x0[k], xref[k], T, Up)[0] - oracle_mod.mpc_cost(x0[k], xref[k], T, Um)[0]) / (2 * h)
+                at_lo, at_hi = U[i, j] <= lo[j] + 1e-6, U[i, j] >= hi[j] - 1e-6
+                if at_lo and gij > 0 or at_hi and gij < 0:
+                    continue      # bound active, multiplier has the right sign
+                gmax = max(gmax, abs(gij))
+        assert gmax < 5e-4, (k, gmax)
+        assert np.all(U >= lo - 1e-7) and np.all(U <= hi + 1e-7)
+        checked += 1
+        if checked >= 6:
+            break
+    assert checked >= 4
+
+
+def test_convergence_rate_and_golden(oracle_mod):
+    for T, need in ((6, 0.995), (21, 0.97)):
+        x0, xref = mpc_problem(1000, T, seed=T)
+        sol, st, cost = oracle_mod.mpc_solve(x0, xref, T)
+        assert (st & 1).mean() >= need
+        assert not np.any(st & 2)          # speed bounds never active on this workload
+    g = np.load(os.path.join(GOLD, "mpc_golden.npz"))
+    sol, st, cost = oracle_mod.mpc_solve(g["x0"], g["xref"], int(g["T"]))
+    ok = (st & 1) == 1
+    assert ok.mean() > 0.95
+    assert floored_rel_err(sol[ok], g["sol"][ok], 1.0) <= 1e-6

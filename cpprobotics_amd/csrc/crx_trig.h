@@ -172,26 +172,47 @@ CRX_HD float cosf_(float y) {
   return y - y;
 }
 
-// Both at once (shares the range reduction); results are identical to sinf_/cosf_.
+// Both at once, branch-free on the common path (|y| < 120): one range reduction, each polynomial
+// evaluated once, quadrant handled with selects.  Bit-identical to sinf_/cosf_ above: the sine
+// polynomial is odd in its argument and the "negated table" of the cosine polynomial is an exact
+// sign flip, so applying the quadrant sign after the polynomial commutes with every rounding.
 CRX_HD void sincosf_(float y, float* sp, float* cp) {
+  typedef SinCosConsts C;
+  const uint32_t top = abstop12(y);
   double x = (double)y;
-  int n;
-  bool neg;
-  double xs, x2;
-  if (abstop12(y) < 0x3f4u) {
-    if (abstop12(y) < 0x398u) { *sp = y; *cp = 1.0f; return; }
-    n = 0; neg = false; xs = x; x2 = x * x;
-  } else if (abstop12(y) < 0x42fu) {
+  int n, q;
+  if (top < 0x42fu) {                     // |y| < 120 (includes |y| < pi/4, where n == 0)
     x = reduce_fast(x, &n);
-    neg = (n & 2) != 0; xs = x * quadrant_sign(n); x2 = x * x;
-  } else if (abstop12(y) < 0x7f8u) {
-    uint32_t xi = f32_bits(y);
-    int sign = (int)(xi >> 31);
+    q = n;
+  } else if (top < 0x7f8u) {              // large finite argument: 192-bit 2/pi reduction
+    const uint32_t xi = f32_bits(y);
     x = reduce_large(xi, &n);
-    neg = ((n + sign) & 2) != 0; xs = x * quadrant_sign(n + sign); x2 = x * x;
+    q = n + (int)(xi >> 31);
   } else { *sp = y - y; *cp = y - y; return; }
-  *sp = sincos_poly(xs, x2, n, neg);
-  *cp = sincos_poly(xs, x2, n ^ 1, neg);
+  const double x2 = x * x;
+  // sine polynomial  x + x^3*s1 + x^7*(s2 + x^2*s3)   (operation order of sincos_poly)
+  const double x3 = x * x2;
+  const double s1 = mad_(x2, C::s3, C::s2);
+  const double x7 = x3 * x2;
+  const double sa = mad_(x3, C::s1, x);
+  const double S = mad_(x7, s1, sa);
+  // cosine polynomial (c0 + x^2*c1) + x^4*c2 + x^6*(c3 + x^2*c4)
+  const double x4 = x2 * x2;
+  const double c2 = mad_(x2, C::c4, C::c3);
+  const double c1 = mad_(x2, C::c1, C::c0);
+  const double x6 = x4 * x2;
+  const double ca = mad_(x4, C::c2, c1);
+  const double Cv = mad_(x6, c2, ca);
+  const bool neg_s = ((q + 1) & 2) != 0;  // sign {1,-1,-1,1}[q&3] of the sine branch
+  const bool neg_c = (q & 2) != 0;        // negated cosine table for quadrants 2,3
+  const float fs = (float)(neg_s ? -S : S);
+  const float fc = (float)(neg_c ? -Cv : Cv);
+  const bool odd = (n & 1) != 0;
+  float so = odd ? fc : fs;
+  float co = odd ? fs : fc;
+  if (top < 0x398u) { so = y; co = 1.0f; }  // |y| < 2^-12: sinf returns y, cosf returns 1
+  *sp = so;
+  *cp = co;
 }
 
 }  // namespace crx

@@ -188,7 +188,24 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
   EkfState s;
   load_state(s, x, P, a);
 
-  for (int t0 = 0; t0 < T; t0 += D) {
+  // main part: every chunk of D steps whose prefetches (t + D) stay inside [0, T) — no guards, one
+  // basic block per chunk, so the compiler can keep all D loads in flight (counted vmcnt waits)
+  int t0 = 0;
+  for (; t0 + 2 * D <= T; t0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int t = t0 + d;
+      const v2f zc = zq[d], uc = uq[d];
+      zq[d] = __builtin_nontemporal_load(&z2[(size_t)(t + D) * n + a]);
+      uq[d] = __builtin_nontemporal_load(&u2[(size_t)(t + D) * n + a]);
+      ekf_step_dev(s, zc.x, zc.y, uc.x, uc.y, k);
+      if (XHIST)
+        __builtin_nontemporal_store(v4f{s.x0, s.x1, s.x2, s.x3}, &xh[(size_t)t * n + a]);
+      if (PHIST) store_P(s, P_hist, (size_t)t * n + a);
+    }
+  }
+  // tail: fewer than 2*D steps left
+  for (; t0 < T; t0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int t = t0 + d;

@@ -59,7 +59,8 @@ EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcrx.so")
+    # CRX_LIB_PATH: developer override used for A/B-ing alternative builds of the same ABI
+    return os.environ.get("CRX_LIB_PATH") or os.path.join(_HERE, "libcrx.so")
 
 
 _lib = None

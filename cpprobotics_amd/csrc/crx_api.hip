@@ -159,7 +159,10 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
   const crx::EkfConsts k = make_consts(Q, R, prm);
   const dim3 grid(blocks_for(n, 64)), block(64);
   hipStream_t s = (hipStream_t)stream;
-  constexpr int D = 8;
+#ifndef CRX_EKF_PREFETCH
+#define CRX_EKF_PREFETCH 4
+#endif
+  constexpr int D = CRX_EKF_PREFETCH;
   if (x_hist && P_hist)
     hipLaunchKernelGGL((crx::ekf_run_kernel<D, true, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
   else if (x_hist)

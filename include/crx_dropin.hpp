@@ -1,0 +1,159 @@
+// crx_dropin.hpp — the reference's own C++ call signatures on top of the crx C ABI (include/crx.h).
+//
+// The reference (onlytailei/CppRobotics) defines its hot-path functions as free functions in the
+// same translation unit as main().  To switch a reference executable to the MI355X engine, delete
+// those function bodies and include this header instead (INTEGRATION.md shows the exact lines):
+//
+//   src/extended_kalman_filter.cpp:22-78   motion_model, jacobF, observation_model, jacobH, ekf_estimation
+//   src/lqr_speed_steer_control.cpp:85-106 solve_DARE (5x5), dlqr (5x5)
+//   src/lqr_steer_control.cpp:75-96        solve_DARE (4x4), dlqr (4x4)
+//   src/model_predictive_control.cpp:255-346 mpc_solve
+//
+// Every function forwards `.data()` pointers (Eigen fixed-size matrices are column-major and
+// contiguous, exactly the ABI's layout) with n = 1 through the host-pointer entry points, which copy
+// to the GPU, launch, and copy back — a faithful but slow single-agent path.  The fast path is the
+// batched one: crx_dropin::Batch* helpers below, or the C ABI directly.
+//
+// With <Eigen/Eigen> present the signatures are the reference's verbatim (Eigen::Vector4f ...).
+// Without Eigen (this build image has none) the same names bind to crx::Mat<R,C>, a minimal
+// column-major stand-in with the members the reference code uses (operator(), data(), <<-free).
+#pragma once
+#include <array>
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "crx.h"
+
+#if defined(CRX_DROPIN_USE_EIGEN) || (!defined(CRX_DROPIN_NO_EIGEN) && defined(__has_include))
+#if defined(CRX_DROPIN_USE_EIGEN) || __has_include(<Eigen/Eigen>)
+#include <Eigen/Eigen>
+#define CRX_DROPIN_HAVE_EIGEN 1
+#endif
+#endif
+
+namespace crx {
+
+#ifdef CRX_DROPIN_HAVE_EIGEN
+template <int R, int C> using Mat = Eigen::Matrix<float, R, C>;
+#else
+// Column-major fixed-size float matrix: M(i,j) = d[i + R*j]  (Eigen's default storage order).
+template <int R, int C>
+struct Mat {
+  float d[R * C];
+  Mat() : d{} {}
+  float& operator()(int i, int j) { return d[i + R * j]; }
+  float operator()(int i, int j) const { return d[i + R * j]; }
+  float& operator()(int i) { return d[i]; }          // vectors
+  float operator()(int i) const { return d[i]; }
+  float* data() { return d; }
+  const float* data() const { return d; }
+  static Mat Zero() { return Mat(); }
+  static Mat Identity() { Mat m; for (int i = 0; i < (R < C ? R : C); ++i) m(i, i) = 1.0f; return m; }
+};
+#endif
+
+inline void dropin_check(int rc, const char* what) {
+  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + crx_last_error());
+}
+
+}  // namespace crx
+
+// Types the reference's sources name.  (Its MPC file also does `#define T 6`; the horizon is a
+// template parameter here.)
+namespace cpprobotics {
+#ifndef _CPPROBOTICS_TYPES_H
+using Vec_f = std::vector<float>;
+using Poi_f = std::array<float, 2>;
+#endif
+#ifndef _MOTION_MODEL_H
+struct State {          // include/motion_model.h:31-42
+  float x, y, yaw, v;
+  State(float x_, float y_, float yaw_, float v_) : x(x_), y(y_), yaw(yaw_), v(v_) {}
+};
+#endif
+}  // namespace cpprobotics
+
+#ifndef CRX_DROPIN_NO_GLOBAL_NAMES
+// ---- src/extended_kalman_filter.cpp -----------------------------------------------------------------
+inline crx::Mat<4, 1> motion_model(crx::Mat<4, 1> x, crx::Mat<2, 1> u) {                        // :22
+  crx::Mat<4, 1> out;
+  crx::dropin_check(crx_motion_model_batch(1, x.data(), u.data(), out.data(), nullptr), "motion_model");
+  return out;
+}
+inline crx::Mat<4, 4> jacobF(crx::Mat<4, 1> x, crx::Mat<2, 1> u) {                              // :38
+  crx::Mat<4, 4> jF;
+  crx::dropin_check(crx_jacobF_batch(1, x.data(), u.data(), jF.data(), nullptr), "jacobF");
+  return jF;
+}
+inline crx::Mat<2, 1> observation_model(crx::Mat<4, 1> x) {                                     // :50
+  crx::Mat<2, 1> z;
+  crx::dropin_check(crx_observation_model_batch(1, x.data(), z.data()), "observation_model");
+  return z;
+}
+inline crx::Mat<2, 4> jacobH() {                                                                // :57
+  crx::Mat<2, 4> h;
+  crx::dropin_check(crx_jacobH(h.data()), "jacobH");
+  return h;
+}
+inline void ekf_estimation(crx::Mat<4, 1>& xEst, crx::Mat<4, 4>& PEst, crx::Mat<2, 1> z, crx::Mat<2, 1> u,
+                           crx::Mat<4, 4> Q, crx::Mat<2, 2> R) {                                // :64-66
+  crx::dropin_check(crx_ekf_step_batch(1, xEst.data(), PEst.data(), z.data(), u.data(), Q.data(), R.data(), nullptr),
+                    "ekf_estimation");
+}
+
+// ---- src/lqr_speed_steer_control.cpp (5x5, two inputs) ----------------------------------------------
+inline crx::Mat<5, 5> solve_DARE(crx::Mat<5, 5> A, crx::Mat<5, 2> B, crx::Mat<5, 5> Q, crx::Mat<2, 2> R) {   // :85
+  crx::Mat<5, 5> X;
+  crx::dropin_check(crx_dare_batch(1, 5, A.data(), B.data(), Q.data(), R.data(), 0.01f, 150, X.data(), nullptr, nullptr),
+                    "solve_DARE");
+  return X;
+}
+inline crx::Mat<2, 5> dlqr(crx::Mat<5, 5> A, crx::Mat<5, 2> B, crx::Mat<5, 5> Q, crx::Mat<2, 2> R) {         // :102
+  crx::Mat<2, 5> K;
+  crx::dropin_check(crx_dare_batch(1, 5, A.data(), B.data(), Q.data(), R.data(), 0.01f, 150, nullptr, K.data(), nullptr),
+                    "dlqr");
+  return K;
+}
+// ---- src/lqr_steer_control.cpp (4x4, one input, scalar R) -------------------------------------------
+inline crx::Mat<4, 4> solve_DARE(crx::Mat<4, 4> A, crx::Mat<4, 1> B, crx::Mat<4, 4> Q, float R) {            // :75
+  crx::Mat<4, 4> X;
+  crx::dropin_check(crx_dare_batch(1, 4, A.data(), B.data(), Q.data(), &R, 0.01f, 150, X.data(), nullptr, nullptr),
+                    "solve_DARE");
+  return X;
+}
+inline crx::Mat<1, 4> dlqr(crx::Mat<4, 4> A, crx::Mat<4, 1> B, crx::Mat<4, 4> Q, float R) {                  // :92
+  crx::Mat<1, 4> K;
+  crx::dropin_check(crx_dare_batch(1, 4, A.data(), B.data(), Q.data(), &R, 0.01f, 150, nullptr, K.data(), nullptr), "dlqr");
+  return K;
+}
+
+// ---- src/model_predictive_control.cpp -----------------------------------------------------------------
+// mpc_solve(State x0, M_XREF traj_ref) :255, M_XREF = Matrix<float, NX, T>.  Returns all
+// 4*T + 2*(T-1) variables in the reference's layout [x|y|yaw|v|delta|a] (:54-60, :341-345).
+template <int T_>
+inline cpprobotics::Vec_f mpc_solve(cpprobotics::State x0, crx::Mat<4, T_> traj_ref) {
+  const float x0v[4] = {x0.x, x0.y, x0.yaw, x0.v};
+  cpprobotics::Vec_f result(4 * T_ + 2 * (T_ - 1));
+  crx::dropin_check(crx_mpc_solve_batch(1, T_, x0v, traj_ref.data(), nullptr, result.data(), nullptr, nullptr), "mpc_solve");
+  return result;
+}
+#endif  // CRX_DROPIN_NO_GLOBAL_NAMES
+
+// ---- batched C++ helpers: the way to actually use the engine from C++ ---------------------------------
+namespace crx_dropin {
+
+// n vehicles stored as std::vector of fixed-size matrices (contiguous: the ABI's layout).
+inline void ekf_estimation_batch(std::vector<crx::Mat<4, 1>>& xEst, std::vector<crx::Mat<4, 4>>& PEst,
+                                 const std::vector<crx::Mat<2, 1>>& z, const std::vector<crx::Mat<2, 1>>& u,
+                                 const crx::Mat<4, 4>& Q, const crx::Mat<2, 2>& R) {
+  static_assert(sizeof(crx::Mat<4, 4>) == 64 && sizeof(crx::Mat<4, 1>) == 16 && sizeof(crx::Mat<2, 1>) == 8,
+                "fixed-size matrices must be densely packed");
+  const int n = (int)xEst.size();
+  if ((int)PEst.size() != n || (int)z.size() != n || (int)u.size() != n) throw std::invalid_argument("batch size mismatch");
+  crx::dropin_check(crx_ekf_step_batch(n, xEst[0].data(), PEst[0].data(), z[0].data(), u[0].data(), Q.data(), R.data(), nullptr),
+                    "ekf_estimation_batch");
+}
+
+}  // namespace crx_dropin

@@ -1,0 +1,60 @@
+// dropin_demo.cpp — the reference's call sites, compiled against include/crx_dropin.hpp.
+// Mirrors: the EKF loop body (src/extended_kalman_filter.cpp:171-183) with fixed inputs instead of the
+// random_device draws; lqr_steering_control()'s dlqr call (src/lqr_speed_steer_control.cpp:116-132,
+// src/lqr_steer_control.cpp:104-118); mpc_simulation()'s mpc_solve call (src/model_predictive_control.cpp:374).
+// Prints every result as hex floats so the GPU test can compare bit-for-bit with the oracle.
+#include <cmath>
+#include <cstdio>
+#include "crx_dropin.hpp"
+
+using crx::Mat;
+
+static void dump(const char* name, const float* p, int n) {
+  std::printf("%s", name);
+  for (int i = 0; i < n; ++i) std::printf(" %a", (double)p[i]);
+  std::printf("\n");
+}
+
+int main() {
+  // ---- EKF: 5 steps of the reference loop, deterministic "noise"
+  Mat<2, 1> u; u(0) = 1.0f; u(1) = 0.1f;
+  Mat<4, 1> xEst, xTrue;
+  Mat<4, 4> PEst = Mat<4, 4>::Identity();
+  Mat<4, 4> Q = Mat<4, 4>::Identity();
+  Q(0, 0) = 0.1 * 0.1; Q(1, 1) = 0.1 * 0.1; Q(2, 2) = (1.0 / 180 * M_PI) * (1.0 / 180 * M_PI); Q(3, 3) = 0.1 * 0.1;
+  Mat<2, 2> R = Mat<2, 2>::Identity();
+  for (int t = 0; t < 5; ++t) {
+    Mat<2, 1> ud; ud(0) = u(0) + 0.05f * (t - 2); ud(1) = u(1) - 0.01f * t;
+    xTrue = motion_model(xTrue, u);
+    Mat<2, 1> z; z(0) = xTrue(0) + 0.1f * (t % 3 - 1); z(1) = xTrue(1) - 0.07f * (t % 2);
+    ekf_estimation(xEst, PEst, z, ud, Q, R);
+    dump("ekf_x", xEst.data(), 4);
+    dump("ekf_P", PEst.data(), 16);
+  }
+  dump("jacobF", jacobF(xEst, u).data(), 16);
+  dump("obs", observation_model(xEst).data(), 2);
+  dump("jacobH", jacobH().data(), 8);
+
+  // ---- LQR 5x5 and 4x4 at v = 2.5
+  const float v = 2.5f, DT = 0.1, L = 0.5;
+  Mat<5, 5> A5 = Mat<5, 5>::Zero();
+  A5(0, 0) = 1.0; A5(0, 1) = DT; A5(1, 2) = v; A5(2, 2) = 1.0; A5(2, 3) = DT; A5(4, 4) = 1.0;
+  Mat<5, 2> B5 = Mat<5, 2>::Zero();
+  B5(3, 0) = v / 0.5; B5(4, 1) = DT;
+  dump("X5", solve_DARE(A5, B5, Mat<5, 5>::Identity(), Mat<2, 2>::Identity()).data(), 25);
+  dump("K5", dlqr(A5, B5, Mat<5, 5>::Identity(), Mat<2, 2>::Identity()).data(), 10);
+  Mat<4, 4> A4 = Mat<4, 4>::Zero();
+  A4(0, 0) = 1.0; A4(0, 1) = DT; A4(1, 2) = v; A4(2, 2) = 1.0; A4(2, 3) = DT;
+  Mat<4, 1> B4 = Mat<4, 1>::Zero();
+  B4(3) = v / L;
+  dump("X4", solve_DARE(A4, B4, Mat<4, 4>::Identity(), 1.0f).data(), 16);
+  dump("K4", dlqr(A4, B4, Mat<4, 4>::Identity(), 1.0f).data(), 4);
+
+  // ---- MPC, reference horizon T = 6: straight reference along x at 10 km/h
+  cpprobotics::State s0(0.0f, 0.3f, 0.05f, 2.0f);
+  Mat<4, 6> xref;
+  for (int i = 0; i < 6; ++i) { xref(0, i) = 0.5f * (i + 1); xref(1, i) = 0.0f; xref(2, i) = 0.0f; xref(3, i) = 10.0f / 3.6f; }
+  cpprobotics::Vec_f sol = mpc_solve<6>(s0, xref);
+  dump("mpc", sol.data(), (int)sol.size());
+  return 0;
+}

@@ -1,0 +1,67 @@
+"""include/crx_dropin.hpp: the reference's C++ signatures over the C ABI (compiled with g++, no Eigen here)."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def demo(tmp_path_factory, crx):
+    exe = str(tmp_path_factory.mktemp("dropin") / "dropin_demo")
+    libdir = os.path.join(ROOT, "cpprobotics_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir, "-lcrx",
+                           f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
+    return exe
+
+
+def test_dropin_compiles_and_fails_loudly_without_gpu(demo):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([demo], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+def _parse(out):
+    res = {}
+    for line in out.strip().splitlines():
+        k, *vals = line.split()
+        res.setdefault(k, []).append(np.array([float.fromhex(v) for v in vals], dtype=np.float32))
+    return res
+
+
+@pytest.mark.gpu
+def test_dropin_matches_oracle(demo, oracle_mod):
+    r = subprocess.run([demo], capture_output=True, text=True, check=True)
+    got = _parse(r.stdout)
+    f32 = np.float32
+    # replay the demo's inputs through the oracle
+    u = np.array([[1.0, 0.1]], f32)
+    Q = np.zeros((4, 4), f32); Q[0, 0] = f32(0.1 * 0.1); Q[1, 1] = f32(0.1 * 0.1)
+    Q[2, 2] = f32((1.0 / 180 * math.pi) ** 2); Q[3, 3] = f32(0.1 * 0.1)
+    Qc, Rc = Q.T.reshape(-1), np.eye(2, dtype=f32).reshape(-1)
+    x, P, xt = np.zeros((1, 4), f32), np.eye(4, dtype=f32).reshape(1, 16), np.zeros((1, 4), f32)
+    for t in range(5):
+        ud = np.array([[f32(1.0) + f32(0.05) * f32(t - 2), f32(0.1) - f32(0.01) * f32(t)]], f32)
+        xt = oracle_mod.motion_model(xt, u)
+        z = np.array([[xt[0, 0] + f32(0.1) * f32(t % 3 - 1), xt[0, 1] - f32(0.07) * f32(t % 2)]], f32)
+        x, P = oracle_mod.ekf_step(x, P, z, ud, Qc, Rc)
+        assert np.array_equal(got["ekf_x"][t], x[0]) and np.array_equal(got["ekf_P"][t], P[0])
+    assert np.array_equal(got["jacobF"][0], oracle_mod.jacobF(x, u)[0])
+    assert np.array_equal(got["obs"][0], x[0, :2]) and np.array_equal(got["jacobH"][0], oracle_mod.jacobH())
+    v = np.array([2.5], f32)
+    for dim in (5, 4):
+        A, B, Qm, Rm = oracle_mod.lqr_build(v, dim)
+        X, K, it = oracle_mod.dare(A, B, Qm, Rm)
+        assert np.array_equal(got[f"X{dim}"][0], X[0]) and np.array_equal(got[f"K{dim}"][0], K[0])
+    x0 = np.array([[0.0, 0.3, 0.05, 2.0]], f32)
+    xref = np.zeros((6, 4), f32)
+    xref[:, 0] = f32(0.5) * np.arange(1, 7, dtype=f32); xref[:, 3] = f32(10.0) / f32(3.6)
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref.reshape(1, 24), 6)
+    assert st[0] & 1
+    assert np.max(np.abs(got["mpc"][0] - sol[0]) / np.maximum(np.abs(sol[0]), 1.0)) <= 1e-6

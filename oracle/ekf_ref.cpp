@@ -120,17 +120,22 @@ void oracle_ekf_run(int n, int T, float* x, float* P, const float* z, const floa
                     int trig_mode, int sum_order, int a0, int a1) {
   Mat<4, 4> Qm = load<4, 4>(Q);
   Mat<2, 2> Rm = load<2, 2>(R);
-  for (int k = a0; k < a1; ++k) {
-    Mat<4, 1> xe = load<4, 1>(x + 4 * k);
-    Mat<4, 4> Pe = load<4, 4>(P + 16 * k);
-    for (int t = 0; t < T; ++t) {
-      size_t o = (size_t)t * n + k;
-      ekf_estimation(xe, Pe, load<2, 1>(z + 2 * o), load<2, 1>(u + 2 * o), Qm, Rm, dt, trig_mode, (SumOrder)sum_order);
-      if (x_hist) store(x_hist + 4 * o, xe);
-      if (P_hist) store(P_hist + 16 * o, Pe);
-    }
-    store(x + 4 * k, xe);
-    store(P + 16 * k, Pe);
+  // z,u are time-major: walk time in the outer loop over a block of vehicles so that memory is
+  // streamed in the order it is laid out (each vehicle's arithmetic is unaffected by the blocking).
+  constexpr int BLK = 64;
+  for (int b0 = a0; b0 < a1; b0 += BLK) {
+    const int nb = (a1 - b0 < BLK) ? (a1 - b0) : BLK;
+    Mat<4, 1> xe[BLK];
+    Mat<4, 4> Pe[BLK];
+    for (int j = 0; j < nb; ++j) { xe[j] = load<4, 1>(x + 4 * (b0 + j)); Pe[j] = load<4, 4>(P + 16 * (b0 + j)); }
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < nb; ++j) {
+        const size_t o = (size_t)t * n + (b0 + j);
+        ekf_estimation(xe[j], Pe[j], load<2, 1>(z + 2 * o), load<2, 1>(u + 2 * o), Qm, Rm, dt, trig_mode, (SumOrder)sum_order);
+        if (x_hist) store(x_hist + 4 * o, xe[j]);
+        if (P_hist) store(P_hist + 16 * o, Pe[j]);
+      }
+    for (int j = 0; j < nb; ++j) { store(x + 4 * (b0 + j), xe[j]); store(P + 16 * (b0 + j), Pe[j]); }
   }
 }
 

@@ -195,10 +195,10 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const int t = t0 + d;
-      const v2f zc = zq[d], uc = uq[d];
+      ekf_step_dev(s, zq[d].x, zq[d].y, uq[d].x, uq[d].y, k);
+      // refill the slot just consumed (its registers are dead now: no copy at the loop back-edge)
       zq[d] = __builtin_nontemporal_load(&z2[(size_t)(t + D) * n + a]);
       uq[d] = __builtin_nontemporal_load(&u2[(size_t)(t + D) * n + a]);
-      ekf_step_dev(s, zc.x, zc.y, uc.x, uc.y, k);
       if (XHIST)
         __builtin_nontemporal_store(v4f{s.x0, s.x1, s.x2, s.x3}, &xh[(size_t)t * n + a]);
       if (PHIST) store_P(s, P_hist, (size_t)t * n + a);

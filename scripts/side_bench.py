@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""Side benchmark for the two compute-bound rows of SURVEY.md 8(d): batched DARE+dlqr (configs[2]) and batched MPC
+(configs[3]).  Prints one JSON line per workload with throughput, the CPU-oracle rate on this host, and parity.
+Used by scripts/gpu_side.sh under rocprofv3 to produce profiles/<round>/lqr_mpc_*.csv."""
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import cpprobotics_amd as crx  # noqa: E402
+import oracle  # noqa: E402
+from common import lqr_speeds, mpc_problem  # noqa: E402
+
+
+def gpu_time(fn, reps):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def cpu_parallel(fn, n, cores):
+    """fn(a0, a1) over a static partition of [0,n) on `cores` threads; returns wall seconds."""
+    bounds = [(i * n // cores, (i + 1) * n // cores) for i in range(cores)]
+    th = [threading.Thread(target=fn, args=b) for b in bounds]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    return time.perf_counter() - t0
+
+
+def main():
+    cores = os.cpu_count() or 1
+    quick = "--quick" in sys.argv
+    # ---- DARE + dlqr, 16,384 agents (configs[2]) ------------------------------------------------------
+    n = 16384
+    v = lqr_speeds(n, 3)
+    vd = torch.from_numpy(v).cuda()
+    for dim in (5, 4):
+        A, B, Q, R = oracle.lqr_build(v, dim)
+        Ad, Bd, Qd, Rd = (torch.from_numpy(a).cuda() for a in (A, B, Q, R))
+        K, X, it = crx.dlqr_from_v(vd, dim=dim)
+        t_struct = gpu_time(lambda: crx.dlqr_from_v(vd, dim=dim), 5 if quick else 20)
+        t_dense = gpu_time(lambda: crx.dlqr(Ad, Bd, Qd, Rd), 3 if quick else 10)
+        iters = it.cpu().numpy()
+        Xo = np.zeros_like(A); Ko = np.zeros((n, (2 if dim == 5 else 1) * dim), np.float32); ito = np.zeros(n, np.int32)
+        import ctypes as C
+        lib = oracle.oracle_lib.lib(); vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+        def work(a0, a1):
+            lib.oracle_dare(C.c_int(n), C.c_int(dim), vp(A), vp(B), vp(Q), vp(R), C.c_float(0.01), C.c_int(150), vp(Xo), vp(Ko),
+                            vp(ito), C.c_int(0), C.c_int(a0), C.c_int(a1))
+        t1 = time.perf_counter(); work(0, 64); single = 64 / (time.perf_counter() - t1)
+        t_cpu = min(cpu_parallel(work, n, cores) for _ in range(2))
+        flop_iter = {5: 300.0, 4: 150.0}[dim]           # structured kernel, as executed
+        flops = float(iters.sum()) * flop_iter
+        print(json.dumps({
+            "workload": f"DARE+dlqr {dim}x{dim}, {n} agents, v~U(-3,6) with 5% |v|<0.1 (BASELINE configs[2])",
+            "solves_per_s_structured": n / t_struct, "solves_per_s_dense": n / t_dense, "ms_structured": t_struct * 1e3,
+            "mean_iters": float(iters.mean()), "max_iters": int(iters.max()),
+            "gflops_structured": flops / t_struct / 1e9,
+            "cpu_baseline": {"value": n / t_cpu, "unit": "solves/s", "cores": cores, "kind": "port", "single_thread_value": single},
+            "parity": {"X_bit_identical": bool(np.array_equal(X.cpu().numpy(), Xo)), "K_bit_identical": bool(np.array_equal(K.cpu().numpy(), Ko)),
+                       "iters_identical": bool(np.array_equal(iters, ito))}}))
+    # ---- MPC, 8,192 agents, T = 21 (configs[3]) ------------------------------------------------------------
+    for n, T in ((8192, 21), (8192, 6)):
+        x0, xref = mpc_problem(n, T, 4)
+        x0d, xrd = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+        sol, st, cost = crx.mpc_solve(x0d, xrd, T, return_status=True)
+        t_gpu = gpu_time(lambda: crx.mpc_solve(x0d, xrd, T), 2 if quick else 5)
+        st = st.cpu().numpy(); sol = sol.cpu().numpy()
+        ns = 2048
+        t1 = time.perf_counter(); so, sto, co = oracle.mpc_solve(x0[:16], xref[:16], T); single = 16 / (time.perf_counter() - t1)
+        so = np.zeros((ns, sol.shape[1]), np.float32); sto = np.zeros(ns, np.int32); co = np.zeros(ns)
+        pp = oracle.oracle_lib._mpc_params(None)
+        import ctypes as C
+        lib = oracle.oracle_lib.lib(); vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        xs, xr = np.ascontiguousarray(x0[:ns]), np.ascontiguousarray(xref[:ns])
+
+        def work(a0, a1):
+            lib.oracle_mpc_solve(C.c_int(ns), C.c_int(T), vp(xs), vp(xr), vp(pp), C.c_int(50), vp(so), vp(sto), vp(co), C.c_int(a0), C.c_int(a1))
+        t_cpu = min(cpu_parallel(work, ns, min(cores, ns // 8)) for _ in range(2))
+        both = ((sto & 1) == 1) & ((st[:ns] & 1) == 1)
+        err = float(np.max(np.abs(sol[:ns][both] - so[both]) / np.maximum(np.abs(so[both]), 1.0)))
+        print(json.dumps({
+            "workload": f"MPC speed+steer, {n} agents, T={T} knots ({T - 1} control intervals) (BASELINE configs[3])" if T == 21 else
+                        f"MPC speed+steer, {n} agents, T={T} (the reference's own horizon)",
+            "solves_per_s": n / t_gpu, "ms": t_gpu * 1e3, "converged_frac": float((st & 1).mean()),
+            "mean_iters": float((st >> 8).mean()), "max_iters": int((st >> 8).max()),
+            "cpu_baseline": {"value": ns / t_cpu, "unit": "solves/s", "cores": min(cores, ns // 8), "kind": "port",
+                             "sample": f"first {ns} agents", "single_thread_value": single},
+            "parity": {"max_rel_err_floored_vs_cpu_twin": err, "both_converged_frac": float(both.mean())}}))
+
+
+if __name__ == "__main__":
+    main()

@@ -157,23 +157,37 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
   if (int rc = check_device()) return rc;
   if (n == 0 || T == 0) return CRX_OK;
   const crx::EkfConsts k = make_consts(Q, R, prm);
-  const dim3 grid(blocks_for(n, 64)), block(64);
+  const dim3 grid(blocks_for(n, CRX_EKF_RUN_BLOCK)), block(CRX_EKF_RUN_BLOCK);
   hipStream_t s = (hipStream_t)stream;
 #ifndef CRX_EKF_PREFETCH
 #define CRX_EKF_PREFETCH 4
 #endif
   constexpr int D = CRX_EKF_PREFETCH;
-  if (x_hist && P_hist)
-    hipLaunchKernelGGL((crx::ekf_run_kernel<D, true, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
-  else if (x_hist)
-    hipLaunchKernelGGL((crx::ekf_run_kernel<D, true, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
-  else if (P_hist)
-    hipLaunchKernelGGL((crx::ekf_run_kernel<D, false, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
-  else
-    hipLaunchKernelGGL((crx::ekf_run_kernel<D, false, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);
+#ifndef CRX_EKF_BUFFER_ADDRESSING
+#define CRX_EKF_BUFFER_ADDRESSING 1
+#endif
+  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN;   // 32-bit buffer offsets (ekf_kernels.hip.h)
+#define CRX_LAUNCH_RUN(XH, PH)                                                                          \
+  do {                                                                                                  \
+    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
+    else hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
+  } while (0)
+  if (x_hist && P_hist) CRX_LAUNCH_RUN(true, true);
+  else if (x_hist) CRX_LAUNCH_RUN(true, false);
+  else if (P_hist) CRX_LAUNCH_RUN(false, true);
+  else CRX_LAUNCH_RUN(false, false);
+#undef CRX_LAUNCH_RUN
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }
+
+#ifdef CRX_EKF_TIMING
+// debug builds only: copies out the per-workgroup {shader-clock ticks, 100 MHz real-time ticks} of the last fused launch
+int crx_debug_ekf_timing(long long* out, int nblocks) {
+  CRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(crx::g_ekf_timing), sizeof(long long) * 2 * (size_t)nblocks));
+  return CRX_OK;
+}
+#endif
 
 int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue, float* xDR,
                                 const float* w, float* z, float* ud, float* xTrue_hist,

@@ -22,113 +22,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "crx_trig.h"
+#include "ekf_math.h"
 
 namespace crx {
 
-// native vector types (the nontemporal builtins do not take HIP's float2/float4 wrappers)
-typedef float v2f __attribute__((ext_vector_type(2)));
+#ifndef CRX_EKF_RUN_BLOCK
+#define CRX_EKF_RUN_BLOCK 64   // threads per workgroup of the fused kernel (a multiple of 64)
+#endif
+
+#ifndef CRX_EKF_PIN
+#define CRX_EKF_PIN 1   // how the per-step prefetch loads are pinned in the chunk's schedule (see the loop)
+#endif
+
+// native 4-wide vector type (the nontemporal builtins do not take HIP's float4 wrapper); v2f: ekf_math.h
 typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct EkfConsts {
-  float Q[16];  // column-major 4x4
-  float R[4];   // column-major 2x2
-  double dt;
-};
-
-struct EkfState {
-  float x0, x1, x2, x3;
-  float P[16];  // column-major: P[i + 4*j]
-};
-
-// motion_model(): x <- F_*x + B_*u   (:22-36)
-__device__ __forceinline__ void motion_model_dev(float& x0, float& x1, float& x2, float& x3,
-                                                 float u0, float u1, double dt) {
-  float s, c;
-  sincosf_(x2, &s, &c);
-  const float b0 = (float)(dt * (double)c);  // B_(0,0) = DT*cos(yaw)
-  const float b1 = (float)(dt * (double)s);  // B_(1,0) = DT*sin(yaw)
-  const float b2 = (float)dt;                // B_(2,1) = DT
-  x0 = x0 + b0 * u0;
-  x1 = x1 + b1 * u0;
-  x2 = x2 + b2 * u1;
-  x3 = x3 + u0;  // F_(3,3)=1.0 and B_(3,0)=1.0: the reference's velocity state integrates u0
-}
-
-// The four non-trivial entries of jacobF(x,u) (:38-47); the rest of jF is the identity.
-struct JacF { float j02, j03, j12, j13; };
-__device__ __forceinline__ JacF jacobF_dev(float yaw, float v, double dt) {
-  float s, c;
-  sincosf_(yaw, &s, &c);
-  JacF j;
-  j.j02 = (float)((-dt * (double)v) * (double)s);
-  j.j03 = (float)(dt * (double)c);
-  j.j12 = (float)((dt * (double)v) * (double)c);
-  j.j13 = (float)(dt * (double)s);
-  return j;
-}
-
-// One ekf_estimation() (:64-78) on register-resident state.
-__device__ __forceinline__ void ekf_step_dev(EkfState& s, float z0, float z1, float u0, float u1,
-                                             const EkfConsts& k) {
-  // xPred = motion_model(xEst, u)                                           :67
-  float xp0 = s.x0, xp1 = s.x1, xp2 = s.x2, xp3 = s.x3;
-  motion_model_dev(xp0, xp1, xp2, xp3, u0, u1, k.dt);
-  // jF = jacobF(xPred, u)                                                   :68
-  const JacF jf = jacobF_dev(xp2, u0, k.dt);
-  const float* P = s.P;
-  // T1 = jF*PEst ; rows 2,3 of jF are unit rows                              :69
-  float T1[16];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    T1[0 + 4 * j] = (P[0 + 4 * j] + jf.j02 * P[2 + 4 * j]) + jf.j03 * P[3 + 4 * j];
-    T1[1 + 4 * j] = (P[1 + 4 * j] + jf.j12 * P[2 + 4 * j]) + jf.j13 * P[3 + 4 * j];
-    T1[2 + 4 * j] = P[2 + 4 * j];
-    T1[3 + 4 * j] = P[3 + 4 * j];
-  }
-  // PPred = T1*jF^T + Q
-  float PP[16];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    PP[i + 0] = ((T1[i + 0] + T1[i + 8] * jf.j02) + T1[i + 12] * jf.j03) + k.Q[i + 0];
-    PP[i + 4] = ((T1[i + 4] + T1[i + 8] * jf.j12) + T1[i + 12] * jf.j13) + k.Q[i + 4];
-    PP[i + 8] = T1[i + 8] + k.Q[i + 8];
-    PP[i + 12] = T1[i + 12] + k.Q[i + 12];
-  }
-  // y = z - H*xPred ; S = H*PPred*H^T + R ; Sinv closed form                 :72-75
-  const float y0 = z0 - xp0;
-  const float y1 = z1 - xp1;
-  const float S00 = PP[0] + k.R[0], S10 = PP[1] + k.R[1];
-  const float S01 = PP[4] + k.R[2], S11 = PP[5] + k.R[3];
-  const float det = S00 * S11 - S10 * S01;
-  const float invdet = 1.0f / det;
-  const float Si00 = S11 * invdet, Si10 = -S10 * invdet;
-  const float Si01 = -S01 * invdet, Si11 = S00 * invdet;
-  // K = (PPred*H^T)*Sinv                                                     :75
-  float K0[4], K1[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    K0[i] = PP[i] * Si00 + PP[i + 4] * Si10;
-    K1[i] = PP[i] * Si01 + PP[i + 4] * Si11;
-  }
-  // xEst = xPred + K*y                                                       :76
-  s.x0 = xp0 + (K0[0] * y0 + K1[0] * y1);
-  s.x1 = xp1 + (K0[1] * y0 + K1[1] * y1);
-  s.x2 = xp2 + (K0[2] * y0 + K1[2] * y1);
-  s.x3 = xp3 + (K0[3] * y0 + K1[3] * y1);
-  // PEst = (I - K*H)*PPred                                                   :77
-  const float M00 = 1.0f - K0[0], M01 = 0.0f - K1[0];
-  const float M10 = 0.0f - K0[1], M11 = 1.0f - K1[1];
-  const float M20 = 0.0f - K0[2], M21 = 0.0f - K1[2];
-  const float M30 = 0.0f - K0[3], M31 = 0.0f - K1[3];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float p0 = PP[0 + 4 * j], p1 = PP[1 + 4 * j], p2 = PP[2 + 4 * j], p3 = PP[3 + 4 * j];
-    s.P[0 + 4 * j] = M00 * p0 + M01 * p1;
-    s.P[1 + 4 * j] = M10 * p0 + M11 * p1;
-    s.P[2 + 4 * j] = (M20 * p0 + M21 * p1) + p2;
-    s.P[3 + 4 * j] = (M30 * p0 + M31 * p1) + p3;
-  }
-}
 
 __device__ __forceinline__ void load_state(EkfState& s, const float* __restrict__ x,
                                            const float* __restrict__ P, size_t a) {
@@ -165,46 +72,128 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
 }
 
 // ---- fused T steps: state/covariance stay in registers, z/u stream in, xEst streams out -----
-// D = software prefetch distance in steps (z,u for step t+D are requested while step t runs).
-template <int D, bool XHIST, bool PHIST>
-__global__ void __launch_bounds__(64)
+// (fast packed step + general step: ekf_math.h)
+// D = steps per chunk = software prefetch distance (z,u for step t+D are requested while step t runs).
+// BUF = true: the streams are addressed through buffer descriptors — a wave-uniform base (4 SGPRs,
+// advanced once per chunk), a per-step scalar offset and one fixed per-lane byte offset — so the
+// loads/stores of the hot loop need no vector address arithmetic at all.  The stores keep their step
+// offset in (loop-invariant) VGPRs and pass soffset = 0: a 16-byte buffer store WITH a scalar-register
+// soffset followed closely by a VALU write of its data registers returned corrupted data on gfx950 (the
+// compiler's hazard recogniser only protects the no-soffset form).  Buffer offsets are 32-bit:
+// the host picks BUF only while every offset of a chunk stays below 2^31 (n <= kEkfBufMaxN).
+constexpr int kEkfBufMaxN = 1 << 22;
+
+#ifdef CRX_EKF_TIMING   // debug builds only (scripts/ubench): per-workgroup shader-clock / real-time deltas
+__device__ long long g_ekf_timing[4096][2];
+#endif
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+template <int D, bool XHIST, bool PHIST, bool BUF>
+__global__ void __launch_bounds__(CRX_EKF_RUN_BLOCK)
 ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
                const float* __restrict__ z, const float* __restrict__ u,
                float* __restrict__ x_hist, float* __restrict__ P_hist, EkfConsts k) {
-  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t blk = (size_t)blockIdx.x * CRX_EKF_RUN_BLOCK;
+  const unsigned lane = threadIdx.x;
+  const size_t a = blk + lane;
   if (a >= (size_t)n) return;
-  const v2f* __restrict__ z2 = reinterpret_cast<const v2f*>(z);
-  const v2f* __restrict__ u2 = reinterpret_cast<const v2f*>(u);
-  v4f* __restrict__ xh = reinterpret_cast<v4f*>(x_hist);
+#ifdef CRX_EKF_TIMING
+  const long long tm0 = clock64(), tr0 = wall_clock64();
+#endif
+  // per-workgroup views of the time-major streams: element [t*n + lane] belongs to this lane at step t
+  const v2f* __restrict__ z2 = reinterpret_cast<const v2f*>(z) + blk;
+  const v2f* __restrict__ u2 = reinterpret_cast<const v2f*>(u) + blk;
+  v4f* __restrict__ xh = reinterpret_cast<v4f*>(x_hist) + blk;
+  v4f* __restrict__ Ph = reinterpret_cast<v4f*>(P_hist) + 4 * blk;
+  const EkfConstsP kp = pack_consts(k);
+  const size_t ns = (size_t)n;
+  const unsigned un = (unsigned)n;
 
   v2f zq[D], uq[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) {
     if (d < T) {
-      zq[d] = __builtin_nontemporal_load(&z2[(size_t)d * n + a]);
-      uq[d] = __builtin_nontemporal_load(&u2[(size_t)d * n + a]);
+      zq[d] = __builtin_nontemporal_load(&(z2 + d * ns)[lane]);
+      uq[d] = __builtin_nontemporal_load(&(u2 + d * ns)[lane]);
     }
   }
   EkfState s;
   load_state(s, x, P, a);
+  EkfStateP sp;
+  pack_state(sp, s);
+  // Let the initial state arrive before the loop: otherwise the compiler's wait-count bookkeeping,
+  // merged over the loop back-edge, puts a full vmcnt(0) drain inside every iteration.
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
-  // main part: every chunk of D steps whose prefetches (t + D) stay inside [0, T) — no guards, one
-  // basic block per chunk, so the compiler can keep all D loads in flight (counted vmcnt waits)
+  // main part: every chunk of D steps whose prefetches (t + D) stay inside [0, T).  One basic block
+  // per chunk; the D loads of the next chunk stay in flight across it (counted vmcnt waits).
   int t0 = 0;
   for (; t0 + 2 * D <= T; t0 += D) {
+    const EkfStateP s_in = sp;
+    FastDomain dom = fast_domain_init();
+    __amdgpu_buffer_rsrc_t rz, ru, rx, rp;
+    if (BUF) {
+      rz = stream_rsrc(z2 + (size_t)t0 * ns);
+      ru = stream_rsrc(u2 + (size_t)t0 * ns);
+      if (XHIST) rx = stream_rsrc(xh + (size_t)t0 * ns);
+      if (PHIST) rp = stream_rsrc(Ph + 4 * (size_t)t0 * ns);
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const int t = t0 + d;
-      ekf_step_dev(s, zq[d].x, zq[d].y, uq[d].x, uq[d].y, k);
+      const size_t t = (size_t)(t0 + d);
+      ekf_step_packed(sp, zq[d], uq[d], kp, dom);
       // refill the slot just consumed (its registers are dead now: no copy at the loop back-edge)
-      zq[d] = __builtin_nontemporal_load(&z2[(size_t)(t + D) * n + a]);
-      uq[d] = __builtin_nontemporal_load(&u2[(size_t)(t + D) * n + a]);
-      if (XHIST)
-        __builtin_nontemporal_store(v4f{s.x0, s.x1, s.x2, s.x3}, &xh[(size_t)t * n + a]);
-      if (PHIST) store_P(s, P_hist, (size_t)t * n + a);
+      if (BUF) {
+        zq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rz, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
+        uq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ru, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
+      } else {
+        zq[d] = __builtin_nontemporal_load(&(z2 + (t + D) * ns)[lane]);
+        uq[d] = __builtin_nontemporal_load(&(u2 + (t + D) * ns)[lane]);
+      }
+      if (XHIST) {
+        const v4f xo = v4f{sp.x01.x, sp.x01.y, sp.x23.x, sp.x23.y};
+        if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, xo), rx, lane * 16u + (unsigned)d * un * 16u, 0, 2);
+        else __builtin_nontemporal_store(xo, &(xh + t * ns)[lane]);
+      }
+      if (PHIST) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const v4f po = v4f{sp.Plo[j].x, sp.Plo[j].y, sp.Phi[j].x, sp.Phi[j].y};
+          if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 64u + (unsigned)d * un * 64u + 16u * j, 0, 2);
+          else __builtin_nontemporal_store(po, &(Ph + 4 * t * ns)[4 * lane + j]);
+        }
+      }
+#if CRX_EKF_PIN == 1
+      // ALU work may be scheduled across this point (the trig of step d+1 overlaps the covariance
+      // update of step d), memory operations may not: keeps each step's prefetch from sinking to the
+      // end of the chunk.
+      __builtin_amdgcn_sched_barrier(0x7);
+#elif CRX_EKF_PIN == 2
+      __builtin_amdgcn_sched_barrier(0);   // nothing crosses: one scheduling region per step
+#endif
+    }
+    // rare: some lane of this wave left the fast domain (yaw = 0 or |yaw| >= 120, extreme det):
+    // redo the chunk for the whole wave with the general step (bit-identical for the other lanes)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_domain_ok(dom)) != 0, 0)) {
+      unpack_state(s, s_in);
+      for (int d = 0; d < D; ++d) {
+        const size_t o = (size_t)(t0 + d) * ns + lane;
+        const v2f zc = z2[o], uc = u2[o];
+        ekf_step_dev(s, zc.x, zc.y, uc.x, uc.y, k);
+        if (XHIST) xh[o] = v4f{s.x0, s.x1, s.x2, s.x3};
+        if (PHIST) store_P(s, P_hist, (size_t)(t0 + d) * ns + a);
+      }
+      pack_state(sp, s);
     }
   }
-  // tail: fewer than 2*D steps left
+  // tail: fewer than 2*D steps left — general step, guarded prefetch
+  unpack_state(s, sp);
   for (; t0 < T; t0 += D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -212,18 +201,24 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
       if (t < T) {
         const v2f zc = zq[d], uc = uq[d];
         if (t + D < T) {
-          zq[d] = __builtin_nontemporal_load(&z2[(size_t)(t + D) * n + a]);
-          uq[d] = __builtin_nontemporal_load(&u2[(size_t)(t + D) * n + a]);
+          zq[d] = __builtin_nontemporal_load(&(z2 + (size_t)(t + D) * ns)[lane]);
+          uq[d] = __builtin_nontemporal_load(&(u2 + (size_t)(t + D) * ns)[lane]);
         }
         ekf_step_dev(s, zc.x, zc.y, uc.x, uc.y, k);
         if (XHIST)
-          __builtin_nontemporal_store(v4f{s.x0, s.x1, s.x2, s.x3}, &xh[(size_t)t * n + a]);
-        if (PHIST) store_P(s, P_hist, (size_t)t * n + a);
+          __builtin_nontemporal_store(v4f{s.x0, s.x1, s.x2, s.x3}, &(xh + (size_t)t * ns)[lane]);
+        if (PHIST) store_P(s, P_hist, (size_t)t * ns + a);
       }
     }
   }
   reinterpret_cast<float4*>(x)[a] = make_float4(s.x0, s.x1, s.x2, s.x3);
   store_P(s, P, a);
+#ifdef CRX_EKF_TIMING
+  if (lane == 0 && blockIdx.x < 4096) {
+    g_ekf_timing[blockIdx.x][0] = clock64() - tm0;
+    g_ekf_timing[blockIdx.x][1] = wall_clock64() - tr0;
+  }
+#endif
 }
 
 // ---- the small reference functions, batched (drop-in completeness) ---------------------------

@@ -1,0 +1,346 @@
+// ekf_math.h — per-vehicle EKF arithmetic of the crx engine (gfx950 device code; also compiles as
+// plain host C++ so tests/tools/ekf_packed_host.cpp can check the packed restatement on the CPU).
+//
+// Replaces the reference's motion_model / jacobF / observation_model / jacobH / ekf_estimation
+// (/root/reference/src/extended_kalman_filter.cpp:22-78) for ONE vehicle held in registers.
+// Arithmetic contract: see ekf_kernels.hip.h.
+#pragma once
+#include "crx_trig.h"
+
+namespace crx {
+
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float v2f __attribute__((vector_size(8)));
+#endif
+
+struct EkfConsts {
+  float Q[16];  // column-major 4x4
+  float R[4];   // column-major 2x2
+  double dt;
+};
+
+struct EkfState {
+  float x0, x1, x2, x3;
+  float P[16];  // column-major: P[i + 4*j]
+};
+
+// motion_model(): x <- F_*x + B_*u   (:22-36)
+CRX_HD void motion_model_dev(float& x0, float& x1, float& x2, float& x3,
+                                                 float u0, float u1, double dt) {
+  float s, c;
+  sincosf_(x2, &s, &c);
+  const float b0 = (float)(dt * (double)c);  // B_(0,0) = DT*cos(yaw)
+  const float b1 = (float)(dt * (double)s);  // B_(1,0) = DT*sin(yaw)
+  const float b2 = (float)dt;                // B_(2,1) = DT
+  x0 = x0 + b0 * u0;
+  x1 = x1 + b1 * u0;
+  x2 = x2 + b2 * u1;
+  x3 = x3 + u0;  // F_(3,3)=1.0 and B_(3,0)=1.0: the reference's velocity state integrates u0
+}
+
+// The four non-trivial entries of jacobF(x,u) (:38-47); the rest of jF is the identity.
+struct JacF { float j02, j03, j12, j13; };
+CRX_HD JacF jacobF_dev(float yaw, float v, double dt) {
+  float s, c;
+  sincosf_(yaw, &s, &c);
+  JacF j;
+  j.j02 = (float)((-dt * (double)v) * (double)s);
+  j.j03 = (float)(dt * (double)c);
+  j.j12 = (float)((dt * (double)v) * (double)c);
+  j.j13 = (float)(dt * (double)s);
+  return j;
+}
+
+// One ekf_estimation() (:64-78) on register-resident state.
+CRX_HD void ekf_step_dev(EkfState& s, float z0, float z1, float u0, float u1,
+                                             const EkfConsts& k) {
+  // xPred = motion_model(xEst, u)                                           :67
+  float xp0 = s.x0, xp1 = s.x1, xp2 = s.x2, xp3 = s.x3;
+  motion_model_dev(xp0, xp1, xp2, xp3, u0, u1, k.dt);
+  // jF = jacobF(xPred, u)                                                   :68
+  const JacF jf = jacobF_dev(xp2, u0, k.dt);
+  const float* P = s.P;
+  // T1 = jF*PEst ; rows 2,3 of jF are unit rows                              :69
+  float T1[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    T1[0 + 4 * j] = (P[0 + 4 * j] + jf.j02 * P[2 + 4 * j]) + jf.j03 * P[3 + 4 * j];
+    T1[1 + 4 * j] = (P[1 + 4 * j] + jf.j12 * P[2 + 4 * j]) + jf.j13 * P[3 + 4 * j];
+    T1[2 + 4 * j] = P[2 + 4 * j];
+    T1[3 + 4 * j] = P[3 + 4 * j];
+  }
+  // PPred = T1*jF^T + Q
+  float PP[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    PP[i + 0] = ((T1[i + 0] + T1[i + 8] * jf.j02) + T1[i + 12] * jf.j03) + k.Q[i + 0];
+    PP[i + 4] = ((T1[i + 4] + T1[i + 8] * jf.j12) + T1[i + 12] * jf.j13) + k.Q[i + 4];
+    PP[i + 8] = T1[i + 8] + k.Q[i + 8];
+    PP[i + 12] = T1[i + 12] + k.Q[i + 12];
+  }
+  // y = z - H*xPred ; S = H*PPred*H^T + R ; Sinv closed form                 :72-75
+  const float y0 = z0 - xp0;
+  const float y1 = z1 - xp1;
+  const float S00 = PP[0] + k.R[0], S10 = PP[1] + k.R[1];
+  const float S01 = PP[4] + k.R[2], S11 = PP[5] + k.R[3];
+  const float det = S00 * S11 - S10 * S01;
+  const float invdet = 1.0f / det;
+  const float Si00 = S11 * invdet, Si10 = -S10 * invdet;
+  const float Si01 = -S01 * invdet, Si11 = S00 * invdet;
+  // K = (PPred*H^T)*Sinv                                                     :75
+  float K0[4], K1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    K0[i] = PP[i] * Si00 + PP[i + 4] * Si10;
+    K1[i] = PP[i] * Si01 + PP[i + 4] * Si11;
+  }
+  // xEst = xPred + K*y                                                       :76
+  s.x0 = xp0 + (K0[0] * y0 + K1[0] * y1);
+  s.x1 = xp1 + (K0[1] * y0 + K1[1] * y1);
+  s.x2 = xp2 + (K0[2] * y0 + K1[2] * y1);
+  s.x3 = xp3 + (K0[3] * y0 + K1[3] * y1);
+  // PEst = (I - K*H)*PPred                                                   :77
+  const float M00 = 1.0f - K0[0], M01 = 0.0f - K1[0];
+  const float M10 = 0.0f - K0[1], M11 = 1.0f - K1[1];
+  const float M20 = 0.0f - K0[2], M21 = 0.0f - K1[2];
+  const float M30 = 0.0f - K0[3], M31 = 0.0f - K1[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float p0 = PP[0 + 4 * j], p1 = PP[1 + 4 * j], p2 = PP[2 + 4 * j], p3 = PP[3 + 4 * j];
+    s.P[0 + 4 * j] = M00 * p0 + M01 * p1;
+    s.P[1 + 4 * j] = M10 * p0 + M11 * p1;
+    s.P[2 + 4 * j] = (M20 * p0 + M21 * p1) + p2;
+    s.P[3 + 4 * j] = (M30 * p0 + M31 * p1) + p3;
+  }
+}
+
+
+//
+// Fast path ("packed" step): the same arithmetic as ekf_step_dev, written on 2-wide vectors so that
+// every fp32 multiply/add is a v_pk_mul_f32 / v_pk_add_f32 (two matrix entries per instruction, the
+// rows (0,1) and (2,3) of a column), with the two sincos of the step evaluated on their |yaw| < 120
+// path and the 2x2 determinant inverted by the un-scaled Newton sequence.  Both shortcuts are
+// bit-identical to the general code on their domain; each lane records whether it stayed inside the
+// domain (FastDomain), and a wave in which any lane left it re-runs the whole chunk of D steps through
+// ekf_step_dev.  The hot loop is therefore ONE basic block per D steps (no per-lane branches), which
+// is what lets the scheduler overlap the fp64 trig chains with the fp32 matrix work.
+//
+// The two shortcuts and their domains are described at sincos_fast2 / recip_fast below.
+
+struct EkfStateP {
+  v2f x01, x23;      // (x, y), (yaw, v)
+  v2f Plo[4], Phi[4];  // column j of P: rows (0,1) and rows (2,3)
+};
+
+struct EkfConstsP {
+  v2f Qlo[4], Qhi[4];
+  v2f Rc0, Rc1;
+  double dt;
+  float dtf;
+};
+
+CRX_HD EkfConstsP pack_consts(const EkfConsts& k) {
+  EkfConstsP c;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c.Qlo[j] = v2f{k.Q[4 * j + 0], k.Q[4 * j + 1]};
+    c.Qhi[j] = v2f{k.Q[4 * j + 2], k.Q[4 * j + 3]};
+  }
+  c.Rc0 = v2f{k.R[0], k.R[1]};
+  c.Rc1 = v2f{k.R[2], k.R[3]};
+  c.dt = k.dt;
+  c.dtf = (float)k.dt;
+  return c;
+}
+
+CRX_HD void pack_state(EkfStateP& p, const EkfState& s) {
+  p.x01 = v2f{s.x0, s.x1};
+  p.x23 = v2f{s.x2, s.x3};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p.Plo[j] = v2f{s.P[4 * j + 0], s.P[4 * j + 1]};
+    p.Phi[j] = v2f{s.P[4 * j + 2], s.P[4 * j + 3]};
+  }
+}
+
+CRX_HD void unpack_state(EkfState& s, const EkfStateP& p) {
+  s.x0 = p.x01[0]; s.x1 = p.x01[1]; s.x2 = p.x23[0]; s.x3 = p.x23[1];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s.P[4 * j + 0] = p.Plo[j][0]; s.P[4 * j + 1] = p.Plo[j][1];
+    s.P[4 * j + 2] = p.Phi[j][0]; s.P[4 * j + 3] = p.Phi[j][1];
+  }
+}
+
+// ---- fast-domain bookkeeping ------------------------------------------------------------------
+// The packed step below takes two shortcuts that are bit-identical to the general code only on a
+// domain: 0 < |yaw| < 120 for both angles of the step (sincos) and 2^-60 <= |det S| <= 2^60 (reciprocal).
+// Instead of a per-step boolean (v_cmp + mask logic), each lane keeps running max/min of the
+// quantities involved — one VALU instruction each — and the caller tests them once per chunk.
+// NaNs pass through max/min unnoticed; that is harmless: a NaN angle or determinant turns the state
+// into NaN on the fast path exactly as it does on the general one.
+struct FastDomain {
+  float amax, amin;   // max / min |yaw| seen
+  float dmax, dmin;   // max / min |det S| seen
+};
+CRX_HD FastDomain fast_domain_init() { return FastDomain{0.0f, 1.0f, 1.0f, 1.0f}; }
+CRX_HD bool fast_domain_ok(const FastDomain& f) {
+  return (f.amax < 120.0f) & (f.amin > 0.0f) & (f.dmax <= 0x1p60f) & (f.dmin >= 0x1p-60f);
+}
+
+// Bit helpers of the quadrant logic.  Deliberately NOT inline asm: the compiler's hazard recogniser does
+// not look inside asm blocks, and an asm VALU write right behind a 16-byte store of the same register
+// corrupted the stored data on gfx950 (seen in the P-history test) — builtins and plain C only.
+// 0xffffffff if bit 24 of v is set, else 0 (v_bfe_i32).
+CRX_HD uint32_t bit24_mask(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_sbfe((int)v, 24u, 1u);
+#else
+  return (uint32_t)((int32_t)(v << 7) >> 31);
+#endif
+}
+// (m & a) | (~m & b)  (v_bfi_b32)
+CRX_HD uint32_t bitselect(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
+// a ^ (b & k)  (v_bitop3_b32)
+CRX_HD uint32_t xor_masked(uint32_t a, uint32_t b, uint32_t k) { return a ^ (b & k); }
+
+CRX_HD uint32_t f2u(float x) { union { float f; uint32_t u; } v; v.f = x; return v.u; }
+CRX_HD float u2f(uint32_t x) { union { float f; uint32_t u; } v; v.u = x; return v.f; }
+
+// sincosf_ restricted to its 0 < |y| < 120 path, for the two angles of one EKF step at once (the two
+// dependency chains are written interleaved so that each fp64 instruction has an independent
+// neighbour).  Outside that domain the outputs are meaningless; `dom` records where the angles were.
+//   * |y| < 2^-12, where sinf_/cosf_ return y and 1: n = 0 and x = y exactly, and the polynomials give
+//     (float)(y - y^3/6..) = y and (float)(1 - y^2/2..) = 1 by themselves (the perturbation is below half
+//     an ulp).  The one input they miss is y = -0.0f (the polynomial yields +0): |y| = 0 is therefore
+//     outside the fast domain.  Checked on every float with |y| < 128: tests/tools/trig_fast_exhaustive.cpp.
+//   * quadrant logic without compares: with v = (int)r + 2^23 (n = v >> 24), bit 24 of v says "swap sine
+//     and cosine", bit 25 is the sign of the sine output and bit 25 of v + 2^24 the sign of the cosine
+//     output; the swap is a bitfield select, the signs are xors of the sign bit.
+CRX_HD void sincos_fast2(const float y[2], float so[2], float co[2], FastDomain& dom) {
+  typedef SinCosConsts C;
+  double x[2], x2[2], x3[2], x4[2], x6[2], x7[2], s1[2], sa[2], S[2], c1[2], c2[2], ca[2], Cv[2];
+  uint32_t v[2];
+#define CRX_BOTH for (int i = 0; i < 2; ++i)
+  dom.amax = __builtin_fmaxf(__builtin_fmaxf(dom.amax, __builtin_fabsf(y[0])), __builtin_fabsf(y[1]));
+  dom.amin = __builtin_fminf(__builtin_fminf(dom.amin, __builtin_fabsf(y[0])), __builtin_fabsf(y[1]));
+  _Pragma("unroll") CRX_BOTH x[i] = (double)y[i];
+  _Pragma("unroll") CRX_BOTH v[i] = (uint32_t)((int32_t)(x[i] * C::hpi_inv) + 0x800000);
+  _Pragma("unroll") CRX_BOTH x[i] = __builtin_fma(-(double)((int32_t)v[i] >> 24), C::hpi, x[i]);
+  _Pragma("unroll") CRX_BOTH x2[i] = x[i] * x[i];
+  // sine polynomial  x + x^3*s1 + x^7*(s2 + x^2*s3)        (operation order of sincos_poly)
+  _Pragma("unroll") CRX_BOTH x3[i] = x[i] * x2[i];
+  _Pragma("unroll") CRX_BOTH s1[i] = __builtin_fma(x2[i], C::s3, C::s2);
+  // cosine polynomial (c0 + x^2*c1) + x^4*c2 + x^6*(c3 + x^2*c4)
+  _Pragma("unroll") CRX_BOTH x4[i] = x2[i] * x2[i];
+  _Pragma("unroll") CRX_BOTH c2[i] = __builtin_fma(x2[i], C::c4, C::c3);
+  _Pragma("unroll") CRX_BOTH c1[i] = __builtin_fma(x2[i], C::c1, C::c0);
+  _Pragma("unroll") CRX_BOTH x7[i] = x3[i] * x2[i];
+  _Pragma("unroll") CRX_BOTH sa[i] = __builtin_fma(x3[i], C::s1, x[i]);
+  _Pragma("unroll") CRX_BOTH x6[i] = x4[i] * x2[i];
+  _Pragma("unroll") CRX_BOTH ca[i] = __builtin_fma(x4[i], C::c2, c1[i]);
+  _Pragma("unroll") CRX_BOTH S[i] = __builtin_fma(x7[i], s1[i], sa[i]);
+  _Pragma("unroll") CRX_BOTH Cv[i] = __builtin_fma(x6[i], c2[i], ca[i]);
+  _Pragma("unroll") CRX_BOTH {
+    const uint32_t fs = f2u((float)S[i]), fc = f2u((float)Cv[i]);  // rounding commutes with the sign flips
+    const uint32_t odd = bit24_mask(v[i]);                           // all ones when n is odd
+    const uint32_t sr = bitselect(odd, fc, fs);
+    const uint32_t cr = bitselect(odd, fs, fc);
+    const uint32_t qs = v[i] << 6;                // bit 31 = bit 1 of n
+    const uint32_t qc = qs + 0x40000000u;         // bit 31 = bit 1 of n + 1
+    so[i] = u2f(xor_masked(sr, qs, 0x80000000u));
+    co[i] = u2f(xor_masked(cr, qc, 0x80000000u));
+  }
+#undef CRX_BOTH
+}
+
+// 1.0f/d, IEEE-rounded, for 2^-60 <= |d| <= 2^60 (`dom` records |d|).
+//   LLVM's IEEE fp32 division is v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup.  In that
+//   range, with numerator 1.0, neither v_div_scale scales, v_div_fmas is a plain fma and v_div_fixup
+//   passes the quotient through: rcp + the same six fma give the same bits.
+CRX_HD float recip_fast(float d, FastDomain& dom) {
+  const float ad = __builtin_fabsf(d);
+  dom.dmax = __builtin_fmaxf(dom.dmax, ad);
+  dom.dmin = __builtin_fminf(dom.dmin, ad);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  const float r1 = __builtin_fmaf(e, r, r);
+  const float q = r1;                                  // 1.0f * r1
+  const float rem = __builtin_fmaf(-d, q, 1.0f);
+  const float q1 = __builtin_fmaf(rem, r1, q);
+  const float rem2 = __builtin_fmaf(-d, q1, 1.0f);
+  return __builtin_fmaf(rem2, r1, q1);
+#else
+  return 1.0f / d;                                     // host build (tests): the IEEE quotient itself
+#endif
+}
+
+CRX_HD v2f bc(float a) { return v2f{a, a}; }
+
+// One ekf_estimation() (:64-78), packed.  Same operation order as ekf_step_dev, entry by entry.
+CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, FastDomain& dom) {
+  const float u0 = u[0], u1 = u[1];
+  // motion_model: both yaw angles of the step are known up front
+  const float yaw0 = s.x23[0];
+  const float yaw1 = yaw0 + k.dtf * u1;                 // xPred(2) = x(2) + DT*u(1)
+  const float yaws[2] = {yaw0, yaw1};
+  float sn[2], cs[2];
+  sincos_fast2(yaws, sn, cs, dom);
+  const float s0 = sn[0], c0 = cs[0], s1 = sn[1], c1 = cs[1];
+  const v2f b01 = v2f{(float)(k.dt * (double)c0), (float)(k.dt * (double)s0)};
+  const v2f xp01 = s.x01 + b01 * bc(u0);
+  const v2f xp23 = v2f{yaw1, s.x23[1] + u0};
+  // jacobF(xPred, u): yaw = xPred(2), v = u(0)
+  const double dv = k.dt * (double)u0;
+  const float j02 = (float)((-dv) * (double)s1);
+  const float j03 = (float)(k.dt * (double)c1);
+  const float j12 = (float)(dv * (double)c1);
+  const float j13 = (float)(k.dt * (double)s1);
+  const v2f jA = v2f{j02, j12}, jB = v2f{j03, j13};
+  // T1 = jF*PEst (rows 2,3 of jF are unit rows)
+  v2f T1lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) T1lo[j] = (s.Plo[j] + jA * bc(s.Phi[j][0])) + jB * bc(s.Phi[j][1]);
+  // PPred = T1*jF^T + Q
+  v2f PPlo[4], PPhi[4];
+  PPlo[0] = ((T1lo[0] + T1lo[2] * bc(j02)) + T1lo[3] * bc(j03)) + k.Qlo[0];
+  PPhi[0] = ((s.Phi[0] + s.Phi[2] * bc(j02)) + s.Phi[3] * bc(j03)) + k.Qhi[0];
+  PPlo[1] = ((T1lo[1] + T1lo[2] * bc(j12)) + T1lo[3] * bc(j13)) + k.Qlo[1];
+  PPhi[1] = ((s.Phi[1] + s.Phi[2] * bc(j12)) + s.Phi[3] * bc(j13)) + k.Qhi[1];
+  PPlo[2] = T1lo[2] + k.Qlo[2];
+  PPhi[2] = s.Phi[2] + k.Qhi[2];
+  PPlo[3] = T1lo[3] + k.Qlo[3];
+  PPhi[3] = s.Phi[3] + k.Qhi[3];
+  // y, S, S^-1
+  const v2f y = z - xp01;
+  const v2f Sc0 = PPlo[0] + k.Rc0;   // (S00, S10)
+  const v2f Sc1 = PPlo[1] + k.Rc1;   // (S01, S11)
+  const v2f dd = Sc0 * v2f{Sc1[1], Sc1[0]};   // (S00*S11, S10*S01)
+  const float det = dd[0] - dd[1];
+  const float inv = recip_fast(det, dom);
+  const float Si00 = Sc1[1] * inv, Si10 = -Sc0[1] * inv;
+  const float Si01 = -Sc1[0] * inv, Si11 = Sc0[0] * inv;
+  // K = (PPred*H^T)*Sinv
+  const v2f K0lo = PPlo[0] * bc(Si00) + PPlo[1] * bc(Si10);
+  const v2f K0hi = PPhi[0] * bc(Si00) + PPhi[1] * bc(Si10);
+  const v2f K1lo = PPlo[0] * bc(Si01) + PPlo[1] * bc(Si11);
+  const v2f K1hi = PPhi[0] * bc(Si01) + PPhi[1] * bc(Si11);
+  // xEst = xPred + K*y
+  s.x01 = xp01 + (K0lo * bc(y[0]) + K1lo * bc(y[1]));
+  s.x23 = xp23 + (K0hi * bc(y[0]) + K1hi * bc(y[1]));
+  // PEst = (I - K*H)*PPred
+  const v2f M0lo = v2f{1.0f, 0.0f} - K0lo, M0hi = v2f{0.0f, 0.0f} - K0hi;
+  const v2f M1lo = v2f{0.0f, 1.0f} - K1lo, M1hi = v2f{0.0f, 0.0f} - K1hi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const v2f p0 = bc(PPlo[j][0]), p1 = bc(PPlo[j][1]);
+    s.Plo[j] = M0lo * p0 + M1lo * p1;
+    s.Phi[j] = (M0hi * p0 + M1hi * p1) + PPhi[j];
+  }
+}
+
+
+}  // namespace crx

@@ -157,3 +157,73 @@ def test_ekf_full_size_properties(crx, oracle_mod):
     assert bit_equal(xh[:, idx].cpu().numpy(), xho)
     assert bit_equal(Pd[idx].cpu().numpy(), Po)
     assert floored_rel_err(xd[idx].cpu().numpy(), xo, 1.0) <= 1e-6   # the stated tolerance, trivially
+
+
+# ---- the fused kernel's fast-domain exits (packed step -> general step for the whole wave) ----------
+def _run_both(crx, oracle_mod, x0, P0, z, ud, Q, R):
+    import torch
+    T, n = z.shape[0], x0.shape[0]
+    xo, Po, xho, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
+    xd, Pd = _t(x0), _t(P0)
+    xh = torch.empty((T, n, 4), dtype=torch.float32, device="cuda")
+    crx.ekf_run(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh)
+    return (xd.cpu().numpy(), Pd.cpu().numpy(), xh.cpu().numpy()), (xo, Po, xho)
+
+
+@pytest.mark.parametrize("yaw", [119.99999, 120.0, 121.0, -500.0, 1.0e6, -3.0e9, 1.0e30])
+def test_ekf_fused_large_yaw_bit_exact(crx, oracle_mod, yaw):
+    """|yaw| >= 120 leaves the fast sincos path (192-bit 2/pi reduction needed): some waves of the launch
+    redo their chunk with the general step, others stay on the packed path — all must match the oracle."""
+    Q, R = ekf_QR()
+    n, T = 64 * 5 + 7, 37
+    u, x0, P0 = ekf_agents(n, 21)
+    x0[64:128:3, 2] = np.float32(yaw)      # one wave partly outside the domain
+    x0[200, 2] = np.float32(-yaw)          # one lane of another wave
+    w = ekf_noise(T, n, 22)
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
+    (x, P, xh), (xo, Po, xho) = _run_both(crx, oracle_mod, x0, P0, z, ud, Q, R)
+    assert bit_equal(xh, xho) and bit_equal(x, xo) and bit_equal(P, Po)
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e12])
+def test_ekf_fused_extreme_determinant_bit_exact(crx, oracle_mod, scale):
+    """det(S) outside [2^-60, 2^60]: the un-scaled Newton reciprocal is not used (v_div_scale would scale)."""
+    Q, R = ekf_QR()
+    Qs, Rs = (Q * np.float32(scale)).astype(np.float32), (R * np.float32(scale)).astype(np.float32)
+    n, T = 130, 23
+    u, x0, P0 = ekf_agents(n, 23)
+    P0 = (P0 * np.float32(scale)).astype(np.float32)
+    w = ekf_noise(T, n, 24)
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
+    (x, P, xh), (xo, Po, xho) = _run_both(crx, oracle_mod, x0, P0, z, ud, Qs, Rs)
+    assert np.isfinite(xho).all()
+    assert bit_equal(xh, xho) and bit_equal(x, xo) and bit_equal(P, Po)
+
+
+def test_ekf_fused_moderate_determinants_bit_exact(crx, oracle_mod):
+    """Determinants spread over 2^-55 .. 2^55 stay on the fast reciprocal: it must round like IEEE division."""
+    Q, R = ekf_QR()
+    n, T = 4096, 9
+    u, x0, P0 = ekf_agents(n, 25)
+    rng = np.random.default_rng(26)
+    sc = np.exp2(rng.uniform(-27, 27, n)).astype(np.float32)          # det ~ sc^2
+    P0 = (P0 * sc[:, None]).astype(np.float32)
+    w = ekf_noise(T, n, 27)
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
+    Rz = np.zeros(4, dtype=np.float32)                                 # S = H*PPred*H^T alone: det follows P0's scale
+    (x, P, xh), (xo, Po, xho) = _run_both(crx, oracle_mod, x0, P0, z, ud, Q, Rz)
+    assert bit_equal(xh, xho) and bit_equal(x, xo) and bit_equal(P, Po)
+
+
+def test_ekf_fused_nonfinite_state(crx, oracle_mod):
+    Q, R = ekf_QR()
+    n, T = 70, 11
+    u, x0, P0 = ekf_agents(n, 28)
+    x0[1, 2] = np.inf
+    x0[65, 2] = np.nan
+    w = ekf_noise(T, n, 29)
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, np.zeros_like(x0), np.zeros_like(x0), w)
+    (x, P, xh), (xo, Po, xho) = _run_both(crx, oracle_mod, x0, P0, z, ud, Q, R)
+    ok = np.ones(n, dtype=bool); ok[[1, 65]] = False
+    assert bit_equal(xh[:, ok], xho[:, ok]) and bit_equal(P[ok], Po[ok])
+    assert np.isnan(xh[:, ~ok, :3]).all() and np.isnan(xho[:, ~ok, :3]).all()

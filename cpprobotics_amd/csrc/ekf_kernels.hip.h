@@ -165,8 +165,10 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const v4f po = v4f{sp.Plo[j].x, sp.Plo[j].y, sp.Phi[j].x, sp.Phi[j].y};
-          if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 64u + (unsigned)d * un * 64u + 16u * j, 0, 2);
-          else __builtin_nontemporal_store(po, &(Ph + 4 * t * ns)[4 * lane + j]);
+          // plain (not nontemporal) stores: a lane's 64-byte column block goes out as four 16-byte pieces
+          // that the L2 has to merge into full lines; streaming stores do not get merged (10x slower)
+          if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 64u + (unsigned)d * un * 64u + 16u * j, 0, 0);
+          else (Ph + 4 * t * ns)[4 * lane + j] = po;
         }
       }
 #if CRX_EKF_PIN == 1

@@ -300,20 +300,35 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   const float j12 = (float)(dv * (double)c1);
   const float j13 = (float)(k.dt * (double)s1);
   const v2f jA = v2f{j02, j12}, jB = v2f{j03, j13};
-  // T1 = jF*PEst (rows 2,3 of jF are unit rows)
-  v2f T1lo[4];
+  // The matrix part is written stage-major (the same operation across all columns, then the next
+  // operation): consecutive instructions are then independent, and the packed-op result hazard
+  // (a dependent instruction right behind a v_pk_* needs a wait state) costs no s_nop.
+  // T1 = jF*PEst (rows 2,3 of jF are unit rows):  T1lo[j] = (Plo[j] + jA*P2j) + jB*P3j
+  v2f T1lo[4], ta[4], tb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) T1lo[j] = (s.Plo[j] + jA * bc(s.Phi[j][0])) + jB * bc(s.Phi[j][1]);
-  // PPred = T1*jF^T + Q
+  for (int j = 0; j < 4; ++j) ta[j] = jA * bc(s.Phi[j][0]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) tb[j] = jB * bc(s.Phi[j][1]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ta[j] = s.Plo[j] + ta[j];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) T1lo[j] = ta[j] + tb[j];
+  // PPred = T1*jF^T + Q:  col0 = ((T1c0 + T1c2*j02) + T1c3*j03) + Qc0, col1 likewise with j12, j13
   v2f PPlo[4], PPhi[4];
-  PPlo[0] = ((T1lo[0] + T1lo[2] * bc(j02)) + T1lo[3] * bc(j03)) + k.Qlo[0];
-  PPhi[0] = ((s.Phi[0] + s.Phi[2] * bc(j02)) + s.Phi[3] * bc(j03)) + k.Qhi[0];
-  PPlo[1] = ((T1lo[1] + T1lo[2] * bc(j12)) + T1lo[3] * bc(j13)) + k.Qlo[1];
-  PPhi[1] = ((s.Phi[1] + s.Phi[2] * bc(j12)) + s.Phi[3] * bc(j13)) + k.Qhi[1];
-  PPlo[2] = T1lo[2] + k.Qlo[2];
-  PPhi[2] = s.Phi[2] + k.Qhi[2];
-  PPlo[3] = T1lo[3] + k.Qlo[3];
-  PPhi[3] = s.Phi[3] + k.Qhi[3];
+  {
+    const v2f m0 = T1lo[2] * bc(j02), m1 = s.Phi[2] * bc(j02), m2 = T1lo[2] * bc(j12), m3 = s.Phi[2] * bc(j12);
+    const v2f n0 = T1lo[3] * bc(j03), n1 = s.Phi[3] * bc(j03), n2 = T1lo[3] * bc(j13), n3 = s.Phi[3] * bc(j13);
+    const v2f a0 = T1lo[0] + m0, a1 = s.Phi[0] + m1, a2 = T1lo[1] + m2, a3 = s.Phi[1] + m3;
+    PPlo[2] = T1lo[2] + k.Qlo[2];
+    PPhi[2] = s.Phi[2] + k.Qhi[2];
+    PPlo[3] = T1lo[3] + k.Qlo[3];
+    PPhi[3] = s.Phi[3] + k.Qhi[3];
+    const v2f c0 = a0 + n0, c1 = a1 + n1, c2 = a2 + n2, c3 = a3 + n3;
+    PPlo[0] = c0 + k.Qlo[0];
+    PPhi[0] = c1 + k.Qhi[0];
+    PPlo[1] = c2 + k.Qlo[1];
+    PPhi[1] = c3 + k.Qhi[1];
+  }
   // y, S, S^-1
   const v2f y = z - xp01;
   const v2f Sc0 = PPlo[0] + k.Rc0;   // (S00, S10)
@@ -324,22 +339,31 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   const float Si00 = Sc1[1] * inv, Si10 = -Sc0[1] * inv;
   const float Si01 = -Sc1[0] * inv, Si11 = Sc0[0] * inv;
   // K = (PPred*H^T)*Sinv
-  const v2f K0lo = PPlo[0] * bc(Si00) + PPlo[1] * bc(Si10);
-  const v2f K0hi = PPhi[0] * bc(Si00) + PPhi[1] * bc(Si10);
-  const v2f K1lo = PPlo[0] * bc(Si01) + PPlo[1] * bc(Si11);
-  const v2f K1hi = PPhi[0] * bc(Si01) + PPhi[1] * bc(Si11);
+  v2f K0lo, K0hi, K1lo, K1hi;
+  {
+    const v2f e0 = PPlo[0] * bc(Si00), e1 = PPhi[0] * bc(Si00), e2 = PPlo[0] * bc(Si01), e3 = PPhi[0] * bc(Si01);
+    const v2f f0 = PPlo[1] * bc(Si10), f1 = PPhi[1] * bc(Si10), f2 = PPlo[1] * bc(Si11), f3 = PPhi[1] * bc(Si11);
+    K0lo = e0 + f0; K0hi = e1 + f1; K1lo = e2 + f2; K1hi = e3 + f3;
+  }
   // xEst = xPred + K*y
-  s.x01 = xp01 + (K0lo * bc(y[0]) + K1lo * bc(y[1]));
-  s.x23 = xp23 + (K0hi * bc(y[0]) + K1hi * bc(y[1]));
-  // PEst = (I - K*H)*PPred
+  {
+    const v2f g0 = K0lo * bc(y[0]), g1 = K0hi * bc(y[0]), h0 = K1lo * bc(y[1]), h1 = K1hi * bc(y[1]);
+    const v2f d0 = g0 + h0, d1 = g1 + h1;
+    s.x01 = xp01 + d0;
+    s.x23 = xp23 + d1;
+  }
+  // PEst = (I - K*H)*PPred:  col j = (M0*p0j + M1*p1j) [+ (p2j, p3j) for rows 2,3]
   const v2f M0lo = v2f{1.0f, 0.0f} - K0lo, M0hi = v2f{0.0f, 0.0f} - K0hi;
   const v2f M1lo = v2f{0.0f, 1.0f} - K1lo, M1hi = v2f{0.0f, 0.0f} - K1hi;
+  v2f qa[4], qb[4], qc[4], qd[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const v2f p0 = bc(PPlo[j][0]), p1 = bc(PPlo[j][1]);
-    s.Plo[j] = M0lo * p0 + M1lo * p1;
-    s.Phi[j] = (M0hi * p0 + M1hi * p1) + PPhi[j];
-  }
+  for (int j = 0; j < 4; ++j) { qa[j] = M0lo * bc(PPlo[j][0]); qb[j] = M0hi * bc(PPlo[j][0]); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { qc[j] = M1lo * bc(PPlo[j][1]); qd[j] = M1hi * bc(PPlo[j][1]); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s.Plo[j] = qa[j] + qc[j]; qb[j] = qb[j] + qd[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s.Phi[j] = qb[j] + PPhi[j];
 }
 
 

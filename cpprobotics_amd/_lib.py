@@ -23,9 +23,26 @@ class MpcParams(C.Structure):
         "rd_delta", "q_x", "q_y", "q_yaw", "q_v", "tol")] + [("max_iter", C.c_int)]
 
 
+class Course(C.Structure):
+    _fields_ = [("n", C.c_int), ("cx", C.c_void_p), ("cy", C.c_void_p), ("cyaw", C.c_void_p), ("ck", C.c_void_p),
+                ("sp", C.c_void_p)]
+
+
+class VehicleParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("wheelbase", C.c_double), ("max_steer", C.c_double), ("clamp_speed", C.c_int),
+                ("max_speed", C.c_double), ("min_speed", C.c_double)]
+
+
+class LoopParams(C.Structure):
+    _fields_ = [("goal_x", C.c_float), ("goal_y", C.c_float), ("goal_dis", C.c_float), ("kp", C.c_double),
+                ("stop_speed", C.c_float), ("max_ticks", C.c_int)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
+_D = C.c_double
+_CP = C.POINTER(Course)
 
 # name -> (restype, argtypes); every symbol include/crx.h declares.
 _SIGNATURES = {
@@ -54,6 +71,23 @@ _SIGNATURES = {
     "crx_dare_from_v_batch_dev": (_I, [_I, _I, _P, C.POINTER(LqrParams), _P, _P, _P, _P]),
     "crx_mpc_solve_batch": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P]),
     "crx_mpc_solve_batch_dev": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P, _P]),
+    "crx_vehicle_default_params": (None, [C.POINTER(VehicleParams), _I]),
+    "crx_calc_nearest_index_batch": (_I, [_I, _P, _CP, _P, _P]),
+    "crx_calc_nearest_index_batch_dev": (_I, [_I, _P, _CP, _P, _P, _P]),
+    "crx_lqr_steering_control_batch": (_I, [_I, _I, _P, _CP, _P, _P, _P, C.POINTER(LqrParams), _P]),
+    "crx_lqr_steering_control_batch_dev": (_I, [_I, _I, _P, _CP, _P, _P, _P, C.POINTER(LqrParams), _P, _P]),
+    "crx_update_batch": (_I, [_I, _P, _P, _P, C.POINTER(VehicleParams)]),
+    "crx_update_batch_dev": (_I, [_I, _P, _P, _P, C.POINTER(VehicleParams), _P]),
+    "crx_lqr_closed_loop_batch": (_I, [_I, _I, _P, _CP, _P, _P, _P, C.POINTER(LqrParams), C.POINTER(VehicleParams),
+                                       C.POINTER(LoopParams), _P, _P]),
+    "crx_lqr_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _P, _P, _P, C.POINTER(LqrParams), C.POINTER(VehicleParams),
+                                           C.POINTER(LoopParams), _P, _P, _P]),
+    "crx_calc_nearest_index_window_batch_dev": (_I, [_I, _P, _CP, _P, _I, _P, _P]),
+    "crx_calc_ref_trajectory_batch": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P]),
+    "crx_calc_ref_trajectory_batch_dev": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P, _P]),
+    "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),
+    "crx_mpc_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
+                                           _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

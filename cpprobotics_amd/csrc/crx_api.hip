@@ -10,6 +10,7 @@
 #include "dare_kernels.hip.h"
 #include "ekf_kernels.hip.h"
 #include "mpc_kernels.hip.h"
+#include "track_kernels.hip.h"
 
 namespace {
 
@@ -390,6 +391,285 @@ int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const 
   if (status) CRX_HIP(hipMemcpy(status, dst.p, 4 * nn, hipMemcpyDeviceToHost));
   if (cost) CRX_HIP(hipMemcpy(cost, dc.p, 8 * nn, hipMemcpyDeviceToHost));
   CRX_HIP(hipDeviceSynchronize());
+  return CRX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// course tracking front-end, vehicle update, closed loops
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+bool course_ok(const crx_course* c, bool need_ck_sp) {
+  return c && c->n > 0 && c->cx && c->cy && c->cyaw && (!need_ck_sp || (c->ck && c->sp));
+}
+crx::CourseView view(const crx_course* c) { return crx::CourseView{c->cx, c->cy, c->cyaw, c->ck, c->sp, c->n}; }
+crx::VehicleParams vparams(const crx_vehicle_params* p, int mpc) {
+  crx_vehicle_params d;
+  if (p) d = *p; else crx_vehicle_default_params(&d, mpc);
+  return crx::VehicleParams{d.dt, d.wheelbase, d.max_steer, d.max_speed, d.min_speed, d.clamp_speed};
+}
+inline bool use_lds(const crx_course* c) { return c->n <= crx::kCourseLdsMax; }
+inline size_t lds_bytes(const crx_course* c) { return use_lds(c) ? sizeof(float2) * (size_t)c->n : 0; }
+
+// host-side staging of a course for the host-pointer entry points
+struct DevCourse {
+  DevBuf b[5];
+  crx_course c;
+  int upload(const crx_course* h) {
+    const float* src[5] = {h->cx, h->cy, h->cyaw, h->ck, h->sp};
+    const float* dst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 5; ++i) {
+      if (!src[i]) continue;
+      if (b[i].alloc(sizeof(float) * (size_t)h->n) != hipSuccess) return CRX_ERR_ALLOC;
+      if (hipMemcpy(b[i].p, src[i], sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice) != hipSuccess) return CRX_ERR_HIP;
+      dst[i] = b[i].as<float>();
+    }
+    c = crx_course{h->n, dst[0], dst[1], dst[2], dst[3], dst[4]};
+    return CRX_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void crx_vehicle_default_params(crx_vehicle_params* p, int mpc) {
+  if (!p) return;
+  p->dt = mpc ? 0.2 : 0.1;
+  p->wheelbase = mpc ? 2.5 : 0.5;
+  p->max_steer = 45.0 / 180 * 3.14159265358979323846;
+  p->clamp_speed = mpc ? 1 : 0;
+  p->max_speed = 55.0 / 3.6;
+  p->min_speed = -20.0 / 3.6;
+}
+
+int crx_calc_nearest_index_batch_dev(int n, const float* state, const crx_course* course, int* ind, float* e, void* stream) {
+  if (n < 0 || !course_ok(course, false) || (n && (!state || !ind))) return fail(CRX_ERR_INVALID, "calc_nearest_index: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  if (use_lds(course))
+    hipLaunchKernelGGL((crx::calc_nearest_index_kernel<true>), grid, block, lds_bytes(course), (hipStream_t)stream, n, state, view(course), ind, e);
+  else
+    hipLaunchKernelGGL((crx::calc_nearest_index_kernel<false>), grid, block, 0, (hipStream_t)stream, n, state, view(course), ind, e);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
+                                       float* pth_e, const crx_lqr_params* prm, float* control, void* stream) {
+  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || (n && (!state || !pe || !pth_e || !control)))
+    return fail(CRX_ERR_INVALID, "lqr_steering_control: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_lqr_params p;
+  if (prm) p = *prm; else crx_lqr_default_params(&p);
+  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const crx::CourseView cv = view(course);
+  hipStream_t s = (hipStream_t)stream;
+#define CRX_LAUNCH_CTL(DIM, LDS) \
+  hipLaunchKernelGGL((crx::lqr_steering_control_kernel<DIM, LDS>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, state, cv, ind, pe, pth_e, p.dt, p.L, p.eps, p.maxiter, control)
+  if (dim == 5) { if (use_lds(course)) CRX_LAUNCH_CTL(5, true); else CRX_LAUNCH_CTL(5, false); }
+  else { if (use_lds(course)) CRX_LAUNCH_CTL(4, true); else CRX_LAUNCH_CTL(4, false); }
+#undef CRX_LAUNCH_CTL
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_update_batch_dev(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm, void* stream) {
+  if (n < 0 || (n && (!state || !a || !delta))) return fail(CRX_ERR_INVALID, "update: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::update_kernel, dim3(blocks_for(n, crx::kTrackBlock)), dim3(crx::kTrackBlock), 0, (hipStream_t)stream,
+                     n, state, a, delta, vparams(prm, 0));
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                                  const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                                  float* traj_hist, int* ticks_done, void* stream) {
+  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
+    return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_lqr_params p;
+  if (prm) p = *prm; else crx_lqr_default_params(&p);
+  const crx::VehicleParams vp = vparams(veh, 0);
+  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const crx::CourseView cv = view(course);
+  hipStream_t s = (hipStream_t)stream;
+#define CRX_LAUNCH_LOOP(DIM, LDS) \
+  hipLaunchKernelGGL((crx::lqr_closed_loop_kernel<DIM, LDS>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, loop->max_ticks, state, cv, \
+                     pe, pth_e, ind, p.dt, p.L, p.eps, p.maxiter, vp, loop->goal_x, loop->goal_y, loop->goal_dis, loop->kp,        \
+                     loop->stop_speed, traj_hist, ticks_done)
+  if (dim == 5) { if (use_lds(course)) CRX_LAUNCH_LOOP(5, true); else CRX_LAUNCH_LOOP(5, false); }
+  else { if (use_lds(course)) CRX_LAUNCH_LOOP(4, true); else CRX_LAUNCH_LOOP(4, false); }
+#undef CRX_LAUNCH_LOOP
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
+                                            int* ind_out, void* stream) {
+  if (n < 0 || nsearch < 0 || !course_ok(course, false) || (n && (!state || !pind || !ind_out)))
+    return fail(CRX_ERR_INVALID, "calc_nearest_index(window): bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::calc_nearest_index_window_kernel, dim3(blocks_for(n, crx::kTrackBlock)), dim3(crx::kTrackBlock), 0,
+                     (hipStream_t)stream, n, state, view(course), pind, nsearch, ind_out);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const crx_course* course, float dl, double dt,
+                                      int nsearch, int* target_ind, float* xref, void* stream) {
+  if (n < 0 || T < 1 || nsearch < 0 || !course_ok(course, true) || (n && (!state || !target_ind || !xref)))
+    return fail(CRX_ERR_INVALID, "calc_ref_trajectory: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, dim3(blocks_for(n, crx::kTrackBlock)), dim3(crx::kTrackBlock), 0,
+                     (hipStream_t)stream, n, T, state, view(course), dl, dt, nsearch, target_ind, xref, (const int*)nullptr);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// work layout: xref [n][4T] floats | sol [n][4T+2(T-1)] floats | active [n] ints
+size_t crx_mpc_closed_loop_work_bytes(int n, int T) {
+  if (n <= 0 || T < 2) return 0;
+  const size_t nn = (size_t)n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  return sizeof(float) * nn * 4 * T + sizeof(float) * nn * nv + sizeof(int) * nn;
+}
+
+int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
+                                  const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
+                                  int* ticks_done, void* work, void* stream) {
+  if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 ||
+      (n && (!state || !target_ind || !ticks_done || !work)))
+    return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const crx::VehicleParams vp{p.dt, p.wb, p.max_steer, p.max_speed, p.min_speed, 1};
+  const size_t nn = (size_t)n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  float* xref = static_cast<float*>(work);
+  float* sol = xref + nn * 4 * T;
+  int* active = reinterpret_cast<int*>(sol + nn * nv);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const crx::CourseView cv = view(course);
+  hipLaunchKernelGGL(crx::fill_int_kernel, grid, block, 0, s, n, active, 1);
+  hipLaunchKernelGGL(crx::fill_int_kernel, grid, block, 0, s, n, ticks_done, 0);
+  for (int t = 0; t < loop->max_ticks; ++t) {
+    hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, grid, block, 0, s, n, T, state, cv, dl, p.dt, nsearch, target_ind, xref,
+                       (const int*)active);
+    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
+    hipLaunchKernelGGL(crx::mpc_tick_tail_kernel, grid, block, 0, s, n, T, t, state, sol, vp, loop->goal_x, loop->goal_y,
+                       loop->goal_dis, active, ticks_done, traj_hist);
+  }
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// ---- host-pointer variants -----------------------------------------------------------------------
+int crx_calc_nearest_index_batch(int n, const float* state, const crx_course* course, int* ind, float* e) {
+  if (n < 0 || !course_ok(course, false) || (n && (!state || !ind))) return fail(CRX_ERR_INVALID, "calc_nearest_index: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  DevCourse dc; DevBuf ds, di, de;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * (size_t)n); CRX_ALLOC(di, 4 * (size_t)n); CRX_ALLOC(de, 4 * (size_t)n);
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * (size_t)n, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(di.p, ind, 4 * (size_t)n, hipMemcpyHostToDevice));
+  if (int rc = crx_calc_nearest_index_batch_dev(n, ds.as<float>(), &dc.c, di.as<int>(), de.as<float>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(ind, di.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  if (e) CRX_HIP(hipMemcpy(e, de.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
+                                   float* pth_e, const crx_lqr_params* prm, float* control) {
+  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || (n && (!state || !pe || !pth_e || !control)))
+    return fail(CRX_ERR_INVALID, "lqr_steering_control: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n, nc = dim == 5 ? 2 : 1;
+  DevCourse dc; DevBuf ds, di, dpe, dpt, dct;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dpe, 4 * nn); CRX_ALLOC(dpt, 4 * nn); CRX_ALLOC(dct, 4 * nc * nn);
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  if (ind) CRX_HIP(hipMemcpy(di.p, ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
+  CRX_HIP(hipMemcpy(dpe.p, pe, 4 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dpt.p, pth_e, 4 * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_lqr_steering_control_batch_dev(n, dim, ds.as<float>(), &dc.c, di.as<int>(), dpe.as<float>(), dpt.as<float>(), prm,
+                                                  dct.as<float>(), nullptr)) return rc;
+  if (ind) CRX_HIP(hipMemcpy(ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipMemcpy(pe, dpe.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipMemcpy(pth_e, dpt.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipMemcpy(control, dct.p, 4 * nc * nn, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_update_batch(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm) {
+  if (n < 0 || (n && (!state || !a || !delta))) return fail(CRX_ERR_INVALID, "update: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n;
+  DevBuf ds, da, dd;
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(da, 4 * nn); CRX_ALLOC(dd, 4 * nn);
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(da.p, a, 4 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dd.p, delta, 4 * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_update_batch_dev(n, ds.as<float>(), da.as<float>(), dd.as<float>(), prm, nullptr)) return rc;
+  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                              const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                              float* traj_hist, int* ticks_done) {
+  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
+    return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n, mt = (size_t)loop->max_ticks;
+  DevCourse dc; DevBuf ds, dpe, dpt, di, dh, dt;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(dpe, 4 * nn); CRX_ALLOC(dpt, 4 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn);
+  if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  if (pe) CRX_HIP(hipMemcpy(dpe.p, pe, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(dpe.p, 0, 4 * nn));
+  if (pth_e) CRX_HIP(hipMemcpy(dpt.p, pth_e, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(dpt.p, 0, 4 * nn));
+  if (ind) CRX_HIP(hipMemcpy(di.p, ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
+  if (int rc = crx_lqr_closed_loop_batch_dev(n, dim, ds.as<float>(), &dc.c, dpe.as<float>(), dpt.as<float>(), di.as<int>(), prm, veh,
+                                             loop, traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
+  if (pe) CRX_HIP(hipMemcpy(pe, dpe.p, 4 * nn, hipMemcpyDeviceToHost));
+  if (pth_e) CRX_HIP(hipMemcpy(pth_e, dpt.p, 4 * nn, hipMemcpyDeviceToHost));
+  if (ind) CRX_HIP(hipMemcpy(ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
+  if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));
+  if (ticks_done) CRX_HIP(hipMemcpy(ticks_done, dt.p, 4 * nn, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_course* course, float dl, double dt, int nsearch,
+                                  int* target_ind, float* xref) {
+  if (n < 0 || T < 1 || nsearch < 0 || !course_ok(course, true) || (n && (!state || !target_ind || !xref)))
+    return fail(CRX_ERR_INVALID, "calc_ref_trajectory: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n;
+  DevCourse dc; DevBuf ds, di, dx;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dx, 16 * nn * T);
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_calc_ref_trajectory_batch_dev(n, T, ds.as<float>(), &dc.c, dl, dt, nsearch, di.as<int>(), dx.as<float>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
+  CRX_HIP(hipMemcpy(xref, dx.p, 16 * nn * T, hipMemcpyDeviceToHost));
   return CRX_OK;
 }
 

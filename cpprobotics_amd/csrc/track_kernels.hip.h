@@ -1,0 +1,345 @@
+// track_kernels.hip.h — the callers on either side of the DARE / MPC solves, batched for gfx950:
+// course tracking front-end, bicycle-model update, and the closed LQR loop as one persistent kernel.
+//
+// Replaces, for n independent agents on one shared course,
+//   calc_nearest_index      /root/reference/src/lqr_speed_steer_control.cpp:65-83 (= src/lqr_steer_control.cpp:55-73)
+//   lqr_steering_control    src/lqr_speed_steer_control.cpp:108-151 (5-state, speed + steer)
+//                           src/lqr_steer_control.cpp:98-133       (4-state, steer only)
+//   update                  src/lqr_speed_steer_control.cpp:154-164 ; src/model_predictive_control.cpp:69-81
+//   closed_loop_prediction  src/lqr_speed_steer_control.cpp:166-205 ; src/lqr_steer_control.cpp:146-197 (math only)
+//   calc_nearest_index      src/model_predictive_control.cpp:107-127 (window of N_IND_SEARCH from pind)
+//   calc_ref_trajectory     src/model_predictive_control.cpp:130-170
+//
+// Arithmetic contract (bit parity with the reference's CPU build): fp32 where the reference computes in
+// float, double where a `#define`d double literal (DT, L, WB, M_PI, MAX_STEER ...) promotes the expression,
+// one rounding back to float at each assignment to a float variable, no fma contraction; cosf/sinf =
+// crx_trig.h, atan2f/tanf = crx_fdlibm.h (both bit-identical to glibc), fmod is exact by definition.
+// One deviation is possible and documented: the feed-forward term atan2(L*k, 1.0) is a DOUBLE atan2 in the
+// reference (glibc, correctly rounded); the device evaluates OCML's double atan (<= 2 ulp) and rounds to
+// float, so that float can differ from the reference's in about one of 10^8 curvature values.
+//
+// Layout: agent state [n][4] = (x, y, yaw, v) — the reference's `struct State` (include/motion_model.h:31-42);
+// the course is five shared read-only arrays of ncourse floats (cx, cy, cyaw, ck, sp).  One agent per lane.
+// The nearest-point search is a linear scan of the whole course per agent per tick, as in the reference; the
+// (cx, cy) pairs are staged once per workgroup in LDS and read as wave-wide broadcasts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "crx_fdlibm.h"
+#include "crx_trig.h"
+#include "dare_kernels.hip.h"
+
+namespace crx {
+
+struct CourseView {
+  const float* cx; const float* cy; const float* cyaw; const float* ck; const float* sp;
+  int n;
+};
+
+struct VehicleParams {   // update(): LQR files use DT 0.1, L 0.5, no speed clamp; MPC uses DT 0.2, WB 2.5 + clamp
+  double dt, wheelbase, max_steer, max_speed, min_speed;
+  int clamp_speed;
+};
+
+constexpr int kTrackBlock = 256;
+constexpr int kCourseLdsMax = 8192;   // (cx,cy) pairs staged in LDS: 64 KB
+
+// #define YAW_P2P(angle) std::fmod(std::fmod((angle)+M_PI, 2*M_PI)-2*M_PI, 2*M_PI)+M_PI   (include/motion_model.h:18)
+// The macro argument is a float expression in every use; M_PI promotes the arithmetic to double.
+__device__ __forceinline__ double yaw_p2p(float angle) {
+  const double pi = 3.14159265358979323846, two_pi = 2 * 3.14159265358979323846;
+  return fmod(fmod((double)angle + pi, two_pi) - two_pi, two_pi) + pi;
+}
+
+// calc_nearest_index of the LQR files: full scan, first strict minimum of the SQUARED distance; returns that
+// squared distance signed by the side of the course the vehicle is on.  `ind` keeps its incoming value if no
+// point compares smaller (NaN position) — as the reference's by-reference parameter does.
+template <bool LDS>
+__device__ __forceinline__ float calc_nearest_index_dev(float sx, float sy, const CourseView& c,
+                                                        const float2* __restrict__ pts, int& ind) {
+  float mind = FLT_MAX;
+  int best = ind;
+  for (int i = 0; i < c.n; ++i) {
+    float px, py;
+    if (LDS) { const float2 p = pts[i]; px = p.x; py = p.y; }
+    else { px = c.cx[i]; py = c.cy[i]; }
+    const float idx = px - sx, idy = py - sy;
+    const float d_e = idx * idx + idy * idy;
+    if (d_e < mind) { mind = d_e; best = i; }
+  }
+  ind = best;
+  const int j = best < 0 ? 0 : (best >= c.n ? c.n - 1 : best);   // memory safety only (stale caller index + NaN position)
+  const float dxl = c.cx[j] - sx, dyl = c.cy[j] - sy;
+  const float angle = (float)yaw_p2p(c.cyaw[j] - atan2f_(dyl, dxl));
+  if (angle < 0) mind = -mind;       // mind * -1
+  return mind;
+}
+
+// A, B from v; Q = I, R = I; cold-started fixed point (dare_kernels.hip.h).  All lanes of the wave iterate
+// until the slowest one has converged (each lane freezes its X when its own test passes).
+template <int DIM>
+__device__ __forceinline__ void dlqr_from_v_dev(float v, float dtf, double L, float eps, int maxiter, bool live, float* K) {
+  constexpr int NN = DIM * DIM;
+  const float bv = (float)((double)v / L);   // B(3,0) = state.v / L
+  float X[NN], Xn[NN];
+#pragma unroll
+  for (int i = 0; i < NN; ++i) X[i] = (i % (DIM + 1) == 0) ? 1.0f : 0.0f;
+  bool done = !live || maxiter <= 0;
+  for (int i = 0; i < maxiter; ++i) {
+    if (!done) {
+      if (DIM == 5) dare5_v_iter(dtf, v, bv, dtf, X, Xn);
+      else dare4_v_iter(dtf, v, bv, X, Xn);
+      const float err = max_abs_diff<NN>(Xn, X);
+#pragma unroll
+      for (int j = 0; j < NN; ++j) X[j] = Xn[j];
+      if (err < eps) done = true;
+    }
+    if (__all(done)) break;
+  }
+  if (DIM == 5) dlqr5_v_gain(dtf, v, bv, dtf, X, K);
+  else dlqr4_v_gain(dtf, v, bv, X, K);
+}
+
+struct LqrCtl { float ai, delta; };
+
+// lqr_steering_control.  DIM 5: returns {ai, delta} (ind is a local starting at 0, :109).  DIM 4: returns
+// delta only (ai = 0 here; the caller adds its PID term) and `ind` is the caller's persistent index (:98).
+template <int DIM, bool LDS>
+__device__ __forceinline__ LqrCtl lqr_steering_control_dev(float sx, float sy, float syaw, float sv,
+                                                           const CourseView& c, const float2* __restrict__ pts,
+                                                           int& ind, float& pe, float& pth_e, double dt, double L,
+                                                           float eps, int maxiter, bool live) {
+  if (DIM == 5) ind = 0;
+  const float e = calc_nearest_index_dev<LDS>(sx, sy, c, pts, ind);
+  const int j = ind < 0 ? 0 : (ind >= c.n ? c.n - 1 : ind);
+  const float k = c.ck[j];
+  const float th_e = (float)yaw_p2p(syaw - c.cyaw[j]);
+  float K[(DIM == 5 ? 2 : 1) * DIM];
+  dlqr_from_v_dev<DIM>(sv, (float)dt, L, eps, maxiter, live, K);
+  const float x0 = e;
+  const float x1 = (float)((double)(e - pe) / dt);
+  const float x2 = th_e;
+  const float x3 = (float)((double)(th_e - pth_e) / dt);
+  LqrCtl out;
+  float u0;
+  if (DIM == 5) {
+    const float x4 = sv - c.sp[j];
+    // ustar = -K * x : (2x5)*(5x1) lazy product, 5-term unrolled redux (t0+t1)+(t2+(t3+t4))  (oracle/eigen_order.h C2)
+    float t[5], s[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { t[j] = (-K[0 + 2 * j]); s[j] = (-K[1 + 2 * j]); }
+    t[0] *= x0; t[1] *= x1; t[2] *= x2; t[3] *= x3; t[4] *= x4;
+    s[0] *= x0; s[1] *= x1; s[2] *= x2; s[3] *= x3; s[4] *= x4;
+    u0 = (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
+    out.ai = (s[0] + s[1]) + (s[2] + (s[3] + s[4]));
+  } else {
+    // (-K * x)(0) : row vector times vector, one SSE packet: (t0+t2)+(t1+t3)  (oracle/eigen_order.h C1)
+    const float t0 = (-K[0]) * x0, t1 = (-K[1]) * x1, t2 = (-K[2]) * x2, t3 = (-K[3]) * x3;
+    u0 = (t0 + t2) + (t1 + t3);
+    out.ai = 0.0f;
+  }
+  const float ff = (float)atan(L * (double)k);    // std::atan2((L*k), (double)1.0)
+  const float fb = (float)yaw_p2p(u0);
+  out.delta = ff + fb;
+  pe = e;
+  pth_e = th_e;
+  return out;
+}
+
+// update(State&, a, delta)
+__device__ __forceinline__ void update_dev(float& sx, float& sy, float& syaw, float& sv, float a, float delta,
+                                           const VehicleParams& p) {
+  if ((double)delta >= p.max_steer) delta = (float)p.max_steer;
+  if ((double)delta <= -p.max_steer) delta = (float)(-p.max_steer);
+  float sn, cs;
+  sincosf_(syaw, &sn, &cs);
+  const float nx = (float)((double)sx + (double)(sv * cs) * p.dt);
+  const float ny = (float)((double)sy + (double)(sv * sn) * p.dt);
+  const float nyaw = (float)((double)syaw + (double)sv / p.wheelbase * (double)tanf_(delta) * p.dt);
+  float nv = (float)((double)sv + (double)a * p.dt);
+  if (p.clamp_speed) {
+    if ((double)nv > p.max_speed) nv = (float)p.max_speed;
+    if ((double)nv < p.min_speed) nv = (float)p.min_speed;
+  }
+  sx = nx; sy = ny; syaw = nyaw; sv = nv;
+}
+
+__device__ __forceinline__ void stage_course(const CourseView& c, float2* pts) {
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) pts[i] = make_float2(c.cx[i], c.cy[i]);
+  __syncthreads();
+}
+
+// ---- one control evaluation per agent --------------------------------------------------------------
+template <int DIM, bool LDS>
+__global__ void __launch_bounds__(kTrackBlock)
+lqr_steering_control_kernel(int n, const float* __restrict__ state, CourseView c, int* __restrict__ ind_io,
+                            float* __restrict__ pe_io, float* __restrict__ pth_io, double dt, double L, float eps,
+                            int maxiter, float* __restrict__ control) {
+  extern __shared__ float2 pts[];
+  if (LDS) stage_course(c, pts);
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = a < (size_t)n;
+  const size_t aa = live ? a : 0;
+  const float4 s = reinterpret_cast<const float4*>(state)[aa];
+  int ind = (DIM == 4 && ind_io) ? ind_io[aa] : 0;
+  float pe = pe_io[aa], pth = pth_io[aa];
+  const LqrCtl u = lqr_steering_control_dev<DIM, LDS>(s.x, s.y, s.z, s.w, c, pts, ind, pe, pth, dt, L, eps, maxiter, live);
+  if (!live) return;
+  if (ind_io) ind_io[a] = ind;
+  pe_io[a] = pe; pth_io[a] = pth;
+  if (DIM == 5) reinterpret_cast<float2*>(control)[a] = make_float2(u.ai, u.delta);
+  else control[a] = u.delta;
+}
+
+__global__ void __launch_bounds__(kTrackBlock)
+update_kernel(int n, float* __restrict__ state, const float* __restrict__ a_in, const float* __restrict__ delta_in,
+              VehicleParams p) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (size_t)n) return;
+  float4 s = reinterpret_cast<float4*>(state)[a];
+  update_dev(s.x, s.y, s.z, s.w, a_in[a], delta_in[a], p);
+  reinterpret_cast<float4*>(state)[a] = s;
+}
+
+// ---- the closed LQR loop: control + update + goal test, max_ticks times, state in registers ------------
+// DIM 5: closed_loop_prediction of lqr_speed_steer_control.cpp (:166-205).  DIM 4: of lqr_steer_control.cpp
+// (:146-197): ai = KP*(speed_profile[ind] - v), ind += 1 while |v| <= stop_speed.
+// The reference's loops never advance `time_` (they run until the goal is reached); max_ticks bounds them here.
+// ticks_done[a] = number of control+update ticks executed (the goal tick included); traj_hist (optional,
+// [max_ticks][n][4]) receives the state after each tick (rows past ticks_done are left untouched).
+template <int DIM, bool LDS>
+__global__ void __launch_bounds__(kTrackBlock)
+lqr_closed_loop_kernel(int n, int max_ticks, float* __restrict__ state, CourseView c, float* __restrict__ pe_io,
+                       float* __restrict__ pth_io, int* __restrict__ ind_io, double dt, double L, float eps, int maxiter,
+                       VehicleParams vp, float goal_x, float goal_y, float goal_dis, double kp, float stop_speed,
+                       float* __restrict__ traj_hist, int* __restrict__ ticks_done) {
+  extern __shared__ float2 pts[];
+  if (LDS) stage_course(c, pts);
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = a < (size_t)n;
+  const size_t aa = live ? a : 0;
+  float4 s = reinterpret_cast<const float4*>(state)[aa];
+  float pe = pe_io ? pe_io[aa] : 0.0f, pth = pth_io ? pth_io[aa] : 0.0f;
+  int ind = ind_io ? ind_io[aa] : 0;
+  bool done = !live;
+  int ticks = 0;
+  for (int t = 0; t < max_ticks; ++t) {
+    if (__all(done)) break;
+    float4 sn = s;
+    float pe_n = pe, pth_n = pth;
+    int ind_n = ind;
+    const LqrCtl u = lqr_steering_control_dev<DIM, LDS>(sn.x, sn.y, sn.z, sn.w, c, pts, ind_n, pe_n, pth_n, dt, L, eps,
+                                                        maxiter, !done);
+    float ai = u.ai;
+    if (DIM == 4) {                                                   // float ai = KP * (speed_profile[ind]-state.v)
+      const int js = ind_n < 0 ? 0 : (ind_n >= c.n ? c.n - 1 : ind_n);
+      ai = (float)(kp * (double)(c.sp[js] - sn.w));
+    }
+    update_dev(sn.x, sn.y, sn.z, sn.w, ai, u.delta, vp);
+    if (DIM == 4 && fabsf(sn.w) <= stop_speed) ind_n += 1;
+    if (!done) {
+      s = sn; pe = pe_n; pth = pth_n; ind = ind_n;
+      ticks = t + 1;
+      if (traj_hist) reinterpret_cast<float4*>(traj_hist)[(size_t)t * n + a] = s;
+      const float dx = s.x - goal_x, dy = s.y - goal_y;
+      if (sqrtf(dx * dx + dy * dy) <= goal_dis) done = true;
+    }
+  }
+  if (!live) return;
+  reinterpret_cast<float4*>(state)[a] = s;
+  if (pe_io) pe_io[a] = pe;
+  if (pth_io) pth_io[a] = pth;
+  if (ind_io) ind_io[a] = ind;
+  if (ticks_done) ticks_done[a] = ticks;
+}
+
+// ---- MPC front-end --------------------------------------------------------------------------------------
+// calc_nearest_index(state, cx, cy, cyaw, pind) of model_predictive_control.cpp: window [pind, pind+N_IND_SEARCH).
+// The reference reads cx[i] without a bounds check (:110); the window is clipped to the course here.
+__device__ __forceinline__ int calc_nearest_index_window_dev(float sx, float sy, const CourseView& c, int pind, int nsearch) {
+  float mind = FLT_MAX;
+  float ind = 0;                          // `float ind = 0;` (:108) — the index travels through a float
+  const int lo = pind < 0 ? 0 : pind;
+  const long long hi_ll = (long long)pind + nsearch;
+  const int hi = hi_ll > c.n ? c.n : (int)hi_ll;
+  for (int i = lo; i < hi; ++i) {
+    const float idx = c.cx[i] - sx, idy = c.cy[i] - sy;
+    const float d_e = idx * idx + idy * idy;
+    if (d_e < mind) { mind = d_e; ind = (float)i; }
+  }
+  return (int)ind;
+}
+
+// calc_ref_trajectory (:130-170).  xref: column-major 4 x T per agent (Eigen::Matrix<float,NX,T>::data()).
+__global__ void __launch_bounds__(kTrackBlock)
+calc_ref_trajectory_kernel(int n, int T, const float* __restrict__ state, CourseView c, float dl, double dt, int nsearch,
+                           int* __restrict__ target_ind, float* __restrict__ xref, const int* __restrict__ active) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (size_t)n) return;
+  if (active && !active[a]) return;
+  const float4 s = reinterpret_cast<const float4*>(state)[a];
+  const int tind = target_ind[a];
+  int ind = calc_nearest_index_window_dev(s.x, s.y, c, tind, nsearch);
+  if (tind >= ind) ind = tind;
+  float* xr = xref + (size_t)a * 4 * T;
+  float travel = 0.0f;
+  const int last = c.n - 1;
+  for (int i = 0; i < T; ++i) {
+    travel = (float)((double)travel + (double)fabsf(s.w) * dt);     // travel += std::abs(state.v) * DT
+    const int dind = (int)roundf(travel / dl);
+    const long long j_ll = (long long)ind + dind;
+    const int j = (j_ll < c.n) ? (int)j_ll : last;
+    xr[4 * i + 0] = c.cx[j]; xr[4 * i + 1] = c.cy[j]; xr[4 * i + 2] = c.cyaw[j]; xr[4 * i + 3] = c.sp[j];
+  }
+  target_ind[a] = ind;
+}
+
+__global__ void __launch_bounds__(kTrackBlock)
+calc_nearest_index_window_kernel(int n, const float* __restrict__ state, CourseView c, const int* __restrict__ pind, int nsearch,
+                                 int* __restrict__ ind_out) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (size_t)n) return;
+  const float4 s = reinterpret_cast<const float4*>(state)[a];
+  ind_out[a] = calc_nearest_index_window_dev(s.x, s.y, c, pind[a], nsearch);
+}
+
+template <bool LDS>
+__global__ void __launch_bounds__(kTrackBlock)
+calc_nearest_index_kernel(int n, const float* __restrict__ state, CourseView c, int* __restrict__ ind_io, float* __restrict__ e_out) {
+  extern __shared__ float2 pts[];
+  if (LDS) stage_course(c, pts);
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (size_t)n) return;
+  const float4 s = reinterpret_cast<const float4*>(state)[a];
+  int ind = ind_io[a];
+  const float e = calc_nearest_index_dev<LDS>(s.x, s.y, c, pts, ind);
+  ind_io[a] = ind;
+  if (e_out) e_out[a] = e;
+}
+
+__global__ void fill_int_kernel(int n, int* __restrict__ p, int v) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a < (size_t)n) p[a] = v;
+}
+
+// MPC closed loop (mpc_simulation :371-385), the per-tick tail: update with the first control of the solution,
+// goal test, bookkeeping.  sol: n x (4T + 2(T-1)), the reference's layout; delta_start = 4T, a_start = 4T + T-1.
+__global__ void __launch_bounds__(kTrackBlock)
+mpc_tick_tail_kernel(int n, int T, int tick, float* __restrict__ state, const float* __restrict__ sol, VehicleParams vp,
+                     float goal_x, float goal_y, float goal_dis, int* __restrict__ active, int* __restrict__ ticks_done,
+                     float* __restrict__ traj_hist) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= (size_t)n) return;
+  if (!active[a]) return;
+  const int nv = 4 * T + 2 * (T - 1);
+  const float* o = sol + (size_t)a * nv;
+  float4 s = reinterpret_cast<float4*>(state)[a];
+  update_dev(s.x, s.y, s.z, s.w, o[4 * T + (T - 1)], o[4 * T], vp);
+  reinterpret_cast<float4*>(state)[a] = s;
+  ticks_done[a] = tick + 1;
+  if (traj_hist) reinterpret_cast<float4*>(traj_hist)[(size_t)tick * n + a] = s;
+  const float dx = s.x - goal_x, dy = s.y - goal_y;
+  if (sqrtf(dx * dx + dy * dy) <= goal_dis) active[a] = 0;
+}
+
+}  // namespace crx

@@ -23,6 +23,7 @@
 #ifndef CRX_H_
 #define CRX_H_
 
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -156,6 +157,89 @@ int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref,
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,
                             const crx_mpc_params* prm, float* sol, int* status, double* cost,
                             void* stream);
+
+
+/* ---- course tracking front-end, vehicle update, closed loops ------------------------------------
+ * The callers on either side of the solves.
+ * State: n x 4 floats (x, y, yaw, v) = the reference's `struct State` (include/motion_model.h:31-42).
+ * The course is shared by all agents: five arrays of `n` floats (cx, cy, cyaw, ck, sp), as the
+ * reference's main() builds them with Spline2D + calc_speed_profile (course generation itself is out
+ * of scope).  In the _dev entry points the arrays are device pointers. */
+typedef struct crx_course {
+  int n;
+  const float* cx;
+  const float* cy;
+  const float* cyaw;
+  const float* ck;   /* curvature; only lqr_steering_control reads it */
+  const float* sp;   /* speed profile */
+} crx_course;
+
+typedef struct crx_vehicle_params {  /* update(State&, a, delta) */
+  double dt;          /* DT:  0.1 in the LQR files, 0.2 in the MPC file                                  */
+  double wheelbase;   /* L 0.5 (src/lqr_speed_steer_control.cpp:21) / WB 2.5 (model_predictive_control.cpp:36) */
+  double max_steer;   /* 45.0/180*M_PI                                                                  */
+  int clamp_speed;    /* 0: LQR update (:154-164); 1: MPC update (:69-81) clamps v to [min_speed, max_speed] */
+  double max_speed, min_speed;   /* 55.0/3.6, -20.0/3.6 (:37-38)                                        */
+} crx_vehicle_params;
+void crx_vehicle_default_params(crx_vehicle_params* p, int mpc /* 0: LQR files, 1: MPC file */);
+
+/* calc_nearest_index(state, cx, cy, cyaw, ind)  src/lqr_speed_steer_control.cpp:65-83 (full scan; returns the
+ * signed SQUARED distance in e, the index through ind — in/out: an agent whose position compares smaller to no
+ * course point (NaN) keeps its incoming ind, as the reference's reference parameter does). */
+int crx_calc_nearest_index_batch(int n, const float* state, const crx_course* course, int* ind, float* e);
+int crx_calc_nearest_index_batch_dev(int n, const float* state, const crx_course* course, int* ind, float* e, void* stream);
+
+/* lqr_steering_control.
+ * dim 5: src/lqr_speed_steer_control.cpp:108-151 — control: n x 2 {ai, delta}; ind (may be NULL): out only.
+ * dim 4: src/lqr_steer_control.cpp:98-133        — control: n x 1 {delta};     ind: in/out (the caller's persistent index).
+ * pe, pth_e: n floats, in/out (previous lateral / heading error). */
+int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
+                                   float* pth_e, const crx_lqr_params* prm, float* control);
+int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
+                                       float* pth_e, const crx_lqr_params* prm, float* control, void* stream);
+
+/* update(state, a, delta) for n agents, in place. */
+int crx_update_batch(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm);
+int crx_update_batch_dev(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm, void* stream);
+
+/* closed_loop_prediction, maths only (src/lqr_speed_steer_control.cpp:194-205 for dim 5, src/lqr_steer_control.cpp:186-196
+ * for dim 4): per tick lqr_steering_control -> update -> goal test, as ONE kernel with the agent state in registers.
+ * The reference's loops never advance their clock and only end at the goal; max_ticks bounds them here.
+ * state: in/out.  pe, pth_e, ind: in/out per-agent loop variables (NULL = start from 0 as the reference does).
+ * kp, stop_speed: the 4-state loop's `KP` and `stop_speed` (ignored for dim 5).
+ * ticks_done (may be NULL): ticks executed per agent (== max_ticks if the goal was not reached).
+ * traj_hist (may be NULL): [max_ticks][n][4], the state after each executed tick. */
+typedef struct crx_loop_params {
+  float goal_x, goal_y, goal_dis;   /* goal_dis: 0.3 (5-state file :168) / 0.5 (4-state file :148, MPC :353) */
+  double kp;                        /* KP 1.0 (src/lqr_steer_control.cpp:22) */
+  float stop_speed;                 /* 0.05 */
+  int max_ticks;
+} crx_loop_params;
+int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                              const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                              float* traj_hist, int* ticks_done);
+int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                                  const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                                  float* traj_hist, int* ticks_done, void* stream);
+
+/* MPC front-end: calc_nearest_index(state, cx, cy, cyaw, pind) src/model_predictive_control.cpp:107-127 (window of
+ * nsearch = N_IND_SEARCH points from pind; the reference's unchecked read past the course end is clipped) and
+ * calc_ref_trajectory :130-170 (xref: n x 4T, column-major 4 x T per agent; target_ind in/out). */
+int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
+                                            int* ind_out, void* stream);
+int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_course* course, float dl, double dt, int nsearch,
+                                  int* target_ind, float* xref);
+int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const crx_course* course, float dl, double dt,
+                                      int nsearch, int* target_ind, float* xref, void* stream);
+
+/* mpc_simulation's loop (:371-385), maths only: per tick calc_ref_trajectory -> mpc_solve -> update (first control of the
+ * solution) -> goal test, for n agents; three kernels per tick enqueued on `stream` (no host synchronisation inside).
+ * Agents that reached the goal stop being updated.  target_ind: in/out.  work: device scratch of
+ * crx_mpc_closed_loop_work_bytes(n, T) bytes. */
+size_t crx_mpc_closed_loop_work_bytes(int n, int T);
+int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
+                                  const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
+                                  int* ticks_done, void* work, void* stream);
 
 #ifdef __cplusplus
 }

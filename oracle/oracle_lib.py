@@ -17,7 +17,7 @@ _F = C.c_float
 
 def build(force=False):
     """g++ -O2 -ffp-contract=off (oracle/Makefile).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "eigen_order.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "eigen_order.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -188,3 +188,109 @@ def mpc_cost(x0, xref, T, U, params=None):
     f.restype = _D
     J = f(_I(T), _p(x0), _p(xref), _p(pp), _p(U), _p(S))
     return float(J), S
+
+
+# ---- course tracking / vehicle update / closed loops (oracle/track_ref.cpp) -----------------------
+def _course(course):
+    cx, cy, cyaw, ck, sp = (_f32(a) for a in course)
+    return cx, cy, cyaw, ck, sp
+
+
+def _track_lib():
+    l = lib()
+    l.oracle_track_set_trig_mode(_I(trig_mode()))
+    return l
+
+
+def calc_nearest_index(state, course, ind=None):
+    """LQR files' calc_nearest_index: returns (ind [n], e [n])."""
+    state = _f32(state)
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    ind = np.zeros(n, dtype=np.int32) if ind is None else np.ascontiguousarray(ind, dtype=np.int32).copy()
+    e = np.zeros(n, dtype=np.float32)
+    _track_lib().oracle_calc_nearest_index(_I(n), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ind), _p(e))
+    return ind, e
+
+
+def lqr_steering_control(state, course, pe, pth_e, dim=5, ind=None, dt=0.1, L=0.5, eps=0.01, maxiter=150, agents=None):
+    """Returns (control [n,2]={ai,delta} for dim 5 / [n]=delta for dim 4, ind, pe, pth_e) — inputs untouched."""
+    state = _f32(state)
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    pe, pth_e = _f32(pe).copy(), _f32(pth_e).copy()
+    ind = np.zeros(n, dtype=np.int32) if ind is None else np.ascontiguousarray(ind, dtype=np.int32).copy()
+    control = np.zeros((n, 2) if dim == 5 else (n,), dtype=np.float32)
+    a0, a1 = (0, n) if agents is None else agents
+    _track_lib().oracle_lqr_steering_control(_I(n), _I(dim), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp),
+                                             _p(ind), _p(pe), _p(pth_e), _D(dt), _D(L), _F(eps), _I(maxiter), _p(control),
+                                             _I(a0), _I(a1))
+    return control, ind, pe, pth_e
+
+
+def update(state, a, delta, dt=0.1, wheelbase=0.5, max_steer=45.0 / 180 * _math.pi, clamp_speed=False,
+           max_speed=55.0 / 3.6, min_speed=-20.0 / 3.6):
+    state = _f32(state).copy()
+    a, delta = _f32(a), _f32(delta)
+    _track_lib().oracle_update(_I(state.shape[0]), _p(state), _p(a), _p(delta), _D(dt), _D(wheelbase), _D(max_steer),
+                               _I(1 if clamp_speed else 0), _D(max_speed), _D(min_speed))
+    return state
+
+
+def lqr_closed_loop(state, course, goal, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L=0.5, eps=0.01, maxiter=150,
+                    max_steer=45.0 / 180 * _math.pi, kp=1.0, stop_speed=0.05, want_hist=False, agents=None):
+    """Returns (state, ticks_done, traj_hist or None, pe, pth_e, ind)."""
+    state = _f32(state).copy()
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    if goal_dis is None:
+        goal_dis = 0.3 if dim == 5 else 0.5
+    pe, pth = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+    ind = np.zeros(n, dtype=np.int32)
+    ticks = np.zeros(n, dtype=np.int32)
+    hist = np.zeros((max_ticks, n, 4), dtype=np.float32) if want_hist else None
+    a0, a1 = (0, n) if agents is None else agents
+    _track_lib().oracle_lqr_closed_loop(_I(n), _I(dim), _I(max_ticks), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck),
+                                        _p(sp), _p(pe), _p(pth), _p(ind), _D(dt), _D(L), _F(eps), _I(maxiter), _D(max_steer),
+                                        _F(goal[0]), _F(goal[1]), _F(goal_dis), _D(kp), _F(stop_speed), _p(hist), _p(ticks),
+                                        _I(a0), _I(a1))
+    return state, ticks, hist, pe, pth, ind
+
+
+def calc_nearest_index_window(state, course, pind, nsearch=10):
+    state = _f32(state)
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    pind = np.ascontiguousarray(pind, dtype=np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    _track_lib().oracle_calc_nearest_index_window(_I(n), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(pind), _I(nsearch), _p(out))
+    return out
+
+
+def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10):
+    """Returns (xref [n,4T] column-major 4xT per agent, target_ind)."""
+    state = _f32(state)
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    tind = np.ascontiguousarray(target_ind, dtype=np.int32).copy()
+    xref = np.zeros((n, 4 * T), dtype=np.float32)
+    _track_lib().oracle_calc_ref_trajectory(_I(n), _I(T), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp),
+                                            _F(dl), _D(dt), _I(nsearch), _p(tind), _p(xref))
+    return xref, tind
+
+
+def mpc_closed_loop(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, nsearch=10, goal_dis=0.5, params=None,
+                    max_iter=50, want_hist=False, agents=None):
+    """mpc_simulation's loop with the oracle's MPC twin.  Returns (state, ticks_done, traj_hist, target_ind)."""
+    state = _f32(state).copy()
+    n = state.shape[0]
+    cx, cy, cyaw, ck, sp = _course(course)
+    tind = np.zeros(n, dtype=np.int32) if target_ind is None else np.ascontiguousarray(target_ind, dtype=np.int32).copy()
+    ticks = np.zeros(n, dtype=np.int32)
+    hist = np.zeros((max_ticks, n, 4), dtype=np.float32) if want_hist else None
+    pp = _mpc_params(params)
+    a0, a1 = (0, n) if agents is None else agents
+    _track_lib().oracle_mpc_closed_loop(_I(n), _I(T), _I(max_ticks), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck),
+                                        _p(sp), _F(dl), _I(nsearch), _p(pp), _I(max_iter), _F(goal[0]), _F(goal[1]),
+                                        _F(goal_dis), _p(tind), _p(hist), _p(ticks), _I(a0), _I(a1))
+    return state, ticks, hist, tind

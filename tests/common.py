@@ -116,3 +116,50 @@ def mpc_problem(n, T, seed, dt=0.2, dl=1.0):
         j = np.minimum(ind + np.round(travel / dl).astype(np.int64), nc - 1)
         xref[:, i, 0] = cx[j]; xref[:, i, 1] = cy[j]; xref[:, i, 2] = cyaw[j]; xref[:, i, 3] = sp[j]
     return x0, xref.reshape(n, 4 * T)
+
+
+# ---- LQR course (lqr_speed_steer_control.cpp main(): waypoints :248-249, ds = 0.1, target speed 10 km/h) -------
+def _spline_dd(sp, t):
+    s, a, b, c, d = sp
+    i = np.clip(np.searchsorted(s, t, side="right") - 1, 0, len(s) - 2)
+    return 2 * c[i] + 6 * d[i] * (t - s[i])
+
+
+def lqr_course(ds=0.1):
+    """Course arrays (cx, cy, cyaw, ck, sp) and the goal, built as the reference's main() builds them (Spline2D
+    through its waypoints, calc_speed_profile's end-of-course slow-down :55-60).  Input data for the tracking
+    kernels; float64 maths rounded to float32 (the course is an input, not part of the parity contract)."""
+    wx = [0.0, 6.0, 12.5, 10.0, 17.5, 20.0, 25.0]
+    wy = [0.0, -3.0, -5.0, 6.5, 3.0, 0.0, 0.0]
+    s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(wx), np.diff(wy)))])
+    sx, sy = natural_cubic_spline(s, wx), natural_cubic_spline(s, wy)
+    t = np.arange(0.0, s[-1], ds)
+    cx, dx = _spline_eval(sx, t)
+    cy, dy = _spline_eval(sy, t)
+    ddx, ddy = _spline_dd(sx, t), _spline_dd(sy, t)
+    cyaw = np.arctan2(dy, dx)
+    ck = (ddy * dx - ddx * dy) / (dx * dx + dy * dy)
+    sp = np.full_like(cx, 10.0 / 3.6)
+    for k in range(1, 40):
+        sp[-k] = max((10.0 / 3.6) / (50 - k), 1.0 / 3.6)
+    course = tuple(np.ascontiguousarray(a, dtype=np.float32) for a in (cx, cy, cyaw, ck, sp))
+    return course, (float(wx[-1]), float(wy[-1]))
+
+
+def mpc_course_f32(ds=1.0):
+    cx, cy, cyaw, sp = mpc_course(ds)
+    ck = np.zeros_like(cx)
+    sp = sp.copy(); sp[-1] = 0.0
+    course = tuple(np.ascontiguousarray(a, dtype=np.float32) for a in (cx, cy, cyaw, ck, sp))
+    return course, (-10.0, -20.0)
+
+
+def tracking_agents(n, course, seed, spread=0.5):
+    """n vehicle states scattered around random course points (lateral/longitudinal ~N(0,spread), yaw ~N(0,0.2),
+    v ~ U(-1, 4)) — the batch analogue of the reference's single start state."""
+    rng = np.random.default_rng(seed)
+    cx, cy, cyaw = course[0], course[1], course[2]
+    i = rng.integers(0, len(cx), n)
+    st = np.stack([cx[i] + rng.normal(0, spread, n), cy[i] + rng.normal(0, spread, n),
+                   cyaw[i] + rng.normal(0, 0.2, n), rng.uniform(-1.0, 4.0, n)], axis=1)
+    return st.astype(np.float32)

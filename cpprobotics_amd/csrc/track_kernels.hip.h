@@ -41,7 +41,7 @@ struct VehicleParams {   // update(): LQR files use DT 0.1, L 0.5, no speed clam
   int clamp_speed;
 };
 
-constexpr int kTrackBlock = 256;
+constexpr int kTrackBlock = 64;    // one wave per workgroup: BASELINE-sized batches (8k-16k agents) then cover all 256 CUs
 constexpr int kCourseLdsMax = 8192;   // (cx,cy) pairs staged in LDS: 64 KB
 
 // #define YAW_P2P(angle) std::fmod(std::fmod((angle)+M_PI, 2*M_PI)-2*M_PI, 2*M_PI)+M_PI   (include/motion_model.h:18)

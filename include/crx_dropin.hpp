@@ -8,6 +8,10 @@
 //   src/lqr_speed_steer_control.cpp:85-106 solve_DARE (5x5), dlqr (5x5)
 //   src/lqr_steer_control.cpp:75-96        solve_DARE (4x4), dlqr (4x4)
 //   src/model_predictive_control.cpp:255-346 mpc_solve
+//   and the callers on either side of the solves — calc_nearest_index, lqr_steering_control, update,
+//   calc_ref_trajectory — in one namespace per reference translation unit (the three files reuse the names
+//   `update` / `calc_nearest_index` with different bodies): crx_dropin::lqr_speed_steer, ::lqr_steer, ::mpc.
+//   `using namespace crx_dropin::lqr_speed_steer;` after deleting src/lqr_speed_steer_control.cpp:65-164 etc.
 //
 // Every function forwards `.data()` pointers (Eigen fixed-size matrices are column-major and
 // contiguous, exactly the ABI's layout) with n = 1 through the host-pointer entry points, which copy
@@ -155,5 +159,70 @@ inline void ekf_estimation_batch(std::vector<crx::Mat<4, 1>>& xEst, std::vector<
   crx::dropin_check(crx_ekf_step_batch(n, xEst[0].data(), PEst[0].data(), z[0].data(), u[0].data(), Q.data(), R.data(), nullptr),
                     "ekf_estimation_batch");
 }
+
+}  // namespace crx_dropin
+
+// ---- the callers on either side of the solves, one namespace per reference translation unit -----------
+namespace crx_dropin {
+using cpprobotics::State;
+using cpprobotics::Vec_f;
+
+inline crx_course course_of(const Vec_f& cx, const Vec_f& cy, const Vec_f& cyaw, const Vec_f* ck, const Vec_f* sp) {
+  if (cy.size() != cx.size() || cyaw.size() != cx.size()) throw std::invalid_argument("course arrays differ in length");
+  return crx_course{(int)cx.size(), cx.data(), cy.data(), cyaw.data(), ck ? ck->data() : nullptr, sp ? sp->data() : nullptr};
+}
+
+namespace lqr_speed_steer {   // src/lqr_speed_steer_control.cpp
+inline float calc_nearest_index(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, int& ind) {                     // :65
+  const crx_course c = course_of(cx, cy, cyaw, nullptr, nullptr);
+  const float s[4] = {state.x, state.y, state.yaw, state.v};
+  float e = 0.0f;
+  crx::dropin_check(crx_calc_nearest_index_batch(1, s, &c, &ind, &e), "calc_nearest_index");
+  return e;
+}
+inline Vec_f lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f sp, float& pe, float& pth_e) {   // :108
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &sp);
+  const float s[4] = {state.x, state.y, state.yaw, state.v};
+  float u[2];
+  crx::dropin_check(crx_lqr_steering_control_batch(1, 5, s, &c, nullptr, &pe, &pth_e, nullptr, u), "lqr_steering_control");
+  return {u[0], u[1]};
+}
+inline void update(State& state, float a, float delta) {                                                     // :154
+  float s[4] = {state.x, state.y, state.yaw, state.v};
+  crx::dropin_check(crx_update_batch(1, s, &a, &delta, nullptr), "update");
+  state.x = s[0]; state.y = s[1]; state.yaw = s[2]; state.v = s[3];
+}
+}  // namespace lqr_speed_steer
+
+namespace lqr_steer {         // src/lqr_steer_control.cpp
+using lqr_speed_steer::calc_nearest_index;   // :55-73, the same text
+using lqr_speed_steer::update;               // :136-146, the same text
+inline float lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, int& ind, float& pe, float& pth_e) {   // :98
+  const Vec_f sp(cx.size(), 0.0f);           // the 4-state controller does not read the speed profile
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &sp);
+  const float s[4] = {state.x, state.y, state.yaw, state.v};
+  float delta = 0.0f;
+  crx::dropin_check(crx_lqr_steering_control_batch(1, 4, s, &c, &ind, &pe, &pth_e, nullptr, &delta), "lqr_steering_control");
+  return delta;
+}
+}  // namespace lqr_steer
+
+namespace mpc {               // src/model_predictive_control.cpp
+inline void update(State& state, float a, float delta) {                                                     // :69
+  crx_vehicle_params p;
+  crx_vehicle_default_params(&p, 1);
+  float s[4] = {state.x, state.y, state.yaw, state.v};
+  crx::dropin_check(crx_update_batch(1, s, &a, &delta, &p), "update");
+  state.x = s[0]; state.y = s[1]; state.yaw = s[2]; state.v = s[3];
+}
+// calc_ref_trajectory(state, cx, cy, cyaw, ck, sp, dl, target_ind, xref) :130 — xref is the reference's M_XREF.
+template <int T_>
+inline void calc_ref_trajectory(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f sp, float dl, int& target_ind,
+                                crx::Mat<4, T_>& xref) {
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &sp);
+  const float s[4] = {state.x, state.y, state.yaw, state.v};
+  crx::dropin_check(crx_calc_ref_trajectory_batch(1, T_, s, &c, dl, 0.2, 10, &target_ind, xref.data()), "calc_ref_trajectory");
+}
+}  // namespace mpc
 
 }  // namespace crx_dropin

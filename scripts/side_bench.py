@@ -16,7 +16,7 @@ import torch  # noqa: E402
 
 import cpprobotics_amd as crx  # noqa: E402
 import oracle  # noqa: E402
-from common import lqr_speeds, mpc_problem  # noqa: E402
+from common import lqr_course, lqr_speeds, mpc_course_f32, mpc_problem, tracking_agents  # noqa: E402
 
 
 def gpu_time(fn, reps):
@@ -100,6 +100,56 @@ def main():
             "cpu_baseline": {"value": ns / t_cpu, "unit": "solves/s", "cores": min(cores, ns // 8), "kind": "port",
                              "sample": f"first {ns} agents", "single_thread_value": single},
             "parity": {"max_rel_err_floored_vs_cpu_twin": err, "both_converged_frac": float(both.mean())}}))
+
+    # ---- course tracking: one control evaluation, and the closed LQR loop as one kernel ----
+    course, goal = lqr_course()
+    dc = crx.Course.from_numpy(course)
+    n = 16384
+    st = tracking_agents(n, tuple(c[:200] for c in course), 5, spread=0.4)
+    for dim in (5, 4):
+        std = torch.from_numpy(st).cuda()
+        pe, pth = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        t_ctl = gpu_time(lambda: crx.lqr_steering_control(std, dc, pe, pth, dim=dim), 3 if quick else 10)
+        max_ticks = 400
+        ticks, _ = crx.closed_loop_prediction(std.clone(), dc, goal, dim=dim, max_ticks=max_ticks)
+        tk = ticks.cpu().numpy().astype(np.int64)
+        t_loop = gpu_time(lambda: crx.closed_loop_prediction(std.clone(), dc, goal, dim=dim, max_ticks=max_ticks), 1 if quick else 3)
+        ns = 512
+        t1 = time.perf_counter()
+        so, tio, *_ = oracle.lqr_closed_loop(st[:ns], course, goal, dim=dim, max_ticks=max_ticks, agents=(0, 8))
+        single = float(tio[:8].sum()) / (time.perf_counter() - t1)
+        res = {}
+
+        def work(a0, a1):
+            res[a0] = oracle.lqr_closed_loop(st[:ns], course, goal, dim=dim, max_ticks=max_ticks, agents=(a0, a1))
+        t_cpu = cpu_parallel(work, ns, min(cores, ns // 4))
+        # parity of the sampled agents: final state + tick count
+        sd = std.clone(); tk2, _ = crx.closed_loop_prediction(sd, dc, goal, dim=dim, max_ticks=max_ticks)
+        same = True
+        for a0, r in res.items():
+            a1 = min(ns, a0 + (ns // min(cores, ns // 4)) + 1)
+        full = oracle.lqr_closed_loop(st[:64], course, goal, dim=dim, max_ticks=max_ticks)
+        same = bool(np.array_equal(sd.cpu().numpy()[:64], full[0]) and np.array_equal(tk2.cpu().numpy()[:64], full[1]))
+        print(json.dumps({
+            "workload": f"LQR tracking {dim}-state, {n} agents on the reference course ({len(course[0])} points): "
+                        f"lqr_steering_control + update + goal test per tick, whole episode in one kernel (max {max_ticks} ticks)",
+            "agent_ticks_per_s": float(tk.sum()) / t_loop, "episodes_per_s": n / t_loop, "ms_episode_batch": t_loop * 1e3,
+            "mean_ticks": float(tk.mean()), "reached_goal_frac": float((tk < max_ticks).mean()),
+            "control_evals_per_s_single_launch": n / t_ctl,
+            "cpu_baseline": {"value": float(tk[:ns].sum()) / t_cpu, "unit": "agent-ticks/s", "cores": min(cores, ns // 4), "kind": "port",
+                             "sample": f"first {ns} agents", "single_thread_value": single},
+            "parity": {"first_64_agents_bit_identical": same}}))
+    # ---- MPC closed loop (mpc_simulation): 3 kernels per tick ---------------------------------------------------------
+    mcourse, mgoal = mpc_course_f32()
+    mdc = crx.Course.from_numpy(mcourse)
+    n, T, max_ticks = 8192, 6, 50
+    mst = tracking_agents(n, tuple(c[:150] for c in mcourse), 9, spread=0.5)
+    mst[:, 3] = np.random.default_rng(10).uniform(0.5, 4.0, n).astype(np.float32)
+    tind0 = torch.from_numpy(oracle.calc_nearest_index(mst, mcourse)[0].astype(np.int32)).cuda()
+    mstd = torch.from_numpy(mst).cuda()
+    t_mpc = gpu_time(lambda: crx.mpc_simulation(mstd.clone(), mdc, mgoal, T, max_ticks, target_ind=tind0.clone()), 1 if quick else 2)
+    print(json.dumps({"workload": f"MPC closed loop (mpc_simulation), {n} agents, T={T}, {max_ticks} ticks: calc_ref_trajectory + mpc_solve + update per tick",
+                      "agent_ticks_per_s": n * max_ticks / t_mpc, "ms_per_tick": t_mpc / max_ticks * 1e3}))
 
 
 if __name__ == "__main__":

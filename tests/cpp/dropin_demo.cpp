@@ -56,5 +56,50 @@ int main() {
   for (int i = 0; i < 6; ++i) { xref(0, i) = 0.5f * (i + 1); xref(1, i) = 0.0f; xref(2, i) = 0.0f; xref(3, i) = 10.0f / 3.6f; }
   cpprobotics::Vec_f sol = mpc_solve<6>(s0, xref);
   dump("mpc", sol.data(), (int)sol.size());
+
+  // ---- tracking call sites: lqr_steering_control + update (src/lqr_speed_steer_control.cpp:195-197, src/lqr_steer_control.cpp:186-188)
+  //      and calc_ref_trajectory + update of the MPC loop (src/model_predictive_control.cpp:372-376), on a small arc course
+  cpprobotics::Vec_f cx, cy, cyaw, ck, sp;
+  for (int i = 0; i < 60; ++i) {
+    const float th = 0.02f * i;
+    cx.push_back(10.0f * std::sin(th)); cy.push_back(10.0f * (1.0f - std::cos(th))); cyaw.push_back(th);
+    ck.push_back(0.1f); sp.push_back(10.0f / 3.6f);
+  }
+  {
+    using namespace crx_dropin::lqr_speed_steer;
+    cpprobotics::State st(0.2f, -0.3f, 0.1f, 1.5f);
+    float e = 0.0f, e_th = 0.0f;
+    for (int t = 0; t < 3; ++t) {
+      cpprobotics::Vec_f control = lqr_steering_control(st, cx, cy, cyaw, ck, sp, e, e_th);
+      update(st, control[0], control[1]);
+      const float row[8] = {control[0], control[1], e, e_th, st.x, st.y, st.yaw, st.v};
+      dump("lqr5_tick", row, 8);
+    }
+  }
+  {
+    using namespace crx_dropin::lqr_steer;
+    cpprobotics::State st(0.2f, -0.3f, 0.1f, 1.5f);
+    float e = 0.0f, e_th = 0.0f;
+    int ind = 0;
+    for (int t = 0; t < 3; ++t) {
+      float di = lqr_steering_control(st, cx, cy, cyaw, ck, ind, e, e_th);
+      float ai = 1.0 * (sp[ind] - st.v);
+      update(st, ai, di);
+      const float row[8] = {ai, di, e, e_th, st.x, st.y, st.yaw, st.v};
+      dump("lqr4_tick", row, 8);
+    }
+  }
+  {
+    cpprobotics::State st(0.5f, 0.2f, 0.05f, 2.0f);
+    int target_ind = 0;
+    Mat<4, 6> xr;
+    crx_dropin::mpc::calc_ref_trajectory<6>(st, cx, cy, cyaw, ck, sp, 1.0f, target_ind, xr);
+    dump("xref", xr.data(), 24);
+    const float ti = (float)target_ind;
+    dump("target_ind", &ti, 1);
+    crx_dropin::mpc::update(st, 0.5f, 0.9f);
+    const float row[4] = {st.x, st.y, st.yaw, st.v};
+    dump("mpc_update", row, 4);
+  }
   return 0;
 }

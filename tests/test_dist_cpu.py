@@ -31,8 +31,15 @@ def _worker(rank, world, port, n, T, q):
     x, P, xh, _ = oracle.ekf_run(x0[lo:hi], P0[lo:hi], z, ud, Q, R)
     xg = swarm.gather_agents(torch.from_numpy(x), n)
     hg = swarm.gather_time_major(torch.from_numpy(xh), n)
+    # tracking swarm: each rank runs the closed LQR loop on its shard of the agents (shared course), results gathered
+    from common import lqr_course, tracking_agents
+    course, goal = lqr_course()
+    st = tracking_agents(n, tuple(c[:100] for c in course), 11, spread=0.3)
+    s1, ticks, *_ = oracle.lqr_closed_loop(st[lo:hi], course, goal, dim=5, max_ticks=300)
+    sg = swarm.gather_agents(torch.from_numpy(s1), n)
+    tg = swarm.gather_agents(torch.from_numpy(ticks), n)
     if rank == 0:
-        q.put((xg.numpy(), hg.numpy()))
+        q.put((xg.numpy(), hg.numpy(), sg.numpy(), tg.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,7 +64,7 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    xg, hg = q.get(timeout=240)
+    xg, hg, sg, tg = q.get(timeout=240)
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
@@ -67,6 +74,11 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
     x, P, xh, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
     assert np.array_equal(xg, x) and np.array_equal(hg, xh)
+    from common import lqr_course, tracking_agents
+    course, goal = lqr_course()
+    st = tracking_agents(n, tuple(c[:100] for c in course), 11, spread=0.3)
+    s1, ticks, *_ = oracle_mod.lqr_closed_loop(st, course, goal, dim=5, max_ticks=300)
+    assert np.array_equal(sg, s1) and np.array_equal(tg, ticks)
 
 
 def test_shard_range_partitions():

@@ -65,3 +65,28 @@ def test_dropin_matches_oracle(demo, oracle_mod):
     sol, st, cost = oracle_mod.mpc_solve(x0, xref.reshape(1, 24), 6)
     assert st[0] & 1
     assert np.max(np.abs(got["mpc"][0] - sol[0]) / np.maximum(np.abs(sol[0]), 1.0)) <= 1e-6
+    # tracking call sites replayed through the oracle
+    th = (f32(0.02) * np.arange(60, dtype=f32)).astype(f32)
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6"); libm.sinf.restype = ctypes.c_float; libm.cosf.restype = ctypes.c_float
+    libm.sinf.argtypes = libm.cosf.argtypes = [ctypes.c_float]
+    cx = np.array([f32(10.0) * f32(libm.sinf(t)) for t in th], f32)
+    cy = np.array([f32(10.0) * (f32(1.0) - f32(libm.cosf(t))) for t in th], f32)
+    course = (cx, cy, th, np.full(60, 0.1, f32), np.full(60, f32(10.0) / f32(3.6), f32))
+    for dim, tag in ((5, "lqr5_tick"), (4, "lqr4_tick")):
+        st = np.array([[0.2, -0.3, 0.1, 1.5]], f32)
+        pe, pth, ind = np.zeros(1, f32), np.zeros(1, f32), np.zeros(1, np.int32)
+        for t in range(3):
+            ctl, ind, pe, pth = oracle_mod.lqr_steering_control(st, course, pe, pth, dim=dim, ind=ind)
+            if dim == 5:
+                ai, di = ctl[0, 0], ctl[0, 1]
+            else:
+                ai, di = f32(1.0 * np.float64(course[4][ind[0]] - st[0, 3])), ctl[0]
+            st = oracle_mod.update(st, np.array([ai], f32), np.array([di], f32))
+            assert np.array_equal(got[tag][t], np.array([ai, di, pe[0], pth[0], *st[0]], f32)), (tag, t)
+    st = np.array([[0.5, 0.2, 0.05, 2.0]], f32)
+    xr, tind = oracle_mod.calc_ref_trajectory(st, course, np.zeros(1, np.int32), 6)
+    assert np.array_equal(got["xref"][0], xr[0]) and got["target_ind"][0][0] == tind[0]
+    st2 = oracle_mod.update(st, np.array([0.5], f32), np.array([0.9], f32), dt=0.2, wheelbase=2.5, clamp_speed=True)
+    assert np.array_equal(got["mpc_update"][0], st2[0])
+

@@ -42,3 +42,27 @@ def test_mpc_golden(crx):
     ok = ((st.cpu().numpy() & 1) == 1) & ((g["status"] & 1) == 1)
     assert ok.mean() > 0.95
     assert floored_rel_err(sol.cpu().numpy()[ok], g["sol"][ok], 1.0) <= 1e-6
+
+
+def test_track_golden(crx):
+    g = np.load(os.path.join(GOLD, "track_golden.npz"))
+    course = tuple(g["course"])
+    dc = crx.Course.from_numpy(course)
+    st = g["state"]
+    for dim in (5, 4):
+        pe, pth = _t(g["pe"]), _t(g["pth"])
+        ctl, ind = crx.lqr_steering_control(_t(st), dc, pe, pth, dim=dim)
+        assert bit_equal(ctl.cpu().numpy(), g[f"ctl{dim}"]) and np.array_equal(ind.cpu().numpy(), g[f"ind{dim}"])
+        assert bit_equal(pe.cpu().numpy(), g[f"pe{dim}"]) and bit_equal(pth.cpu().numpy(), g[f"pth{dim}"])
+        sd = _t(st)
+        ticks, _ = crx.closed_loop_prediction(sd, dc, tuple(g["goal"]), dim=dim, max_ticks=600)
+        assert np.array_equal(ticks.cpu().numpy(), g[f"loop_ticks{dim}"]) and bit_equal(sd.cpu().numpy(), g[f"loop_state{dim}"])
+    for mpc, key in ((False, "update_lqr"), (True, "update_mpc")):
+        sd = _t(st)
+        crx.update(sd, _t(g["a"]), _t(g["delta"]), crx.vehicle_params(mpc))
+        assert bit_equal(sd.cpu().numpy(), g[key])
+    mdc = crx.Course.from_numpy(tuple(g["mcourse"]))
+    td = _t(g["tind0"])
+    xr = crx.calc_ref_trajectory(_t(g["mstate"]), mdc, td, 21)
+    assert bit_equal(xr.cpu().numpy(), g["xref21"]) and np.array_equal(td.cpu().numpy(), g["tind"])
+

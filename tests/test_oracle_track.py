@@ -90,3 +90,18 @@ def test_mpc_closed_loop_tracks_the_course(oracle_mod):
     p = hist[:, 0, :2].astype(np.float64)
     d = np.sqrt(((p[:, None, 0] - course[0][None]) ** 2 + (p[:, None, 1] - course[1][None]) ** 2).min(axis=1))
     assert d.max() < 1.0
+
+
+def test_oracle_matches_committed_golden(oracle_mod):
+    """tests/golden/track_golden.npz pins the tracking oracle against silent drift."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "track_golden.npz"))
+    course, st = tuple(g["course"]), g["state"]
+    for dim in (5, 4):
+        ctl, ind, pe, pth = oracle_mod.lqr_steering_control(st, course, g["pe"], g["pth"], dim=dim)
+        assert np.array_equal(ctl, g[f"ctl{dim}"]) and np.array_equal(ind, g[f"ind{dim}"])
+        s1, ticks, *_ = oracle_mod.lqr_closed_loop(st, course, tuple(g["goal"]), dim=dim, max_ticks=600)
+        assert np.array_equal(s1, g[f"loop_state{dim}"]) and np.array_equal(ticks, g[f"loop_ticks{dim}"])
+    assert np.array_equal(oracle_mod.update(st, g["a"], g["delta"]), g["update_lqr"])
+    xr, tind = oracle_mod.calc_ref_trajectory(g["mstate"], tuple(g["mcourse"]), g["tind0"], 21)
+    assert np.array_equal(xr, g["xref21"]) and np.array_equal(tind, g["tind"])

@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -39,6 +40,17 @@ int check_device() {
 }
 
 inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// Threads per workgroup of the iterative kernels (DARE, MPC, tracking): full 64-lane waves.  Narrower waves
+// (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized
+// batches) were measured and are 1.0x-5x SLOWER: with single-wave workgroups the dispatcher stacks the extra waves
+// on a subset of the CUs instead of spreading them (scripts/gpu_lanes_sweep.sh; CRX_LANES overrides for experiments).
+inline unsigned narrow_block(size_t n, unsigned min_lanes = 4) {
+  (void)n; (void)min_lanes;
+  static const int forced = [] { const char* e = std::getenv("CRX_LANES"); return e ? std::atoi(e) : 0; }();
+  if (forced >= 1 && forced <= 64) return (unsigned)forced;
+  return 64;
+}
 
 crx::EkfConsts make_consts(const float* Q, const float* R, const crx_ekf_params* prm) {
   crx::EkfConsts k;
@@ -292,7 +304,8 @@ int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const flo
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const dim3 grid(blocks_for(n, 64)), block(64);
+  const unsigned bs = narrow_block(n);
+  const dim3 grid(blocks_for(n, bs)), block(bs);
   if (dim == 5)
     hipLaunchKernelGGL((crx::dare_dense_kernel<5>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
   else
@@ -309,7 +322,8 @@ int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_para
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
-  const dim3 grid(blocks_for(n, 64)), block(64);
+  const unsigned bs = narrow_block(n);
+  const dim3 grid(blocks_for(n, bs)), block(bs);
   if (dim == 5)
     hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
   else
@@ -369,7 +383,7 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream) == hipSuccess
+  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, narrow_block(n)) == hipSuccess
              ? CRX_OK
              : hip_fail(hipGetLastError(), "mpc launch");
 }
@@ -466,7 +480,8 @@ int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
-  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const unsigned bs = narrow_block(n, 8);
+  const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
 #define CRX_LAUNCH_CTL(DIM, LDS) \
@@ -498,7 +513,8 @@ int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
   const crx::VehicleParams vp = vparams(veh, 0);
-  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const unsigned bs = narrow_block(n, 8);
+  const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
 #define CRX_LAUNCH_LOOP(DIM, LDS) \
@@ -566,7 +582,7 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   for (int t = 0; t < loop->max_ticks; ++t) {
     hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, grid, block, 0, s, n, T, state, cv, dl, p.dt, nsearch, target_ind, xref,
                        (const int*)active);
-    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
+    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, narrow_block(n)) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
     hipLaunchKernelGGL(crx::mpc_tick_tail_kernel, grid, block, 0, s, n, T, t, state, sol, vp, loop->goal_x, loop->goal_y,
                        loop->goal_dis, active, ticks_done, traj_hist);
   }

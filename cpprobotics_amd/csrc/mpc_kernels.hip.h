@@ -397,13 +397,13 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 }
 
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                             int* status, double* cost, hipStream_t stream) {
+                             int* status, double* cost, hipStream_t stream, unsigned lanes = 64) {
   MpcP p;
   p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
   p.max_speed = q.max_speed; p.min_speed = q.min_speed;
   p.r_a = q.r_a; p.r_d = q.r_delta; p.rd_a = q.rd_a; p.rd_d = q.rd_delta;
   p.qx = q.q_x; p.qy = q.q_y; p.qyaw = q.q_yaw; p.qv = q.q_v; p.tol = q.tol; p.max_iter = q.max_iter;
-  const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+  const dim3 grid((unsigned)((n + lanes - 1) / lanes)), block(lanes);
   if (T <= 8)
     hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
   else if (T <= 24)

@@ -34,6 +34,41 @@
 
 namespace crx {
 
+// sin, cos (and tan = sin/cos) in fp64 for the solver.  OCML's sincos()/tan() carry a full Payne-Hanek reduction and
+// cost ~150 instructions each; the solver calls them once per stage per rollout.  For |x| < 2^17 a three-term
+// Cody-Waite reduction (fma) and the fdlibm kernel polynomials give <= 1 ulp in ~45 instructions; larger arguments
+// (never produced by a sane course) fall back to OCML.  MPC parity is tolerance-based (1e-6 vs the CPU twin, which
+// uses the host libm), so last-ulp differences are immaterial.
+__device__ __forceinline__ void mpc_sincos(double x, double* sp, double* cp) {
+  if (!(fabs(x) < 131072.0)) { sincos(x, sp, cp); return; }
+  const double two_over_pi = 6.36619772367581382433e-01;
+  const double pio2_hi = 1.57079632679489655800e+00, pio2_mid = 6.12323399573676603587e-17, pio2_lo = -1.49738490485916983693e-33;
+  const double fn = rint(x * two_over_pi);
+  double r = fma(-fn, pio2_hi, x);
+  r = fma(-fn, pio2_mid, r);
+  r = fma(-fn, pio2_lo, r);
+  const int q = (int)fn;
+  const double z = r * r;
+  // __kernel_sin / __kernel_cos (fdlibm k_sin.c, k_cos.c), without their extra-precision tails
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                              2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                              -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const double s0 = (q & 1) ? cr : sr;
+  const double c0 = (q & 1) ? sr : cr;
+  *sp = (q & 2) ? -s0 : s0;
+  *cp = ((q + 1) & 2) ? -c0 : c0;
+}
+__device__ __forceinline__ double mpc_tan(double x) {
+  double sn, cs;
+  mpc_sincos(x, &sn, &cs);
+  return sn / cs;
+}
+
 struct MpcP {
   double dt, wb, max_steer, max_accel, max_speed, min_speed;
   double r_a, r_d, rd_a, rd_d, qx, qy, qyaw, qv, tol;
@@ -93,6 +128,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
   double U[2][MAXT][2];   // stages: delta, a
   double kf[MAXT][2];     // feed-forward
   double Kf[MAXT][12];    // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev)
+  double TR[2][MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them
 
   const double dt = p.dt, wb = p.wb;
   const double lb0 = -p.max_steer, ub0 = p.max_steer, lb1 = -p.max_accel, ub1 = p.max_accel;
@@ -113,12 +149,14 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     }
     return v;
   };
-  auto step = [&](const double* s, double d, double a, double* sn) {
+  auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
     double sn_, cs_;
-    sincos(s[2], &sn_, &cs_);
+    mpc_sincos(s[2], &sn_, &cs_);
+    const double tn_ = mpc_tan(d);
+    tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
     sn[0] = s[0] + s[3] * cs_ * dt;
     sn[1] = s[1] + s[3] * sn_ * dt;
-    sn[2] = s[2] + s[3] * tan(d) / wb * dt;
+    sn[2] = s[2] + s[3] * tn_ / wb * dt;
     sn[3] = s[3] + a * dt;
   };
 
@@ -135,7 +173,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     U[0][i][0] = 0.0; U[0][i][1] = 0.0;
     J += ctrl(0, i);
     if (i >= 1) J += track(S[0][i], i);
-    step(S[0][i], 0.0, 0.0, S[0][i + 1]);
+    step(S[0][i], 0.0, 0.0, S[0][i + 1], TR[0][i]);
   }
   J += track(S[0][N], N);
 
@@ -177,10 +215,9 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       const double ud = U[cur][i][0], ua = U[cur][i][1];
       const bool inner = i >= 1;
       const double pd = inner ? U[cur][i - 1][0] : 0.0, pa = inner ? U[cur][i - 1][1] : 0.0;
-      double sn_, cs_;
-      sincos(s[2], &sn_, &cs_);
+      const double sn_ = TR[cur][i][0], cs_ = TR[cur][i][1];
       const double v = s[3];
-      const double tn = tan(ud), sec2 = 1.0 + tn * tn;
+      const double tn = TR[cur][i][2], sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn / wb * dt;
       const double bd = v * sec2 / wb * dt;
       // stage cost derivatives
@@ -356,7 +393,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
         U[nxt][i][0] = nd; U[nxt][i][1] = na;
         Jn += ctrl(nxt, i);
         if (i >= 1) Jn += track(sn, i);
-        step(sn, nd, na, S[nxt][i + 1]);
+        step(sn, nd, na, S[nxt][i + 1], TR[nxt][i]);
       }
       Jn += track(S[nxt][N], N);
       if (Jn < J || (trust && Jn <= J + noise)) { J = Jn; accepted = true; break; }

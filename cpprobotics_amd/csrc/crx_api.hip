@@ -179,7 +179,10 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
 #ifndef CRX_EKF_BUFFER_ADDRESSING
 #define CRX_EKF_BUFFER_ADDRESSING 1
 #endif
-  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN;   // 32-bit buffer offsets (ekf_kernels.hip.h)
+  // 32-bit buffer offsets (ekf_kernels.hip.h); CRX_EKF_BUFFER=0 forces the 64-bit-address kernels that large
+  // batches get (tests exercise both with small inputs)
+  const char* env_buf = std::getenv("CRX_EKF_BUFFER");
+  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !(env_buf && env_buf[0] == '0');
 #define CRX_LAUNCH_RUN(XH, PH)                                                                          \
   do {                                                                                                  \
     if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \

@@ -227,3 +227,21 @@ def test_ekf_fused_nonfinite_state(crx, oracle_mod):
     ok = np.ones(n, dtype=bool); ok[[1, 65]] = False
     assert bit_equal(xh[:, ok], xho[:, ok]) and bit_equal(P[ok], Po[ok])
     assert np.isnan(xh[:, ~ok, :3]).all() and np.isnan(xho[:, ~ok, :3]).all()
+
+
+def test_ekf_fused_64bit_address_kernels(crx, oracle_mod, monkeypatch):
+    """Batches above 4 M vehicles use the fused kernel's 64-bit-address instantiations; forced here on a small input."""
+    import torch
+    monkeypatch.setenv("CRX_EKF_BUFFER", "0")
+    Q, R = ekf_QR()
+    n, T = 333, 41
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, n, T, seed=91)
+    x0[5, 2] = np.float32(300.0)               # one vehicle through the general-step redo as well
+    z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
+    xo, Po, xho, pho = oracle_mod.ekf_run(x0, P0, z, ud, Q, R, want_phist=True)
+    xd, Pd = _t(x0), _t(P0)
+    xh = torch.empty((T, n, 4), dtype=torch.float32, device="cuda")
+    ph = torch.empty((T, n, 16), dtype=torch.float32, device="cuda")
+    crx.ekf_run(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh, P_hist=ph)
+    assert bit_equal(xh.cpu().numpy(), xho) and bit_equal(ph.cpu().numpy(), pho)
+    assert bit_equal(xd.cpu().numpy(), xo) and bit_equal(Pd.cpu().numpy(), Po)

@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: a mixed EKF + MPC swarm sharded over the GPUs of one node.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/swarm_bench.py
+  python scripts/swarm_bench.py --agents 131072          # one GPU, one shard of the 1,048,576-agent swarm
+
+Every rank owns a contiguous shard of the agents (no data-path collective: agents are independent).  Per round:
+  1. all vehicles of the shard run T fused EKF steps (crx_ekf_run_batch_dev), estimated trajectory [T][n][4] out;
+  2. one agent in eight also plans: calc_ref_trajectory on the shared course from its estimated state, then
+     mpc_solve over N = 20 control intervals (T = 21 knots);
+  3. the estimated trajectories are concatenated over the ranks with ONE RCCL all-gather (xGMI) — the exchange step
+     north_star names.  `--gather final` gathers the final estimates only (16 B/agent instead of 16*T).
+Prints one JSON line on rank 0: EKF updates/s, MPC solves/s, end-to-end rounds/s, bytes gathered."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--agents", type=int, default=131072, help="agents per GPU (1,048,576 / 8)")
+    ap.add_argument("--T", type=int, default=100, help="EKF steps per round")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import cpprobotics_amd as crx
+    from cpprobotics_amd import swarm
+    from common import ekf_QR, mpc_course_f32
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n, T = args.agents, args.T
+    n_total, n_mpc, Tm = n * world, n // 8, 21
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    dc = crx.Course.from_numpy(course, device=dev)
+    g = torch.Generator(device=dev); g.manual_seed(99 + rank)       # agent parameters keyed by (rank-)global position
+    ci = torch.randint(0, len(course[0]) - 30, (n,), generator=g, device=dev)
+    cx, cy, cyaw = (torch.from_numpy(a).to(dev) for a in course[:3])
+    x0 = torch.stack([cx[ci], cy[ci], cyaw[ci], torch.full((n,), 2.5, device=dev)], dim=1).contiguous()
+    u_true = torch.stack([torch.full((n,), 0.0, device=dev), torch.zeros(n, device=dev)], dim=1).contiguous()  # (accel, yaw rate)
+    w = torch.randn((T, n, 4), generator=g, device=dev)
+    z, ud = crx.ekf_simulate_inputs(u_true, x0.clone(), x0.clone(), w)
+    del w
+    P0 = torch.eye(4, device=dev).reshape(1, 16).repeat(n, 1).contiguous()
+    x, P = x0.clone(), P0.clone()
+    x_hist = torch.empty((T, n, 4), device=dev)
+    tind = torch.zeros(n_mpc, dtype=torch.int32, device=dev)
+
+    def one_round():
+        x.copy_(x0); P.copy_(P0)
+        crx.ekf_run(x, P, z, ud, Q, R, x_hist=x_hist)
+        st = x[::8].contiguous()                                      # every eighth agent plans from its estimate
+        crx.calc_nearest_index(st, dc, tind)
+        xref = crx.calc_ref_trajectory(st, dc, tind, Tm)
+        sol = crx.mpc_solve(st, xref, Tm)
+        out = None
+        if world > 1 and args.gather != "none":
+            out = swarm.gather_time_major(x_hist, n_total) if args.gather == "traj" else swarm.gather_agents(x, n_total)
+        return sol, out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(3):
+        one_round()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.rounds):
+        one_round()
+    sync()
+    dt = (time.perf_counter() - t0) / args.rounds
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    if rank == 0:
+        gb = {"traj": 16.0 * T * n_total, "final": 16.0 * n_total, "none": 0.0}[args.gather] if world > 1 else 0.0
+        print(json.dumps({"workload": f"mixed swarm: {n_total} agents over {world} GPU(s), {T} EKF steps + 1/8 of the agents one MPC solve (T=21) per round",
+                          "round_ms": dt * 1e3, "ekf_updates_per_s": n_total * T / dt, "mpc_solves_per_s": n_mpc * world / dt,
+                          "gather": args.gather if world > 1 else "n/a", "gathered_bytes_per_rank_per_round": gb}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,10 @@ class LoopParams(C.Structure):
                 ("stop_speed", C.c_float), ("max_ticks", C.c_int)]
 
 
+class PfParams(C.Structure):
+    _fields_ = [("rsim0", C.c_float), ("rsim1", C.c_float), ("Q", C.c_float), ("dt", C.c_double), ("nth", C.c_float)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -85,6 +89,8 @@ _SIGNATURES = {
     "crx_calc_nearest_index_window_batch_dev": (_I, [_I, _P, _CP, _P, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch_dev": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P, _P]),
+    "crx_pf_default_params": (None, [C.POINTER(PfParams)]),
+    "crx_pf_run_batch_dev": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(PfParams), _P, _P, _P]),
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),
     "crx_mpc_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
                                            _P, _P]),

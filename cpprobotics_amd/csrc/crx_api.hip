@@ -12,6 +12,7 @@
 #include "ekf_kernels.hip.h"
 #include "mpc_kernels.hip.h"
 #include "track_kernels.hip.h"
+#include "pf_kernels.hip.h"
 
 namespace {
 
@@ -693,3 +694,40 @@ int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// particle filter
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+void crx_pf_default_params(crx_pf_params* p) {
+  if (!p) return;
+  p->rsim0 = 1.0 * 1.0;
+  p->rsim1 = (float)(30.0 / 180.0 * 3.141592653 * 30.0 / 180.0 * 3.141592653);
+  p->Q = 0.01f;
+  p->dt = 0.1;
+  p->nth = 0.0f;
+}
+
+int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs,
+                         const int* nobs, const float* u, const float* nrm, const float* uni, const crx_pf_params* prm,
+                         float* x_hist, int* n_resampled, void* stream) {
+  if (n < 0 || T < 0 || L < 0 || (np != 100 && np != 64 && np != 128) ||
+      (n && (!px || !pw || !xEst || !PEst)) || (n && T && (!nobs || !u || !nrm || !uni || (L && !obs))))
+    return fail(CRX_ERR_INVALID, "pf_run: bad argument (np must be 64, 100 or 128)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_pf_params q;
+  if (prm) q = *prm; else crx_pf_default_params(&q);
+  const crx::PfParams p{q.rsim0, q.rsim1, q.Q, q.dt, q.nth > 0.0f ? q.nth : (float)(np / 2)};
+  const dim3 grid(blocks_for(n, crx::kPfWavesPerBlock)), block(64 * crx::kPfWavesPerBlock);
+  hipStream_t s = (hipStream_t)stream;
+  if (np == 100) hipLaunchKernelGGL((crx::pf_run_kernel<100>), grid, block, 0, s, n, T, L, px, pw, xEst, PEst, obs, nobs, u, nrm, uni, p, x_hist, n_resampled);
+  else if (np == 64) hipLaunchKernelGGL((crx::pf_run_kernel<64>), grid, block, 0, s, n, T, L, px, pw, xEst, PEst, obs, nobs, u, nrm, uni, p, x_hist, n_resampled);
+  else hipLaunchKernelGGL((crx::pf_run_kernel<128>), grid, block, 0, s, n, T, L, px, pw, xEst, PEst, obs, nobs, u, nrm, uni, p, x_hist, n_resampled);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+}  // extern "C"
+

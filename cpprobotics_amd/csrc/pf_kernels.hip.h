@@ -1,0 +1,181 @@
+// pf_kernels.hip.h — batched particle-filter localisation for gfx950: ONE VEHICLE PER WAVEFRONT, its NP particles
+// spread over the 64 lanes (NP = 100 -> 36 lanes carry two), wave-wide reductions for the weight sum, the weighted
+// mean and covariance, a wave scan + LDS binary search for the low-variance resampling.  All T ticks of a launch are
+// fused: the particle set lives in registers (LDS only while resampling), inputs stream in, xEst streams out.
+//
+// Replaces, for n independent vehicles, /root/reference/src/particle_filter.cpp:
+//   motion_model :25-39, gauss_likelihood :50-54, calc_covariance :56-68, pf_localization :70-108,
+//   cumsum :110-117, resampling :119-150.
+// Random numbers are inputs (the reference draws them from std::mt19937 inside these functions): nrm [T][n][NP][2]
+// standard normals for the motion noise (:86-87), uni [T][n][NP] uniforms in [1,2) for the resampling (:134, uni_d{1,2}).
+//
+// Parity is statistical / tolerance-based by construction: per-particle arithmetic follows the
+// reference statement by statement (double promotions included, cosf/sinf glibc-exact), but expf is OCML's and the
+// reductions are wave butterflies instead of Eigen's vectorised redux / gemv order, so sums differ in the last bits and
+// a resampling threshold can flip on a tie.
+//
+// Layout: px [n][NP][4] (Eigen::Matrix<float,4,NP> column-major = one float4 per particle), pw [n][NP], xEst [n][4],
+// PEst [n][16] column-major, obs [T][n][L][3] = (range, landmark x, landmark y), nobs [T][n], u [T][n][2].
+#pragma once
+#include <hip/hip_runtime.h>
+#include "crx_trig.h"
+
+namespace crx {
+
+struct PfParams {
+  float rsim0, rsim1;   // Rsim(0,0), Rsim(1,1)
+  float Q;              // observation variance (gauss_likelihood's sigma = sqrt(Q))
+  double dt;
+  float nth;            // resampling threshold NTh = NP/2
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+// inclusive scan over the 64 lanes (lane order)
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_scan_max(int v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d, 64);
+    if (lane >= d) v = v > t ? v : t;
+  }
+  return v;
+}
+
+constexpr int kPfWavesPerBlock = 4;
+
+template <int NP>
+__global__ void __launch_bounds__(64 * kPfWavesPerBlock)
+pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ pw, float* __restrict__ xEst,
+              float* __restrict__ PEst, const float* __restrict__ obs, const int* __restrict__ nobs,
+              const float* __restrict__ u, const float* __restrict__ nrm, const float* __restrict__ uni, PfParams p,
+              float* __restrict__ x_hist, int* __restrict__ n_resampled) {
+  static_assert(NP >= 1 && NP <= 128, "one or two particles per lane");
+  __shared__ float4 s_x[kPfWavesPerBlock][NP];
+  __shared__ float s_wc[kPfWavesPerBlock][NP];
+  __shared__ float s_base[NP];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t a = (size_t)blockIdx.x * kPfWavesPerBlock + wv;
+  const float inv = (float)(1.0 / NP);
+  if (threadIdx.x == 0) {            // base = cumsum(pw*0.0 + Ones*1.0/NP) - Ones*1.0/NP  (:129), input-independent
+    float c = inv;
+    s_base[0] = c - inv;
+    for (int i = 1; i < NP; ++i) { c = c + inv; s_base[i] = c - inv; }
+  }
+  __syncthreads();
+  if (a >= (size_t)n) return;        // whole waves only: no barrier below this point
+  const int p0 = lane, p1 = lane + 64;
+  const bool v1 = p1 < NP, v0 = p0 < NP;
+  float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
+  float w0 = 0.0f, w1 = 0.0f;
+  const float4* pxa = reinterpret_cast<const float4*>(px) + a * NP;
+  if (v0) { x0 = pxa[p0]; w0 = pw[a * NP + p0]; }
+  if (v1) { x1 = pxa[p1]; w1 = pw[a * NP + p1]; }
+  const float sig = sqrtf(p.Q);                                              // std::sqrt(Q) :99
+  const double lik_c = 1.0 / sqrt(2.0 * 3.141592653 * (double)sig * (double)sig);   // 1.0 / std::sqrt(2.0*PI*sigma*sigma) :51
+  const float lik_d = 2 * sig * sig;                                          // (2 * sigma * sigma), float
+  float4 xe = make_float4(0, 0, 0, 0);
+  float Pe[10];
+  int nres = 0;
+
+  auto advance = [&](float4& x, float& w, const float2 nz, const float u0, const float u1, const float* Z, int nob) {
+    const float ud0 = (float)((double)u0 + (double)nz.x * (double)p.rsim0);   // :86-87
+    const float ud1 = (float)((double)u1 + (double)nz.y * (double)p.rsim1);
+    float sn, cs;
+    sincosf_(x.z, &sn, &cs);                                                  // motion_model :25-39
+    const float b0 = (float)(p.dt * (double)cs), b1 = (float)(p.dt * (double)sn), b2 = (float)p.dt;
+    x = make_float4(x.x + b0 * ud0, x.y + b1 * ud0, x.z + b2 * ud1, x.w + ud0);
+    for (int i = 0; i < nob; ++i) {                                           // :91-99
+      const float dx = x.x - Z[3 * i + 1], dy = x.y - Z[3 * i + 2];
+      const float prez = sqrtf(dx * dx + dy * dy);
+      const float dz = prez - Z[3 * i];
+      const float pl = (float)(lik_c * (double)expf(-dz * dz / lik_d));        // gauss_likelihood :50-54
+      w = w * pl;
+    }
+  };
+
+  for (int t = 0; t < T; ++t) {
+    const size_t o = (size_t)t * n + a;
+    const float u0 = u[2 * o], u1 = u[2 * o + 1];
+    const int nob = nobs[o];
+    const float* Z = obs + o * (size_t)L * 3;
+    const float2* nz = reinterpret_cast<const float2*>(nrm) + o * NP;
+    if (v0) advance(x0, w0, nz[p0], u0, u1, Z, nob);
+    if (v1) advance(x1, w1, nz[p1], u0, u1, Z, nob);
+    // pw = pw / pw.sum()  :103
+    const float s = wave_sum(w0 + w1);
+    w0 = w0 / s; w1 = w1 / s;
+    // xEst = px * pw  :105
+    xe.x = wave_sum(x0.x * w0 + x1.x * w1);
+    xe.y = wave_sum(x0.y * w0 + x1.y * w1);
+    xe.z = wave_sum(x0.z * w0 + x1.z * w1);
+    xe.w = wave_sum(x0.w * w0 + x1.w * w1);
+    // calc_covariance :56-68 (symmetric: 10 sums)
+    {
+      const float d0[4] = {x0.x - xe.x, x0.y - xe.y, x0.z - xe.z, x0.w - xe.w};
+      const float d1[4] = {x1.x - xe.x, x1.y - xe.y, x1.z - xe.z, x1.w - xe.w};
+      int k = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r <= c; ++r) Pe[k++] = wave_sum((w0 * d0[r]) * d0[c] + (v1 ? (w1 * d1[r]) * d1[c] : 0.0f));
+    }
+    if (x_hist && lane == 0) reinterpret_cast<float4*>(x_hist)[o] = xe;
+    // resampling :119-150
+    const float ww = wave_sum(w0 * w0 + w1 * w1);
+    const float Neff = (float)(1.0 / (double)ww);
+    if (Neff < p.nth) {                                   // wave-uniform
+      ++nres;
+      float c0 = wave_scan_add(w0, lane);                 // cumsum :110-117 (particles 0..63, then 64..NP-1)
+      const float tot0 = __shfl(c0, 63, 64);
+      float c1 = wave_scan_add(w1, lane) + tot0;
+      if (v0) { s_wc[wv][p0] = c0; s_x[wv][p0] = x0; }
+      if (v1) { s_wc[wv][p1] = c1; s_x[wv][p1] = x1; }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): LDS writes of this wave visible to its own reads
+      const float* un = uni + o * NP;
+      auto pick = [&](int pidx) -> int {                  // smallest ind with !(resampleid > wcum[ind]), capped at NP-1 (:140-142)
+        const float rid = (float)((double)s_base[pidx] + (double)un[pidx] / NP);   // :134
+        int lo = 0, hi = NP - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rid > s_wc[wv][mid]) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+      };
+      int i0 = v0 ? pick(p0) : 0, i1 = v1 ? pick(p1) : 0;
+      // `ind` never moves back in the reference's loop: running maximum in particle order
+      i0 = wave_scan_max(i0, lane);
+      const int m0 = __shfl(i0, 63, 64);
+      i1 = wave_scan_max(i1, lane);
+      i1 = i1 > m0 ? i1 : m0;
+      if (v0) x0 = s_x[wv][i0];
+      if (v1) x1 = s_x[wv][i1];
+      w0 = v0 ? inv : 0.0f; w1 = v1 ? inv : 0.0f;         // pw = Ones * 1.0/NP  :148
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  float4* pxo = reinterpret_cast<float4*>(px) + a * NP;
+  if (v0) { pxo[p0] = x0; pw[a * NP + p0] = w0; }
+  if (v1) { pxo[p1] = x1; pw[a * NP + p1] = w1; }
+  if (lane == 0) {
+    reinterpret_cast<float4*>(xEst)[a] = xe;
+    float* Pa = PEst + a * 16;
+    int k = 0;
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r <= c; ++r) { Pa[r + 4 * c] = Pe[k]; Pa[c + 4 * r] = Pe[k]; ++k; }
+    if (n_resampled) n_resampled[a] += nres;
+  }
+}
+
+}  // namespace crx

@@ -241,6 +241,27 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
                                   int* ticks_done, void* work, void* stream);
 
+
+/* ---- particle-filter localisation (src/particle_filter.cpp) ---------------------------------
+ * pf_localization (:70-108) + resampling (:119-150) for n vehicles, T fused ticks, NP particles each (NP <= 128; the
+ * reference's `#define NP 100`).  One vehicle per wavefront.  The random numbers the reference draws from std::mt19937
+ * inside these functions are inputs here.  Device pointers:
+ *   px [n][NP][4] in/out (Eigen::Matrix<float,4,NP> column-major), pw [n][NP] in/out, xEst [n][4] out, PEst [n][16] out,
+ *   obs [T][n][L][3] = (noisy range, landmark x, landmark y) with nobs [T][n] <= L valid rows (:252-261),
+ *   u [T][n][2], nrm [T][n][NP][2] standard normals (:86-87), uni [T][n][NP] uniforms in [1,2) (:134, uni_d{1.0,2.0}),
+ *   x_hist [T][n][4] (may be NULL), n_resampled [n] (may be NULL; incremented by the number of resampling ticks).
+ * Parity with the reference is statistical / tolerance-based: see pf_kernels.hip.h. */
+typedef struct crx_pf_params {
+  float rsim0, rsim1;   /* Rsim(0,0) = 1.0, Rsim(1,1) = (30 deg)^2 with PI 3.141592653   :229-230 */
+  float Q;              /* 0.01   :219 */
+  double dt;            /* DT 0.1 :18  */
+  float nth;            /* NTh = NP/2  :22 ; <= 0 selects NP/2 */
+} crx_pf_params;
+void crx_pf_default_params(crx_pf_params* p);
+int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs,
+                         const int* nobs, const float* u, const float* nrm, const float* uni, const crx_pf_params* prm,
+                         float* x_hist, int* n_resampled, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

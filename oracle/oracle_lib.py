@@ -17,7 +17,7 @@ _F = C.c_float
 
 def build(force=False):
     """g++ -O2 -ffp-contract=off (oracle/Makefile).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "eigen_order.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "eigen_order.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -294,3 +294,58 @@ def mpc_closed_loop(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, 
                                         _p(sp), _F(dl), _I(nsearch), _p(pp), _I(max_iter), _F(goal[0]), _F(goal[1]),
                                         _F(goal_dis), _p(tind), _p(hist), _p(ticks), _I(a0), _I(a1))
     return state, ticks, hist, tind
+
+
+# ---- particle filter (oracle/pf_ref.cpp) ---------------------------------------------------------------
+PF_RSIM = (1.0 * 1.0, 30.0 / 180.0 * 3.141592653 * 30.0 / 180.0 * 3.141592653)   # Rsim(0,0), Rsim(1,1)  :229-230
+PF_RFID = np.array([[10.0, 0.0], [10.0, 10.0], [0.0, 15.0], [-5.0, 20.0]], dtype=np.float32)   # :195-198
+
+
+def _pf_lib():
+    l = lib()
+    l.oracle_pf_set_trig_mode(_I(trig_mode()))
+    return l
+
+
+def pf_simulate_inputs(u_true, xTrue, xDR, w_u, w_z, rfid=PF_RFID, rsim=PF_RSIM, Qsim=0.04, max_range=20.0, dt=0.1):
+    """main() :247-263 for n vehicles: returns ud [T,n,2], obs [T,n,L,3], nobs [T,n], xTrue_hist, xDR_hist."""
+    u_true, xTrue, xDR, w_u, w_z, rfid = _f32(u_true), _f32(xTrue).copy(), _f32(xDR).copy(), _f32(w_u), _f32(w_z), _f32(rfid)
+    T, n, L = w_u.shape[0], w_u.shape[1], rfid.shape[0]
+    ud = np.zeros((T, n, 2), np.float32); obs = np.zeros((T, n, L, 3), np.float32); nobs = np.zeros((T, n), np.int32)
+    xth = np.zeros((T, n, 4), np.float32); xdh = np.zeros((T, n, 4), np.float32)
+    rs = _f32(rsim)
+    _pf_lib().oracle_pf_simulate_inputs(_I(n), _I(T), _I(L), _p(u_true), _p(xTrue), _p(xDR), _p(rfid), _p(w_u), _p(w_z), _p(rs),
+                                        _F(Qsim), _F(max_range), _D(dt), _p(ud), _p(obs), _p(nobs), _p(xth), _p(xdh))
+    return ud, obs, nobs, xth, xdh
+
+
+def pf_step(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None):
+    """pf_localization + resampling, one tick.  px [n,NP,4], pw [n,NP], obs [n,L,3], nobs [n], u [n,2], nrm [n,NP,2], uni [n,NP].
+    Returns (px, pw, xEst [n,4], PEst [n,16], resampled [n], ancestors [n,NP])."""
+    px, pw = _f32(px).copy(), _f32(pw).copy()
+    obs, u, nrm, uni = _f32(obs), _f32(u), _f32(nrm), _f32(uni)
+    nobs = np.ascontiguousarray(nobs, dtype=np.int32)
+    n, NP, L = px.shape[0], px.shape[1], obs.shape[1]
+    xEst = np.zeros((n, 4), np.float32); PEst = np.zeros((n, 16), np.float32)
+    res = np.zeros(n, np.int32); anc = np.zeros((n, NP), np.int32)
+    rs = _f32(rsim)
+    a0, a1 = (0, n) if agents is None else agents
+    _pf_lib().oracle_pf_step(_I(n), _I(NP), _I(L), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm), _p(uni),
+                             _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(res), _p(anc), _I(a0), _I(a1))
+    return px, pw, xEst, PEst, res, anc
+
+
+def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None):
+    """T ticks.  obs [T,n,L,3], nobs [T,n], u [T,n,2], nrm [T,n,NP,2], uni [T,n,NP].
+    Returns (px, pw, xEst, PEst, x_hist [T,n,4], n_resampled [n])."""
+    px, pw = _f32(px).copy(), _f32(pw).copy()
+    obs, u, nrm, uni = _f32(obs), _f32(u), _f32(nrm), _f32(uni)
+    nobs = np.ascontiguousarray(nobs, dtype=np.int32)
+    T, n, NP, L = u.shape[0], px.shape[0], px.shape[1], obs.shape[2]
+    xEst = np.zeros((n, 4), np.float32); PEst = np.zeros((n, 16), np.float32)
+    xh = np.zeros((T, n, 4), np.float32); nres = np.zeros(n, np.int32)
+    rs = _f32(rsim)
+    a0, a1 = (0, n) if agents is None else agents
+    _pf_lib().oracle_pf_run(_I(n), _I(NP), _I(L), _I(T), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm),
+                            _p(uni), _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(xh), _p(nres), _I(a0), _I(a1))
+    return px, pw, xEst, PEst, xh, nres

@@ -151,6 +151,43 @@ def main():
     print(json.dumps({"workload": f"MPC closed loop (mpc_simulation), {n} agents, T={T}, {max_ticks} ticks: calc_ref_trajectory + mpc_solve + update per tick",
                       "agent_ticks_per_s": n * max_ticks / t_mpc, "ms_per_tick": t_mpc / max_ticks * 1e3}))
 
+    # ---- particle filter: one vehicle per wavefront, T fused ticks ---------------------------------
+    n, T, NP = 16384, 100, 100
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    u1 = np.tile(np.array([[1.0, 0.1]], np.float32), (n, 1))
+    rng = np.random.default_rng(8)
+    w_u = rng.standard_normal((T, n, 2)).astype(np.float32); w_z = rng.standard_normal((T, n, 4)).astype(np.float32)
+    ud, obs, nobs, xth, xdh = oracle.pf_simulate_inputs(u1, np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), w_u, w_z)
+    ut = np.tile(u1[None], (T, 1, 1))
+    nrm = torch.randn((T, n, NP, 2), generator=g, device="cuda")
+    uni = torch.rand((T, n, NP), generator=g, device="cuda") + 1.0
+    obs_d, nobs_d, ut_d = torch.from_numpy(obs).cuda(), torch.from_numpy(nobs).cuda(), torch.from_numpy(ut).cuda()
+    px0 = torch.zeros((n, NP, 4), device="cuda"); pw0 = torch.full((n, NP), 1.0 / NP, device="cuda")
+    xe, Pe, hist, nres = crx.pf_run(px0.clone(), pw0.clone(), obs_d, nobs_d, ut_d, nrm, uni)
+    t_pf = gpu_time(lambda: crx.pf_run(px0.clone(), pw0.clone(), obs_d, nobs_d, ut_d, nrm, uni), 2 if quick else 5)
+    h = hist.cpu().numpy()
+    err = float(np.hypot(h[..., 0] - xth[..., 0], h[..., 1] - xth[..., 1]).mean())
+    ns = 256
+    nrm_h, uni_h = nrm[:, :ns].cpu().numpy(), uni[:, :ns].cpu().numpy()
+    t1 = time.perf_counter()
+    ro = oracle.pf_run(np.zeros((ns, NP, 4), np.float32), np.full((ns, NP), 1.0 / NP, np.float32), obs[:, :ns], nobs[:, :ns], ut[:, :ns],
+                       nrm_h, uni_h, agents=(0, 8))
+    single = 8 * T / (time.perf_counter() - t1)
+    res = {}
+
+    def work(a0, a1):
+        res[a0] = oracle.pf_run(np.zeros((ns, NP, 4), np.float32), np.full((ns, NP), 1.0 / NP, np.float32), obs[:, :ns], nobs[:, :ns],
+                                ut[:, :ns], nrm_h, uni_h, agents=(a0, a1))
+    t_cpu = cpu_parallel(work, ns, min(cores, ns // 2))
+    in_bytes = (NP * 2 * 4 + NP * 4 + 4 * 3 * 4 + 4 + 8) + 16
+    print(json.dumps({
+        "workload": f"particle filter, {n} vehicles x {T} ticks x {NP} particles, one vehicle per wavefront (pf_localization + resampling)",
+        "vehicle_ticks_per_s": n * T / t_pf, "particle_updates_per_s": n * T * NP / t_pf, "ms": t_pf * 1e3,
+        "GB_per_s_inputs": n * T * in_bytes / t_pf / 1e9, "mean_position_error_m": err,
+        "resampling_fraction": float(nres.float().mean().item()) / T,
+        "cpu_baseline": {"value": ns * T / t_cpu, "unit": "vehicle-ticks/s", "cores": min(cores, ns // 2), "kind": "port",
+                         "sample": f"first {ns} vehicles", "single_thread_value": single}}))
+
 
 if __name__ == "__main__":
     main()

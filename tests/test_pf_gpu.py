@@ -1,0 +1,54 @@
+"""GPU parity of the particle filter (one vehicle per wavefront) against the CPU oracle.  Statistical by construction
+(pf_kernels.hip.h): single ticks agree to float round-off; over long runs a resampling tie can flip, so episodes are
+compared through their estimation error and resampling counts."""
+import numpy as np
+import pytest
+
+from test_oracle_pf import _scenario
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 130])
+def test_pf_single_tick_matches_oracle(crx, oracle_mod, n):
+    NP = 100
+    rng = np.random.default_rng(n)
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle_mod, n, 30, NP, 10 + n)
+    pw = rng.uniform(0.5, 1.5, (n, NP)).astype(np.float32); pw /= pw.sum(axis=1, keepdims=True)
+    for t in (1, 7, 20):
+        px = (xth[t - 1][:, None, :] + rng.normal(0, 0.05, (n, NP, 4))).astype(np.float32)   # a particle cloud around the truth
+        pxo, pwo, xeo, Peo, reso, anco = oracle_mod.pf_step(px, pw, obs[t], nobs[t], ut[t], nrm[t], uni[t])
+        pxd, pwd = _t(px), _t(pw)
+        xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs[t:t + 1]), _t(nobs[t:t + 1]), _t(ut[t:t + 1]), _t(nrm[t:t + 1]), _t(uni[t:t + 1]))
+        assert np.allclose(xe.cpu().numpy(), xeo, rtol=1e-5, atol=1e-5)
+        assert np.allclose(Pe.cpu().numpy(), Peo, rtol=1e-3, atol=1e-6)
+        assert np.allclose(hist.cpu().numpy()[0], xeo, rtol=1e-5, atol=1e-5)
+        same = nres.cpu().numpy() == reso
+        assert same.mean() >= 0.95                                   # Neff within round-off of NP/2 may flip
+        g = pxd.cpu().numpy()
+        close = np.isclose(g, pxo, rtol=1e-5, atol=1e-5).all(axis=2)
+        assert close[same].mean() > 0.98                             # a particle on a cumulative-weight boundary may pick its neighbour
+        assert np.allclose(pwd.cpu().numpy()[same], pwo[same], rtol=1e-4, atol=1e-8)
+
+
+def test_pf_episode_tracks_like_the_oracle(crx, oracle_mod):
+    n, T, NP = 96, 300, 100
+    ut, obs, nobs, nrm, uni, xth, xdh = _scenario(oracle_mod, n, T, NP, 5)
+    px, pw = np.zeros((n, NP, 4), np.float32), np.full((n, NP), 1.0 / NP, np.float32)
+    _, _, xeo, Peo, xho, nreso = oracle_mod.pf_run(px, pw, obs, nobs, ut, nrm, uni)
+    pxd, pwd = _t(px), _t(pw)
+    xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs), _t(nobs), _t(ut), _t(nrm), _t(uni))
+    h = hist.cpu().numpy()
+    err_g = np.hypot(h[..., 0] - xth[..., 0], h[..., 1] - xth[..., 1])
+    err_o = np.hypot(xho[..., 0] - xth[..., 0], xho[..., 1] - xth[..., 1])
+    assert err_g.mean() < 0.1 and abs(err_g.mean() - err_o.mean()) < 0.01
+    # vehicles whose runs never diverged (no flipped resampling decision) agree to round-off for the whole episode
+    same = np.abs(h - xho).max(axis=(0, 2)) < 1e-3
+    assert same.mean() > 0.5
+    assert np.abs(nres.cpu().numpy().astype(int) - nreso).max() <= 0.05 * T
+    assert np.allclose(pwd.cpu().numpy().sum(axis=1), 1.0, atol=1e-4)

@@ -147,15 +147,47 @@ __device__ __forceinline__ void dlqr4_dense_gain(const float* A, const float* B,
   for (int j = 0; j < 4; ++j) Kout[j] = inv * BtXA[j];
 }
 
+// (Xn - X).cwiseAbs().maxCoeff(): a strict '>' scan from element 0 in which a NaN element never replaces the
+// running maximum, and a NaN FIRST element sticks.  v_max_f32 has exactly that behaviour for every element but the
+// first (max(m, NaN) = m), so the scan is one subtract + one max per element, with the first-element NaN patched in.
 template <int N>
 __device__ __forceinline__ float max_abs_diff(const float* a, const float* b) {
-  float m = fabsf(a[0] - b[0]);
+  const float m0 = fabsf(a[0] - b[0]);
+  float m = m0;
 #pragma unroll
-  for (int i = 1; i < N; ++i) {
-    const float e = fabsf(a[i] - b[i]);
-    m = (e > m) ? e : m;  // maxCoeff(): strict '>' scan; NaN never replaces
+  for (int i = 1; i < N; ++i) m = fmaxf(m, fabsf(a[i] - b[i]));
+  return (m0 != m0) ? m0 : m;
+}
+
+// The reference's fixed-point loop (solve_DARE :86-99): X = Q; repeat Xn = f(X); stop when max|Xn - X| < eps (return Xn)
+// else X = Xn; after maxiter evaluations return the last one.  Either way the value handed back is the most recent
+// iterate.  Written as a two-buffer ping-pong (X -> Y -> X ...) so that no 16/25-register copy sits in the loop; lanes
+// that have converged are masked off (their buffers are no longer written) while the wave finishes its slowest agent.
+// X holds the start value on entry and the result on return; returns the number of evaluations performed.
+template <int NN, class IterFn>
+__device__ __forceinline__ int riccati_fixed_point(float* X, float eps, int maxiter, bool live, IterFn iter) {
+  float Y[NN];
+  bool done = !live || maxiter <= 0;
+  bool in_y = false;                      // which buffer holds this lane's most recent iterate
+  int it = maxiter < 0 ? 0 : maxiter;
+  for (int i = 0; i < maxiter; i += 2) {
+    if (!done) {
+      iter(X, Y);
+      in_y = true;
+      if (max_abs_diff<NN>(Y, X) < eps) { done = true; it = i + 1; }
+    }
+    if (!done && i + 1 < maxiter) {
+      iter(Y, X);
+      in_y = false;
+      if (max_abs_diff<NN>(X, Y) < eps) { done = true; it = i + 2; }
+    }
+    if (__all(done)) break;
   }
-  return m;
+  if (in_y) {
+#pragma unroll
+    for (int j = 0; j < NN; ++j) X[j] = Y[j];
+  }
+  return it;
 }
 
 template <int DIM>
@@ -168,7 +200,7 @@ dare_dense_kernel(int n, const float* __restrict__ Ag, const float* __restrict__
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = a < (size_t)n;
   const size_t ai = live ? a : 0;
-  float A[NN], B[DIM * M], Q[NN], R[M * M], X[NN], Xn[NN];
+  float A[NN], B[DIM * M], Q[NN], R[M * M], X[NN];
 #pragma unroll
   for (int i = 0; i < NN; ++i) { A[i] = Ag[ai * NN + i]; Q[i] = Qg[ai * NN + i]; X[i] = Q[i]; }
 #pragma unroll
@@ -176,20 +208,10 @@ dare_dense_kernel(int n, const float* __restrict__ Ag, const float* __restrict__
 #pragma unroll
   for (int i = 0; i < M * M; ++i) R[i] = Rg[ai * M * M + i];
 
-  bool done = !live || maxiter <= 0;
-  int it = maxiter < 0 ? 0 : maxiter;
-  for (int i = 0; i < maxiter; ++i) {
-    if (!done) {
-      if (DIM == 5) dare5_dense_iter(A, B, Q, R, X, Xn);
-      else dare4_dense_iter(A, B, Q, R[0], X, Xn);
-      const float err = max_abs_diff<NN>(Xn, X);
-      // reference: if (err < eps) return Xn;  X = Xn;   — either way the value kept is Xn
-#pragma unroll
-      for (int j = 0; j < NN; ++j) X[j] = Xn[j];
-      if (err < eps) { done = true; it = i + 1; }
-    }
-    if (__all(done)) break;
-  }
+  const int it = riccati_fixed_point<NN>(X, eps, maxiter, live, [&](const float* Xi, float* Xo) {
+    if (DIM == 5) dare5_dense_iter(A, B, Q, R, Xi, Xo);
+    else dare4_dense_iter(A, B, Q, R[0], Xi, Xo);
+  });
   if (!live) return;
   if (Xg) {
 #pragma unroll
@@ -325,23 +347,13 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
   const bool live = a < (size_t)n;
   const float v = live ? vg[a] : 1.0f;
   const float bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
-  float X[NN], Xn[NN];
+  float X[NN];
 #pragma unroll
   for (int i = 0; i < NN; ++i) X[i] = (i % (DIM + 1) == 0) ? 1.0f : 0.0f;
-
-  bool done = !live || maxiter <= 0;
-  int it = maxiter < 0 ? 0 : maxiter;
-  for (int i = 0; i < maxiter; ++i) {
-    if (!done) {
-      if (DIM == 5) dare5_v_iter(dt, v, bv, dt, X, Xn);
-      else dare4_v_iter(dt, v, bv, X, Xn);
-      const float err = max_abs_diff<NN>(Xn, X);
-#pragma unroll
-      for (int j = 0; j < NN; ++j) X[j] = Xn[j];
-      if (err < eps) { done = true; it = i + 1; }
-    }
-    if (__all(done)) break;
-  }
+  const int it = riccati_fixed_point<NN>(X, eps, maxiter, live, [&](const float* Xi, float* Xo) {
+    if (DIM == 5) dare5_v_iter(dt, v, bv, dt, Xi, Xo);
+    else dare4_v_iter(dt, v, bv, Xi, Xo);
+  });
   if (!live) return;
   if (Xg) {
 #pragma unroll

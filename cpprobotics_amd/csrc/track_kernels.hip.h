@@ -81,21 +81,13 @@ template <int DIM>
 __device__ __forceinline__ void dlqr_from_v_dev(float v, float dtf, double L, float eps, int maxiter, bool live, float* K) {
   constexpr int NN = DIM * DIM;
   const float bv = (float)((double)v / L);   // B(3,0) = state.v / L
-  float X[NN], Xn[NN];
+  float X[NN];
 #pragma unroll
   for (int i = 0; i < NN; ++i) X[i] = (i % (DIM + 1) == 0) ? 1.0f : 0.0f;
-  bool done = !live || maxiter <= 0;
-  for (int i = 0; i < maxiter; ++i) {
-    if (!done) {
-      if (DIM == 5) dare5_v_iter(dtf, v, bv, dtf, X, Xn);
-      else dare4_v_iter(dtf, v, bv, X, Xn);
-      const float err = max_abs_diff<NN>(Xn, X);
-#pragma unroll
-      for (int j = 0; j < NN; ++j) X[j] = Xn[j];
-      if (err < eps) done = true;
-    }
-    if (__all(done)) break;
-  }
+  riccati_fixed_point<NN>(X, eps, maxiter, live, [&](const float* Xi, float* Xo) {
+    if (DIM == 5) dare5_v_iter(dtf, v, bv, dtf, Xi, Xo);
+    else dare4_v_iter(dtf, v, bv, Xi, Xo);
+  });
   if (DIM == 5) dlqr5_v_gain(dtf, v, bv, dtf, X, K);
   else dlqr4_v_gain(dtf, v, bv, X, K);
 }

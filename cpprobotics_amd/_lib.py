@@ -38,6 +38,11 @@ class LoopParams(C.Structure):
                 ("stop_speed", C.c_float), ("max_ticks", C.c_int)]
 
 
+class DwaConfig(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("max_speed", "min_speed", "max_yawrate", "max_accel", "robot_radius", "max_dyawrate",
+                                          "v_reso", "yawrate_reso", "dt", "predict_time", "to_goal_cost_gain", "speed_cost_gain")]
+
+
 class PfParams(C.Structure):
     _fields_ = [("rsim0", C.c_float), ("rsim1", C.c_float), ("Q", C.c_float), ("dt", C.c_double), ("nth", C.c_float)]
 
@@ -89,6 +94,8 @@ _SIGNATURES = {
     "crx_calc_nearest_index_window_batch_dev": (_I, [_I, _P, _CP, _P, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch_dev": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P, _P]),
+    "crx_dwa_default_config": (None, [C.POINTER(DwaConfig)]),
+    "crx_dwa_run_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _I, C.POINTER(DwaConfig), _P, _P, _P, _P, _P, _P]),
     "crx_pf_default_params": (None, [C.POINTER(PfParams)]),
     "crx_pf_run_batch_dev": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(PfParams), _P, _P, _P]),
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),

@@ -116,6 +116,46 @@ CRX_FD float atan2f_(float y, float x) {
   }
 }
 
+// ---- acosf (e_acosf.c) --------------------------------------------------------------------------
+// std::acos(float) in the reference's DWA goal cost (/root/reference/src/dynamic_window_approach.cpp:107).
+CRX_FD float acosf_(float x) {
+  const float pi = fd_float(0x40490fdau), pio2_hi = fd_float(0x3fc90fdau), pio2_lo = fd_float(0x33a22168u);
+  const float pS0 = fd_float(0x3e2aaaabu), pS1 = fd_float(0xbea6b090u), pS2 = fd_float(0x3e4e0aa8u),
+              pS3 = fd_float(0xbd241146u), pS4 = fd_float(0x3a4f7f04u), pS5 = fd_float(0x3811ef08u),
+              qS1 = fd_float(0xc019d139u), qS2 = fd_float(0x4001572du), qS3 = fd_float(0xbf303361u),
+              qS4 = fd_float(0x3d9dc62eu);
+  const int32_t hx = (int32_t)fd_bits(x);
+  const int32_t ix = hx & 0x7fffffff;
+  if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;   // |x| == 1
+  if (ix > 0x3f800000) return (x - x) / (x - x);                      // |x| > 1 or NaN -> NaN
+  if (ix < 0x3f000000) {                                              // |x| < 0.5
+    if (ix <= 0x23000000) return pio2_hi + pio2_lo;                   // |x| < 2^-57
+    const float z = x * x;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    return pio2_hi - (x - (pio2_lo - x * r));
+  } else if (hx < 0) {                                                // x < -0.5
+    const float z = (1.0f + x) * 0.5f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float s = __builtin_sqrtf(z);
+    const float r = p / q;
+    const float w = r * s - pio2_lo;
+    return pi - 2.0f * (s + w);
+  } else {                                                            // x > 0.5
+    const float z = (1.0f - x) * 0.5f;
+    const float s = __builtin_sqrtf(z);
+    const float df = fd_float(fd_bits(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+  }
+}
+
 // ---- tanf (s_tanf.c, k_tanf.c, the |x| < 2^7*pi/2 part of e_rem_pio2f.c) -------------------------
 CRX_FD float kernel_tanf_(float x, float y, int iy) {
   const float pio4 = fd_float(0x3f490fdau), pio4lo = fd_float(0x33222168u);

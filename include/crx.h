@@ -262,6 +262,23 @@ int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, floa
                          const int* nobs, const float* u, const float* nrm, const float* uni, const crx_pf_params* prm,
                          float* x_hist, int* n_resampled, void* stream);
 
+
+/* ---- dynamic-window planner (src/dynamic_window_approach.cpp) -----------------------------------
+ * The reference's main loop (:190-192, goal test :225) for n agents, max_ticks control steps at most, ONE AGENT PER
+ * WAVEFRONT: per tick dwa_control (calc_dynamic_window, every (v, yawrate) sample rolled out and scored, the reference's
+ * winner picked) -> motion -> goal test.  max_ticks = 1 is a single dwa_control + motion.
+ * state [n][5] = (x, y, yaw, v, yawrate) in/out; u [n][2] in/out; goal [n][2]; ob [nob][2] shared (nob <= 256);
+ * traj_hist (may be NULL) [max_ticks][n][5]; ticks_done, status (bit 0: the window held more samples than the kernel's
+ * grids, 64 speeds x 1024 yaw rates, and was clipped), best_idx / n_samples of the LAST executed tick (may be NULL). */
+typedef struct crx_dwa_config {   /* Config :25-41 */
+  float max_speed, min_speed, max_yawrate, max_accel, robot_radius, max_dyawrate, v_reso, yawrate_reso, dt, predict_time,
+      to_goal_cost_gain, speed_cost_gain;
+} crx_dwa_config;
+void crx_dwa_default_config(crx_dwa_config* c);
+int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const float* goal, const float* ob, int nob,
+                          const crx_dwa_config* cfg, float* traj_hist, int* ticks_done, int* status, int* best_idx,
+                          int* n_samples, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

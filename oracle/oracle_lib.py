@@ -17,7 +17,7 @@ _F = C.c_float
 
 def build(force=False):
     """g++ -O2 -ffp-contract=off (oracle/Makefile).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "eigen_order.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "dwa_ref.cpp", "eigen_order.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -349,3 +349,39 @@ def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=Non
     _pf_lib().oracle_pf_run(_I(n), _I(NP), _I(L), _I(T), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm),
                             _p(uni), _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(xh), _p(nres), _I(a0), _I(a1))
     return px, pw, xEst, PEst, xh, nres
+
+
+# ---- dynamic window approach (oracle/dwa_ref.cpp) ---------------------------------------------------------
+_PI_REF = 3.141592653     # `#define PI 3.141592653` (src/dynamic_window_approach.cpp:16)
+DWA_CONFIG = np.array([1.0, -0.5, 40.0 * _PI_REF / 180.0, 0.2, 1.0, 40.0 * _PI_REF / 180.0, 0.01, 0.1 * _PI_REF / 180.0, 0.1, 3.0,
+                       1.0, 1.0], dtype=np.float32)   # Config :25-41, field order
+DWA_OBSTACLES = np.array([[-1, -1], [0, 2], [4.0, 2.0], [5.0, 4.0], [5.0, 5.0], [5.0, 6.0], [5.0, 9.0], [8.0, 9.0], [7.0, 9.0],
+                          [12.0, 12.0]], dtype=np.float32)   # :164-175
+
+
+def _dwa_lib():
+    l = lib()
+    l.oracle_dwa_set_trig_mode(_I(trig_mode()))
+    return l
+
+
+def dwa_control(state, u, goal, ob=DWA_OBSTACLES, cfg=DWA_CONFIG, agents=None):
+    """dwa_control for n agents: state [n,5], u [n,2], goal [n,2].  Returns (u_new, n_samples, best_idx)."""
+    state, u, goal, ob, cfg = _f32(state), _f32(u).copy(), _f32(goal), _f32(ob), _f32(cfg)
+    n = state.shape[0]
+    ns, bi = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    a0, a1 = (0, n) if agents is None else agents
+    _dwa_lib().oracle_dwa_control(_I(n), _p(state), _p(u), _p(goal), _p(ob), _I(ob.shape[0]), _p(cfg), _p(ns), _p(bi), _I(a0), _I(a1))
+    return u, ns, bi
+
+
+def dwa_run(state, u, goal, max_ticks, ob=DWA_OBSTACLES, cfg=DWA_CONFIG, want_hist=False, agents=None):
+    """The reference's main loop (dwa_control -> motion -> goal test).  Returns (state, u, ticks_done, traj_hist)."""
+    state, u, goal, ob, cfg = _f32(state).copy(), _f32(u).copy(), _f32(goal), _f32(ob), _f32(cfg)
+    n = state.shape[0]
+    ticks = np.zeros(n, np.int32)
+    hist = np.zeros((max_ticks, n, 5), np.float32) if want_hist else None
+    a0, a1 = (0, n) if agents is None else agents
+    _dwa_lib().oracle_dwa_run(_I(n), _I(max_ticks), _p(state), _p(u), _p(goal), _p(ob), _I(ob.shape[0]), _p(cfg), _p(hist), _p(ticks),
+                              _I(a0), _I(a1))
+    return state, u, ticks, hist

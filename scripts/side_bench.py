@@ -188,6 +188,38 @@ def main():
         "cpu_baseline": {"value": ns * T / t_cpu, "unit": "vehicle-ticks/s", "cores": min(cores, ns // 2), "kind": "port",
                          "sample": f"first {ns} vehicles", "single_thread_value": single}}))
 
+    # ---- dynamic-window planner: one agent per wavefront, whole episode fused ------------------------
+    n, max_ticks = 8192, 200
+    rng = np.random.default_rng(12)
+    dst = np.stack([rng.uniform(-1, 3, n), rng.uniform(-1, 3, n), rng.uniform(0, 1.2, n), np.zeros(n), np.zeros(n)], axis=1).astype(np.float32)
+    dgoal = np.tile(np.array([[10.0, 10.0]], np.float32), (n, 1))
+    du = np.zeros((n, 2), np.float32)
+    ob = oracle.oracle_lib.DWA_OBSTACLES
+    dsd, dud, dgd, obd = (torch.from_numpy(a).cuda() for a in (dst, du, dgoal, ob))
+    tk, _, stt, _, nsamp = crx.dwa_run(dsd.clone(), dud.clone(), dgd, obd, max_ticks)
+    t_dwa = gpu_time(lambda: crx.dwa_run(dsd.clone(), dud.clone(), dgd, obd, max_ticks), 1 if quick else 3)
+    tk = tk.cpu().numpy().astype(np.int64)
+    ns = 128
+    t1 = time.perf_counter()
+    ro = oracle.dwa_run(dst[:ns], du[:ns], dgoal[:ns], max_ticks, agents=(0, 4))
+    single = float(ro[2][:4].sum()) / (time.perf_counter() - t1)
+    res = {}
+
+    def work(a0, a1):
+        res[a0] = oracle.dwa_run(dst[:ns], du[:ns], dgoal[:ns], max_ticks, agents=(a0, a1))
+    t_cpu = cpu_parallel(work, ns, min(cores, ns))
+    full = oracle.dwa_run(dst[:32], du[:32], dgoal[:32], max_ticks)
+    s2, u2 = dsd.clone(), dud.clone()
+    tk2, *_ = crx.dwa_run(s2, u2, dgd, obd, max_ticks)
+    same = bool(np.array_equal(s2.cpu().numpy()[:32], full[0]) and np.array_equal(tk2.cpu().numpy()[:32], full[2]))
+    print(json.dumps({
+        "workload": f"dynamic-window planner, {n} agents, up to {max_ticks} control steps, ~405 sampled trajectories x 31 steps x {len(ob)} obstacles per step, one agent per wavefront",
+        "agent_steps_per_s": float(tk.sum()) / t_dwa, "trajectories_per_s": float(tk.sum()) * 405 / t_dwa, "ms": t_dwa * 1e3,
+        "mean_ticks": float(tk.mean()), "reached_goal_frac": float((tk < max_ticks).mean()),
+        "cpu_baseline": {"value": float(tk[:ns].sum()) / t_cpu, "unit": "agent-steps/s", "cores": min(cores, ns), "kind": "port",
+                         "sample": f"first {ns} agents", "single_thread_value": single},
+        "parity": {"first_32_agents_bit_identical": same}}))
+
 
 if __name__ == "__main__":
     main()

@@ -47,8 +47,7 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 // (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized
 // batches) were measured and are 1.0x-5x SLOWER: with single-wave workgroups the dispatcher stacks the extra waves
 // on a subset of the CUs instead of spreading them (scripts/gpu_lanes_sweep.sh; CRX_LANES overrides for experiments).
-inline unsigned narrow_block(size_t n, unsigned min_lanes = 4) {
-  (void)n; (void)min_lanes;
+inline unsigned iter_block() {
   static const int forced = [] { const char* e = std::getenv("CRX_LANES"); return e ? std::atoi(e) : 0; }();
   if (forced >= 1 && forced <= 64) return (unsigned)forced;
   return 64;
@@ -309,7 +308,7 @@ int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const flo
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const unsigned bs = narrow_block(n);
+  const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
   if (dim == 5)
     hipLaunchKernelGGL((crx::dare_dense_kernel<5>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
@@ -327,7 +326,7 @@ int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_para
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
-  const unsigned bs = narrow_block(n);
+  const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
   if (dim == 5)
     hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
@@ -388,7 +387,7 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, narrow_block(n)) == hipSuccess
+  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, iter_block()) == hipSuccess
              ? CRX_OK
              : hip_fail(hipGetLastError(), "mpc launch");
 }
@@ -485,7 +484,7 @@ int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
-  const unsigned bs = narrow_block(n, 8);
+  const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
@@ -518,7 +517,7 @@ int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
   const crx::VehicleParams vp = vparams(veh, 0);
-  const unsigned bs = narrow_block(n, 8);
+  const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
@@ -587,7 +586,7 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   for (int t = 0; t < loop->max_ticks; ++t) {
     hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, grid, block, 0, s, n, T, state, cv, dl, p.dt, nsearch, target_ind, xref,
                        (const int*)active);
-    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, narrow_block(n)) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
+    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, iter_block()) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
     hipLaunchKernelGGL(crx::mpc_tick_tail_kernel, grid, block, 0, s, n, T, t, state, sol, vp, loop->goal_x, loop->goal_y,
                        loop->goal_dis, active, ticks_done, traj_hist);
   }

@@ -11,7 +11,7 @@
 //
 // Parity is statistical / tolerance-based by construction: per-particle arithmetic follows the
 // reference statement by statement (double promotions included, cosf/sinf glibc-exact), but expf is OCML's and the
-// reductions are wave butterflies instead of Eigen's vectorised redux / gemv order, so sums differ in the last bits and
+// reductions are wave (DPP) reductions instead of Eigen's vectorised redux / gemv order, so sums differ in the last bits and
 // a resampling threshold can flip on a tie.
 //
 // Layout: px [n][NP][4] (Eigen::Matrix<float,4,NP> column-major = one float4 per particle), pw [n][NP], xEst [n][4],
@@ -29,26 +29,48 @@ struct PfParams {
   float nth;            // resampling threshold NTh = NP/2
 };
 
+// Wave-wide primitives on DPP (data-parallel primitives: the cross-lane operand is read through the VALU's own
+// lane-permute network, one instruction per step, no LDS traffic — `__shfl_*` compiles to ds_bpermute, which made the
+// first version of this kernel LDS-pipe bound).  gfx9 control words: quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E,
+// row_half_mirror = 0x141, row_mirror = 0x140, row_shr:n = 0x110 + n, row_bcast15 = 0x142 (rows 1,3 <- lane 15 of the row
+// before), row_bcast31 = 0x143 (rows 2,3 <- lane 31).  Lanes a control word does not cover read `old` (the identity).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v, float identity = 0.0f) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int v, int identity) {
+  return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false);
+}
+// sum over the 64 lanes, returned in every lane (through an SGPR)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);            // every lane: the sum of its row of 16
+  v += dpp_f<0x142, 0xA>(v);       // rows 1,3 += row before
+  v += dpp_f<0x143, 0xC>(v);       // rows 2,3 += rows 0+1  -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // inclusive scan over the 64 lanes (lane order)
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float t = __shfl_up(v, d, 64);
-    if (lane >= d) v += t;
-  }
+__device__ __forceinline__ float wave_scan_add(float v, int /*lane*/) {
+  v += dpp_f<0x111>(v);
+  v += dpp_f<0x112>(v);
+  v += dpp_f<0x114>(v);
+  v += dpp_f<0x118>(v);            // inclusive within the row of 16
+  v += dpp_f<0x142, 0xA>(v);
+  v += dpp_f<0x143, 0xC>(v);
   return v;
 }
-__device__ __forceinline__ int wave_scan_max(int v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(v, d, 64);
-    if (lane >= d) v = v > t ? v : t;
-  }
+__device__ __forceinline__ int wave_scan_max(int v, int /*lane*/) {
+  const int lowest = -2147483647 - 1;
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  v = mx(v, dpp_i<0x111>(v, lowest));
+  v = mx(v, dpp_i<0x112>(v, lowest));
+  v = mx(v, dpp_i<0x114>(v, lowest));
+  v = mx(v, dpp_i<0x118>(v, lowest));
+  v = mx(v, dpp_i<0x142, 0xA>(v, lowest));
+  v = mx(v, dpp_i<0x143, 0xC>(v, lowest));
   return v;
 }
 
@@ -137,7 +159,7 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
     if (Neff < p.nth) {                                   // wave-uniform
       ++nres;
       float c0 = wave_scan_add(w0, lane);                 // cumsum :110-117 (particles 0..63, then 64..NP-1)
-      const float tot0 = __shfl(c0, 63, 64);
+      const float tot0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0), 63));
       float c1 = wave_scan_add(w1, lane) + tot0;
       if (v0) { s_wc[wv][p0] = c0; s_x[wv][p0] = x0; }
       if (v1) { s_wc[wv][p1] = c1; s_x[wv][p1] = x1; }
@@ -156,7 +178,7 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
       int i0 = v0 ? pick(p0) : 0, i1 = v1 ? pick(p1) : 0;
       // `ind` never moves back in the reference's loop: running maximum in particle order
       i0 = wave_scan_max(i0, lane);
-      const int m0 = __shfl(i0, 63, 64);
+      const int m0 = __builtin_amdgcn_readlane(i0, 63);
       i1 = wave_scan_max(i1, lane);
       i1 = i1 > m0 ? i1 : m0;
       if (v0) x0 = s_x[wv][i0];

@@ -68,6 +68,32 @@ def test_argument_validation(crx):
     assert len(l.crx_last_error()) > 0
 
 
+def test_argument_validation_tracking_pf_dwa(crx):
+    """The newer entry points validate before touching the device (status CRX_ERR_INVALID = -1, message set)."""
+    from cpprobotics_amd import _lib as L
+    l = crx.lib()
+    x = np.zeros((4, 4), np.float32); f = np.zeros(4, np.float32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    course = L.Course(4, vp(f), vp(f), vp(f), vp(f), vp(f))
+    assert l.crx_lqr_steering_control_batch(4, 3, vp(x), C.byref(course), None, vp(f), vp(f), None, vp(x)) == -1       # dim
+    bad = L.Course(0, vp(f), vp(f), vp(f), vp(f), vp(f))
+    assert l.crx_lqr_steering_control_batch(4, 5, vp(x), C.byref(bad), None, vp(f), vp(f), None, vp(x)) == -1        # empty course
+    assert l.crx_calc_nearest_index_batch(4, None, C.byref(course), None, None) == -1
+    assert l.crx_update_batch(4, vp(x), None, vp(f), None) == -1
+    lp = L.LoopParams(0, 0, 0.3, 1.0, 0.05, -1)
+    assert l.crx_lqr_closed_loop_batch(4, 5, vp(x), C.byref(course), None, None, None, None, None, C.byref(lp), None, None) == -1   # max_ticks < 0
+    assert l.crx_calc_ref_trajectory_batch(4, 0, vp(x), C.byref(course), 1.0, 0.2, 10, vp(f), vp(x)) == -1              # T < 1
+    assert l.crx_pf_run_batch_dev(4, 77, 1, 4, vp(x), vp(x), vp(x), vp(x), None, None, None, None, None, None, None, None, None) == -1   # NP
+    assert l.crx_dwa_run_batch_dev(4, 1, vp(x), vp(x), vp(x), vp(x), 1000, None, None, None, None, None, None, None) == -1   # too many obstacles
+    assert b"bad argument" in l.crx_last_error()
+    v = L.VehicleParams(); l.crx_vehicle_default_params(C.byref(v), 1)
+    assert (v.dt, v.wheelbase, v.clamp_speed) == (0.2, 2.5, 1) and abs(v.max_steer - np.pi / 4) < 1e-15
+    d = L.DwaConfig(); l.crx_dwa_default_config(C.byref(d))
+    assert abs(d.max_yawrate - 40.0 * 3.141592653 / 180.0) < 1e-7 and abs(d.yawrate_reso - 0.1 * 3.141592653 / 180.0) < 1e-9
+    q = L.PfParams(); l.crx_pf_default_params(C.byref(q))
+    assert abs(q.Q - 0.01) < 1e-9 and q.dt == 0.1 and q.rsim0 == 1.0
+
+
 def test_product_does_not_reference_the_oracle():
     """Nothing under cpprobotics_amd/ may import, include or link the oracle (crx_trig.h is the one
     file the oracle borrows FROM the product, not the other way round)."""

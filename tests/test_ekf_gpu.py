@@ -245,3 +245,26 @@ def test_ekf_fused_64bit_address_kernels(crx, oracle_mod, monkeypatch):
     crx.ekf_run(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh, P_hist=ph)
     assert bit_equal(xh.cpu().numpy(), xho) and bit_equal(ph.cpu().numpy(), pho)
     assert bit_equal(xd.cpu().numpy(), xo) and bit_equal(Pd.cpu().numpy(), Po)
+
+
+@pytest.mark.parametrize("n,T", [(1 << 20, 24), ((1 << 22) + 64 * 3 + 5, 9)])
+def test_ekf_fused_large_batches(crx, oracle_mod, n, T):
+    """Million-vehicle launches: 2^20 uses the buffer-addressed kernel at its intended scale, 2^22 + 197 the 64-bit-address
+    one (beyond kEkfBufMaxN) with a ragged last workgroup.  A strided sample of vehicles is compared bit-for-bit."""
+    import torch
+    Q, R = ekf_QR()
+    g = torch.Generator(device="cuda"); g.manual_seed(n % 1000)
+    x0 = torch.zeros((n, 4), device="cuda")
+    x0[:, 2] = (torch.rand(n, generator=g, device="cuda") - 0.5) * 6.0
+    P0 = torch.eye(4, device="cuda").reshape(1, 16).repeat(n, 1).contiguous()
+    z = torch.randn((T, n, 2), generator=g, device="cuda") * 0.5
+    ud = torch.randn((T, n, 2), generator=g, device="cuda") * 0.3 + 1.0
+    xh = torch.empty((T, n, 4), device="cuda")
+    xd, Pd = x0.clone(), P0.clone()
+    crx.ekf_run(xd, Pd, z, ud, Q, R, x_hist=xh)
+    idx = torch.cat([torch.arange(0, n, 4099, device="cuda"), torch.arange(n - 70, n, device="cuda")])
+    ii = idx.cpu().numpy()
+    xo, Po, xho, _ = oracle_mod.ekf_run(x0[idx].cpu().numpy(), P0[idx].cpu().numpy(), z[:, idx].cpu().numpy(), ud[:, idx].cpu().numpy(), Q, R)
+    assert bit_equal(xh[:, idx].cpu().numpy(), xho)
+    assert bit_equal(xd[idx].cpu().numpy(), xo) and bit_equal(Pd[idx].cpu().numpy(), Po)
+    assert len(ii) > 300

@@ -268,3 +268,38 @@ def test_ekf_fused_large_batches(crx, oracle_mod, n, T):
     assert bit_equal(xh[:, idx].cpu().numpy(), xho)
     assert bit_equal(xd[idx].cpu().numpy(), xo) and bit_equal(Pd[idx].cpu().numpy(), Po)
     assert len(ii) > 300
+
+
+def test_ekf_fused_fuzz_wide_ranges(crx, oracle_mod):
+    """Fuzz: states, covariances, measurements and Q/R spread over 60 decades (denormals, huge values, a few inf/nan),
+    so that lanes leave and re-enter the fast domain in every combination."""
+    import torch
+    rng = np.random.default_rng(2025)
+    n, T = 64 * 9, 13
+    def wide(shape, lo=-30, hi=30):
+        return (rng.choice([-1.0, 1.0], shape) * np.exp(rng.uniform(lo, hi, shape) * np.log(10.0))).astype(np.float32)
+    x0 = wide((n, 4), -20, 8)
+    x0[:, 2] = wide(n, -45, 3)                       # yaw from denormal to 1000 rad
+    A = rng.standard_normal((n, 4, 4)).astype(np.float32)
+    P0 = (np.einsum("nij,nkj->nik", A, A) * wide((n, 1, 1), -30, 30)).astype(np.float32).reshape(n, 16)
+    z = wide((T, n, 2), -10, 6)
+    ud = wide((T, n, 2), -10, 2)
+    x0[5, 2] = np.inf; x0[70, 0] = np.nan; P0[130, 5] = np.inf; z[3, 200, 0] = np.nan; ud[5, 300, 1] = np.inf
+    for qs, rs in ((1.0, 1.0), (1e-10, 1e-8), (1e18, 1e20)):
+        Q0, R0 = ekf_QR()
+        Q, R = (Q0 * np.float32(qs)).astype(np.float32), (R0 * np.float32(rs)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            xo, Po, xho, pho = oracle_mod.ekf_run(x0, P0, z, ud, Q, R, want_phist=True)
+        xd, Pd = _t(x0), _t(P0)
+        xh = torch.empty((T, n, 4), dtype=torch.float32, device="cuda")
+        ph = torch.empty((T, n, 16), dtype=torch.float32, device="cuda")
+        crx.ekf_run(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh, P_hist=ph)
+        # Vehicles whose reference run stays finite must match bit for bit.  Once an operand is inf/nan the two differ by
+        # design: the engine skips the multiplications by the literal 0/1 entries of F_, jF, jH (exact for finite operands
+        # only: 0*inf = nan in the dense Eigen expression), so a non-finite vehicle is only required to end non-finite.
+        ok = np.isfinite(xho).all(axis=(0, 2)) & np.isfinite(pho).all(axis=(0, 2))
+        assert ok.sum() > 100
+        assert np.array_equal(xh.cpu().numpy()[:, ok], xho[:, ok]) and np.array_equal(ph.cpu().numpy()[:, ok], pho[:, ok])
+        assert np.array_equal(Pd.cpu().numpy()[ok], Po[ok]) and np.array_equal(xd.cpu().numpy()[ok], xo[ok])
+        bad = ~np.isfinite(xho[-1]).all(axis=1)
+        assert not np.isfinite(xh.cpu().numpy()[-1][bad]).all(axis=1).any()

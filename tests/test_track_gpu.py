@@ -130,3 +130,37 @@ def test_mpc_closed_loop_matches_oracle(crx, oracle_mod):
     assert floored_rel_err(hist.cpu().numpy(), histo, 1.0) <= 1e-5
     assert floored_rel_err(sd.cpu().numpy(), so, 1.0) <= 1e-5
     assert np.array_equal(td.cpu().numpy(), tindo)
+
+
+def test_tracking_fuzz_wide_ranges(crx, oracle_mod, lqr_setup):
+    """Control evaluation and update with states spread over many decades (vehicles far off the course, huge/tiny speeds,
+    NaN positions): wherever the oracle's result is finite the engine's is bit-identical; NaN positions keep the incoming
+    index, as the reference's reference parameter does."""
+    course, goal, dc = lqr_setup
+    rng = np.random.default_rng(99)
+    n = 3000
+    def wide(shape, lo, hi):
+        return (rng.choice([-1.0, 1.0], shape) * np.exp(rng.uniform(lo, hi, shape) * np.log(10.0))).astype(np.float32)
+    st = np.stack([wide(n, -6, 6), wide(n, -6, 6), wide(n, -8, 4), wide(n, -12, 6)], axis=1)
+    st[::97, 0] = np.nan
+    pe, pth = wide(n, -10, 3), wide(n, -10, 3)
+    ind0 = rng.integers(0, len(course[0]), n).astype(np.int32)
+    for dim in (5, 4):
+        with np.errstate(all="ignore"):
+            co, io, peo, ptho = oracle_mod.lqr_steering_control(st, course, pe, pth, dim=dim, ind=ind0)
+        ped, pthd, indd = _t(pe), _t(pth), _t(ind0)
+        ctl, ind = crx.lqr_steering_control(_t(st), dc, ped, pthd, dim=dim, ind=indd)
+        assert np.array_equal(ind.cpu().numpy(), io)
+        c = ctl.cpu().numpy().reshape(n, -1); cr = co.reshape(n, -1)
+        fin = np.isfinite(cr).all(axis=1) & np.isfinite(peo) & np.isfinite(ptho)
+        assert fin.mean() > 0.5
+        assert np.array_equal(c[fin], cr[fin]) and np.array_equal(ped.cpu().numpy()[fin], peo[fin]) and np.array_equal(pthd.cpu().numpy()[fin], ptho[fin])
+    a, d = wide(n, -8, 3), wide(n, -8, 2)
+    for mpc in (False, True):
+        dt, wb = (0.2, 2.5) if mpc else (0.1, 0.5)
+        with np.errstate(all="ignore"):
+            ref = oracle_mod.update(st, a, d, dt=dt, wheelbase=wb, clamp_speed=mpc)
+        sd = _t(st)
+        crx.update(sd, _t(a), _t(d), crx.vehicle_params(mpc))
+        got = sd.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(got[~np.isnan(ref)], ref[~np.isnan(ref)])

@@ -351,11 +351,11 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
           else if (a == 4 && b == 4) qss = l_pp0;
           else if (a == 5 && b == 5) qss = l_pp1;
           else qss = 0.0;
+          // K'QuuK + K'Qus + Qus'K is symmetric (Quu is symmetrised through `hod`); only the upper triangle is formed and
+          // mirrored below, so one evaluation per entry suffices
           const double tab = (K[0][a] * QuuK[0][b] + K[1][a] * QuuK[1][b]) + (K[0][a] * Qus[0][b] + K[1][a] * Qus[1][b]) +
                              (Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b]);
-          const double tba = (K[0][b] * QuuK[0][a] + K[1][b] * QuuK[1][a]) + (K[0][b] * Qus[0][a] + K[1][b] * Qus[1][a]) +
-                             (Qus[0][b] * K[0][a] + Qus[1][b] * K[1][a]);
-          Vss[a][b] = qss + 0.5 * (tab + tba);
+          Vss[a][b] = qss + tab;
         }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {

@@ -1,21 +1,22 @@
-set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_mpc_gpu.py -m gpu -x -q 2>&1 | tail -30 > gpurun_out/pytest_mpc.log
-cat gpurun_out/pytest_mpc.log
-timeout 300 python - <<'PY' 2>&1 | tee gpurun_out/mpc_bench.log
-import torch, sys, numpy as np
-sys.path.insert(0,'tests')
-import cpprobotics_amd as crx
+timeout 900 python -m pytest tests/test_mpc_gpu.py tests/test_golden_gpu.py tests/test_track_gpu.py -x -q -m gpu 2>&1 | tail -4 | cut -c1-300
+timeout 600 python - <<'PY' 2>/dev/null
+import sys, numpy as np, torch
+sys.path.insert(0,'tests'); sys.path.insert(0,'.')
+import cpprobotics_amd as crx, oracle
 from common import *
-for n,T in [(8192,21),(65536,21),(8192,6)]:
-    x0,xref=mpc_problem(n,T,4)
-    x0=torch.from_numpy(x0).cuda(); xref=torch.from_numpy(xref).cuda()
-    sol,st,c=crx.mpc_solve(x0,xref,T,return_status=True); torch.cuda.synchronize()
-    s=torch.cuda.Event(enable_timing=True); e=torch.cuda.Event(enable_timing=True)
-    s.record()
-    for i in range(3): crx.mpc_solve(x0,xref,T)
-    e.record(); torch.cuda.synchronize(); ms=s.elapsed_time(e)/3
-    it=(st>>8).cpu().numpy()
-    print(f"mpc n={n} T={T}: {ms:.3f} ms  {n/ms/1e3:.3f} M solves/s  conv {(st&1).float().mean().item():.4f} mean_it {it.mean():.2f} max_it {it.max()}")
+def gt(fn, reps):
+    fn(); torch.cuda.synchronize()
+    a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize(); return a.elapsed_time(b)/reps
+for T in (21,6):
+    x0,xr=mpc_problem(8192,T,4); x0d,xrd=torch.from_numpy(x0).cuda(),torch.from_numpy(xr).cuda()
+    ms=gt(lambda: crx.mpc_solve(x0d,xrd,T),5)
+    sol,st,cost=crx.mpc_solve(x0d,xrd,T,return_status=True)
+    so,sto,co=oracle.mpc_solve(x0[:1024],xr[:1024],T)
+    st=st.cpu().numpy()[:1024]; both=((st&1)==1)&((sto&1)==1)
+    err=np.max(np.abs(sol.cpu().numpy()[:1024][both]-so[both])/np.maximum(np.abs(so[both]),1.0))
+    print(f"T={T}: {ms:.3f} ms  {8192/ms*1e3/1e6:.3f} M solves/s  err vs twin {err:.2e}  iters equal {np.mean((st>>8)==(sto>>8)):.4f} both_conv {both.mean():.4f}")
 PY

@@ -131,6 +131,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
   double TR[2][MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them
 
   const double dt = p.dt, wb = p.wb;
+  const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
   const double lb0 = -p.max_steer, ub0 = p.max_steer, lb1 = -p.max_accel, ub1 = p.max_accel;
 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
@@ -156,7 +157,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
     sn[0] = s[0] + s[3] * cs_ * dt;
     sn[1] = s[1] + s[3] * sn_ * dt;
-    sn[2] = s[2] + s[3] * tn_ / wb * dt;
+    sn[2] = s[2] + s[3] * tn_ * dt_wb;
     sn[3] = s[3] + a * dt;
   };
 
@@ -218,8 +219,8 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       const double sn_ = TR[cur][i][0], cs_ = TR[cur][i][1];
       const double v = s[3];
       const double tn = TR[cur][i][2], sec2 = 1.0 + tn * tn;
-      const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn / wb * dt;
-      const double bd = v * sec2 / wb * dt;
+      const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
+      const double bd = v * sec2 * dt_wb;
       // stage cost derivatives
       double l_x[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
       double l_u0 = 2.0 * p.r_d * ud, l_u1 = 2.0 * p.r_a * ua;
@@ -290,8 +291,8 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
         Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
         const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
         Qxx[2][3] += cross; Qxx[3][2] += cross;
-        Qux[0][3] += lx[2] * sec2 / wb * dt;
-        Quu00 += lx[2] * v / wb * dt * 2.0 * tn * sec2;
+        Qux[0][3] += lx[2] * sec2 * dt_wb;
+        Quu00 += lx[2] * v * dt_wb * 2.0 * tn * sec2;
       }
       const double hod = 0.5 * (Quu01 + Quu10);
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
@@ -302,23 +303,21 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 #pragma unroll
       for (int b = 0; b < 4; ++b) { Qus[0][b] = Qux[0][b]; Qus[1][b] = Qux[1][b]; }
       Qus[0][4] = l_up0; Qus[0][5] = 0.0; Qus[1][4] = 0.0; Qus[1][5] = l_up1;
+      // K = -Hinv * Qus with Hinv the inverse of the free block of [h00 hod; hod h11]: one reciprocal and selects instead
+      // of a divergent four-way branch with up to 24 fp64 divisions (each ~35 instructions on gfx950)
       double K[2][6];
-      if (f0 && f1) {
-        const double det = h00 * h11 - hod * hod;
+      {
+        const bool both = f0 && f1;
+        const double den = both ? (h00 * h11 - hod * hod) : (f0 ? h00 : (f1 ? h11 : 1.0));
+        const double inv = 1.0 / den;
+        const double i00 = both ? h11 * inv : (f0 ? inv : 0.0);
+        const double i11 = both ? h00 * inv : (f1 ? inv : 0.0);
+        const double i01 = both ? -hod * inv : 0.0;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-          K[0][b] = -(h11 * Qus[0][b] - hod * Qus[1][b]) / det;
-          K[1][b] = -(-hod * Qus[0][b] + h00 * Qus[1][b]) / det;
+          K[0][b] = -(i00 * Qus[0][b] + i01 * Qus[1][b]);
+          K[1][b] = -(i01 * Qus[0][b] + i11 * Qus[1][b]);
         }
-      } else if (f0) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b) { K[0][b] = -Qus[0][b] / h00; K[1][b] = 0.0; }
-      } else if (f1) {
-#pragma unroll
-        for (int b = 0; b < 6; ++b) { K[0][b] = 0.0; K[1][b] = -Qus[1][b] / h11; }
-      } else {
-#pragma unroll
-        for (int b = 0; b < 6; ++b) { K[0][b] = 0.0; K[1][b] = 0.0; }
       }
       kf[i][0] = k0; kf[i][1] = k1;
 #pragma unroll

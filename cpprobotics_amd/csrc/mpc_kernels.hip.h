@@ -32,6 +32,12 @@
 
 #define CRX_MPC_MAX_T 64
 
+// The library is built with -ffp-contract=off because the fp32 EKF / DARE / tracking kernels reproduce the reference's
+// unfused mul-then-add arithmetic bit for bit.  The MPC solver is fp64 with tolerance-based parity (the reference's own
+// answer is an IPOPT iterate), so inside this header multiply-adds may fuse: the backward sweep is ~650 dependent fp64
+// mul/add per stage, which fma contraction cuts by a third.  Restored to `off` at the end of the file.
+#pragma clang fp contract(fast)
+
 namespace crx {
 
 // sin, cos (and tan = sin/cos) in fp64 for the solver.  OCML's sincos()/tan() carry a full Payne-Hanek reduction and
@@ -450,3 +456,5 @@ inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, c
 }
 
 }  // namespace crx
+
+#pragma clang fp contract(off)

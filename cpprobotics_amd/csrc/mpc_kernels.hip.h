@@ -90,8 +90,9 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   const double tiny = 1e-12;
   const double det = h00 * h11 - hod * hod;
   if (h00 > tiny && det > tiny * h00) {
-    const double a = -(h11 * g0 - hod * g1) / det;
-    const double b = -(-hod * g0 + h00 * g1) / det;
+    const double idet = 1.0 / det;
+    const double a = -(h11 * g0 - hod * g1) * idet;
+    const double b = -(-hod * g0 + h00 * g1) * idet;
     if (a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1) { k0 = a; k1 = b; f0 = true; f1 = true; return; }
   }
   double best = 1e300;
@@ -100,16 +101,17 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
     const double obj = 0.5 * (h00 * a * a + 2.0 * hod * a * b + h11 * b * b) + g0 * a + g1 * b;
     if (obj < best) { best = obj; k0 = a; k1 = b; f0 = fa; f1 = fb; }
   };
+  const double ih11 = (h11 > tiny) ? 1.0 / h11 : 0.0, ih00 = (h00 > tiny) ? 1.0 / h00 : 0.0;   // one reciprocal per edge pair
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double c0 = b ? hi0 : lo0;
     if (h11 > tiny) {
-      const double t = -(g1 + hod * c0) / h11;
+      const double t = -(g1 + hod * c0) * ih11;
       if (t >= lo1 && t <= hi1) consider(c0, t, false, true);
     }
     const double c1 = b ? hi1 : lo1;
     if (h00 > tiny) {
-      const double t = -(g0 + hod * c1) / h00;
+      const double t = -(g0 + hod * c1) * ih00;
       if (t >= lo0 && t <= hi0) consider(t, c1, true, false);
     }
   }

@@ -16,6 +16,7 @@ from .ekf import (  # noqa: F401
 from .lqr import dlqr, dlqr_from_v, solve_DARE, solve_DARE_from_v  # noqa: F401
 from .mpc import mpc_n_vars, mpc_solve  # noqa: F401
 from .dwa import dwa_control, dwa_default_config, dwa_run  # noqa: F401
+from .frenet import FrenetCourse, frenet_default_config, frenet_num_paths, frenet_optimal_planning, frenet_run  # noqa: F401
 from .pf import pf_default_params, pf_run  # noqa: F401
 from .track import (  # noqa: F401
     Course, calc_nearest_index, calc_nearest_index_window, calc_ref_trajectory, closed_loop_prediction,
@@ -29,6 +30,7 @@ __all__ = [
     "solve_DARE", "dlqr", "solve_DARE_from_v", "dlqr_from_v",
     "mpc_solve", "mpc_n_vars",
     "pf_run", "pf_default_params", "dwa_run", "dwa_control", "dwa_default_config",
+    "FrenetCourse", "frenet_default_config", "frenet_num_paths", "frenet_optimal_planning", "frenet_run",
     "Course", "calc_nearest_index", "lqr_steering_control", "update", "closed_loop_prediction",
     "calc_nearest_index_window", "calc_ref_trajectory", "mpc_simulation", "vehicle_params",
 ]

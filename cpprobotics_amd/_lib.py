@@ -43,6 +43,12 @@ class DwaConfig(C.Structure):
                                           "v_reso", "yawrate_reso", "dt", "predict_time", "to_goal_cost_gain", "speed_cost_gain")]
 
 
+class FrenetConfig(C.Structure):
+    _fields_ = ([(k, C.c_double) for k in ("max_speed", "max_accel", "max_curvature", "max_road_width", "d_road_w", "dt", "maxt",
+                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int), ("single_d_push", C.c_int)] +
+                [(k, C.c_double) for k in ("robot_radius", "kj", "kt", "kd", "klat", "klon")])
+
+
 class PfParams(C.Structure):
     _fields_ = [("rsim0", C.c_float), ("rsim1", C.c_float), ("Q", C.c_float), ("dt", C.c_double), ("nth", C.c_float)]
 
@@ -96,6 +102,11 @@ _SIGNATURES = {
     "crx_calc_ref_trajectory_batch_dev": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P, _P]),
     "crx_dwa_default_config": (None, [C.POINTER(DwaConfig)]),
     "crx_dwa_run_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _I, C.POINTER(DwaConfig), _P, _P, _P, _P, _P, _P]),
+    "crx_frenet_default_config": (None, [C.POINTER(FrenetConfig)]),
+    "crx_frenet_num_paths": (_I, [C.POINTER(FrenetConfig)]),
+    "crx_frenet_spline_build": (_I, [_P, _P, _I, _P]),
+    "crx_frenet_course_samples": (_I, [_P, _I, _P, _P, _I]),
+    "crx_frenet_run_batch_dev": (_I, [_I, _I, _P, _P, _I, _P, _P, _I, C.POINTER(FrenetConfig), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "crx_pf_default_params": (None, [C.POINTER(PfParams)]),
     "crx_pf_run_batch_dev": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(PfParams), _P, _P, _P]),
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),

@@ -14,6 +14,7 @@
 #include "track_kernels.hip.h"
 #include "pf_kernels.hip.h"
 #include "dwa_kernels.hip.h"
+#include "frenet_kernels.hip.h"
 
 namespace {
 
@@ -765,3 +766,147 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
 
 }  // extern "C"
 
+
+// ---------------------------------------------------------------------------------------------
+// Frenet optimal-trajectory planner
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// host mirror of cubic_spline.h's Spline: coefficients of one coordinate over the knots s (cubic_spline.h:54-66,:91-116)
+void spline1d_build(const float* x, const float* y, int nx, float* a, float* b, float* c, float* d) {
+  std::vector<float> h(nx - 1);
+  for (int i = 1; i < nx; ++i) h[i - 1] = x[i] - x[i - 1];
+  for (int i = 0; i < nx; ++i) a[i] = y[i];
+  // rows 0 and nx-1 are identity rows with zero right-hand sides (natural spline); the rest is tridiagonal
+  std::vector<double> lo(nx, 0.0), di(nx, 1.0), up(nx, 0.0), rhs(nx, 0.0);
+  for (int i = 0; i < nx - 2; ++i) {
+    lo[i + 1] = h[i];
+    di[i + 1] = (double)(2 * (h[i] + h[i + 1]));
+    up[i + 1] = h[i + 1];
+    rhs[i + 1] = (double)(float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
+  }
+  for (int i = 1; i < nx; ++i) {            // Thomas elimination (the matrix is diagonally dominant)
+    const double f = lo[i] / di[i - 1];
+    di[i] -= f * up[i - 1];
+    rhs[i] -= f * rhs[i - 1];
+  }
+  std::vector<double> sol(nx);
+  sol[nx - 1] = rhs[nx - 1] / di[nx - 1];
+  for (int i = nx - 2; i >= 0; --i) sol[i] = (rhs[i] - up[i] * sol[i + 1]) / di[i];
+  for (int i = 0; i < nx; ++i) c[i] = (float)sol[i];
+  for (int i = 0; i < nx - 1; ++i) {
+    d[i] = (float)((c[i + 1] - c[i]) / (3.0 * h[i]));
+    b[i] = (float)((a[i + 1] - a[i]) / h[i] - h[i] * (c[i + 1] + 2 * c[i]) / 3.0);
+  }
+  b[nx - 1] = 0.0f; d[nx - 1] = 0.0f;
+}
+
+int host_bisect(const float* x, float t, int start, int end) {   // cubic_spline.h:118-128
+  for (;;) {
+    const int mid = (start + end) / 2;
+    if (t == x[mid] || end - start <= 1) return mid;
+    if (t > x[mid]) start = mid; else end = mid;
+  }
+}
+
+struct FrenetGrid { int ndi, nTi, ntv, ntt, min_nt; };
+FrenetGrid frenet_grid(const crx_frenet_config& g) {   // the loop trip counts of :55-56,:58,:66-68
+  FrenetGrid r{0, 0, 0, 0, 1 << 30};
+  const int cap = 1 << 16;
+  for (float di = (float)(-1 * g.max_road_width); di < g.max_road_width && r.ndi < cap; di += g.d_road_w) ++r.ndi;
+  float Tmax = 0.0f;
+  std::vector<float> Tis;
+  for (float Ti = (float)g.mint; Ti < g.maxt && r.nTi < cap; Ti += g.dt) { ++r.nTi; Tmax = Ti; Tis.push_back(Ti); }
+  for (float tv = (float)(g.target_speed - g.d_t_s * g.n_s_sample); tv < g.target_speed + g.d_t_s * g.n_s_sample && r.ntv < cap; tv += g.d_t_s) ++r.ntv;
+  std::vector<float> ts;
+  for (float t = 0; t < Tmax && r.ntt < cap; t += g.dt) { ++r.ntt; ts.push_back(t); }
+  for (float Ti : Tis) { int c = 0; while (c < r.ntt && ts[c] < Ti) ++c; if (c < r.min_nt) r.min_nt = c; }
+  return r;
+}
+int frenet_check_cfg(const crx_frenet_config& q, FrenetGrid* out) {
+  if (!(q.dt > 0.0) || !(q.d_road_w > 0.0) || !(q.d_t_s > 0.0))
+    return fail(CRX_ERR_INVALID, "frenet: dt, d_road_w and d_t_s must be positive");
+  const FrenetGrid gr = frenet_grid(q);
+  if (gr.ndi < 1 || gr.nTi < 1 || gr.ntv < 1) return fail(CRX_ERR_INVALID, "frenet: the configuration generates no candidate path");
+  if (gr.ndi > crx::kFrMaxDi || gr.nTi > crx::kFrMaxTi || gr.ntv > crx::kFrMaxTv || gr.ntt > crx::kFrMaxT ||
+      gr.ndi * gr.nTi * gr.ntv > crx::kFrMaxPaths)
+    return fail(CRX_ERR_INVALID, "frenet: sample grid too large (<= 64 offsets, 32 horizons, 16 speeds, 128 time steps)");
+  if (gr.min_nt < 2) return fail(CRX_ERR_INVALID, "frenet: every horizon needs at least two time steps (mint > dt)");
+  if (out) *out = gr;
+  return CRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void crx_frenet_default_config(crx_frenet_config* c) {
+  if (!c) return;
+  c->max_speed = 50.0 / 3.6; c->max_accel = 2.0; c->max_curvature = 1.0; c->max_road_width = 7.0; c->d_road_w = 1.0;
+  c->dt = 0.2; c->maxt = 5.0; c->mint = 4.0; c->target_speed = 30.0 / 3.6; c->d_t_s = 5.0 / 3.6; c->n_s_sample = 1; c->single_d_push = 0;
+  c->robot_radius = 1.5; c->kj = 0.1; c->kt = 0.1; c->kd = 1.0; c->klat = 1.0; c->klon = 1.0;
+}
+
+int crx_frenet_num_paths(const crx_frenet_config* cfg) {
+  crx_frenet_config q;
+  if (cfg) q = *cfg; else crx_frenet_default_config(&q);
+  FrenetGrid gr;
+  if (int rc = frenet_check_cfg(q, &gr)) return rc;
+  return gr.ndi * gr.nTi * gr.ntv;
+}
+
+int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef) {
+  if (!wx || !wy || !coef || nx < 2 || nx > crx::kFrMaxKnots) return fail(CRX_ERR_INVALID, "frenet_spline_build: bad argument (2 <= nx <= 128)");
+  float* s = coef;
+  s[0] = 0.0f;                                   // Spline2D::calc_s :172-186
+  float temp = 0;
+  for (int i = 1; i < nx; ++i) {
+    const float dx = wx[i] - wx[i - 1], dy = wy[i] - wy[i - 1];
+    temp += std::sqrt(dx * dx + dy * dy);
+    s[i] = temp;
+    if (!(s[i] > s[i - 1])) return fail(CRX_ERR_INVALID, "frenet_spline_build: consecutive way-points must be distinct");
+  }
+  spline1d_build(s, wx, nx, coef + nx, coef + 2 * nx, coef + 3 * nx, coef + 4 * nx);
+  spline1d_build(s, wy, nx, coef + 5 * nx, coef + 6 * nx, coef + 7 * nx, coef + 8 * nx);
+  return CRX_OK;
+}
+
+int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap) {
+  if (!coef || nx < 2 || cap < 0 || (cap && (!rx || !ry))) return fail(CRX_ERR_INVALID, "frenet_course_samples: bad argument");
+  const float* s = coef;
+  int k = 0;
+  for (float i = 0; i < s[nx - 1]; i += 0.1) {   // main :205-213
+    if (k < cap) {
+      const int seg = host_bisect(s, i, 0, nx);
+      const float dx = i - s[seg];
+      rx[k] = coef[nx + seg] + coef[2 * nx + seg] * dx + coef[3 * nx + seg] * dx * dx + coef[4 * nx + seg] * dx * dx * dx;
+      ry[k] = coef[5 * nx + seg] + coef[6 * nx + seg] * dx + coef[7 * nx + seg] * dx * dx + coef[8 * nx + seg] * dx * dx * dx;
+    }
+    ++k;
+  }
+  return k;
+}
+
+int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
+                             const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
+                             int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,
+                             void* stream) {
+  if (n < 0 || max_ticks < 0 || nob < 0 || nob > crx::kFrMaxOb || (nob && !ob) || nx < 2 || nx > crx::kFrMaxKnots || !coef ||
+      !goal_xy || path_cap < 0 || (n && !state))
+    return fail(CRX_ERR_INVALID, "frenet_run: bad argument (2 <= nx <= 128, nob <= 256)");
+  crx_frenet_config q;
+  if (cfg) q = *cfg; else crx_frenet_default_config(&q);
+  if (int rc = frenet_check_cfg(q, nullptr)) return rc;
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx::FrenetCfg c;
+  static_assert(sizeof(c) == sizeof(q), "config layouts must agree");
+  std::memcpy(&c, &q, sizeof(c));
+  hipLaunchKernelGGL(crx::frenet_run_kernel, dim3(blocks_for(n, crx::kFrWavesPerBlock)), dim3(64 * crx::kFrWavesPerBlock), 0,
+                     (hipStream_t)stream, n, max_ticks, state, coef, nx, goal_xy[0], goal_xy[1], ob, nob, c, hist, ticks_done,
+                     status, best_idx, n_valid, path_cf, path_ok, path_cap);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,269 @@
+// frenet_kernels.hip.h — batched Frenet optimal-trajectory planner for gfx950: ONE AGENT PER WAVEFRONT, the candidate
+// paths of one planning call (14 lateral offsets x 5 horizons x 2 target speeds = 140 with the reference's constants)
+// spread over the 64 lanes.  Each lane builds its path's lateral quintic and longitudinal quartic, walks the time steps
+// once — polynomial samples, jerk sums, speed/acceleration maxima, the course spline lookup, the global point, the
+// heading/curvature sliding window and the obstacle test all in registers — and a wave-wide (cost, index) reduction picks
+// the reference's winner (the LAST path in generation order attaining the minimum cost among the survivors).  All ticks
+// of an episode are fused: plan -> hand the winner's second sample over as the new state -> goal test.
+//
+// Replaces, for n independent agents sharing one course and one obstacle set,
+// /root/reference/src/frenet_optimal_trajectory.cpp: calc_frenet_paths :52-106, calc_global_paths :108-142,
+// check_collision :144-154, check_paths :156-164, frenet_optimal_planning :166-182, main loop :224-236; with
+// /root/reference/include/quintic_polynomial.h:34-62, quartic_polynomial.h:33-60 and the Spline evaluation of
+// cubic_spline.h:68-84,:118-128 (the spline coefficients are built once per course on the host, crx_frenet_spline_build).
+//
+// Arithmetic contract (tolerance parity, 1e-5 — see DESIGN.md §5e): every expression keeps the reference's C++ types
+// (float members, double macros, std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in
+// float).  Differences from the CPU oracle are confined to (a) pow(t,k) formed by exact-operand double products instead
+// of libm pow and (b) the double sin/cos (<= 1 ulp) — each can move a float result by one ulp only when the double lands
+// within 2^-29 of a rounding boundary.  The 3x3 / 2x2 coefficient solves are the oracle's cofactor expression, in double.
+// Reference quirks that decide the numbers are kept (the doubled fp.d push, the missing factor 5 in the quintic's first
+// derivative, maxima starting at FLT_MIN; FrenetCfg::single_d_push = 1 — off by default, not the reference — pushes
+// once); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
+// throw (s before the course) the path is dropped and status bit 2 is set.
+//
+// State per agent: (s0, c_speed, c_d, c_d_d, c_d_dd).  History row: (s0, c_speed, c_d, c_d_d, c_d_dd, x, y, cf).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "crx_fdlibm.h"
+#include "mpc_kernels.hip.h"   // mpc_sincos (double)
+
+namespace crx {
+
+struct FrenetCfg {   // the #defines :20-38, as the double expressions they expand to
+  double max_speed, max_accel, max_curvature, max_road_width, d_road_w, dt, maxt, mint, target_speed, d_t_s;
+  int n_s_sample, single_d_push;
+  double robot_radius, kj, kt, kd, klat, klon;
+};
+
+constexpr int kFrWavesPerBlock = 4;
+constexpr int kFrMaxDi = 64, kFrMaxTi = 32, kFrMaxTv = 16, kFrMaxT = 128, kFrMaxKnots = 128, kFrMaxOb = 256;
+constexpr int kFrMaxPaths = 4096;
+
+struct FrQuintic { float a0, a1, a2, a3, a4, a5; };
+struct FrQuartic { float a0, a1, a2, a3, a4; };
+
+__device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, float xe, float vxe, float axe, float T) {
+  FrQuintic q;
+  q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
+  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td, T4 = T2 * T2, T5 = T4 * Td;
+  const double a00 = (double)(float)T3, a01 = (double)(float)T4, a02 = (double)(float)T5;
+  const double a10 = (double)(float)(3.0 * T2), a11 = (double)(float)(4.0 * T3), a12 = (double)(float)(5.0 * T4);
+  const double a20 = (double)(6.0f * T), a21 = (double)(float)(12.0 * T2), a22 = (double)(float)(20.0 * T3);
+  const double b0 = (double)(float)((double)(xe - q.a0 - q.a1 * T) - (double)q.a2 * T2);
+  const double b1 = (double)(vxe - q.a1 - 2.0f * q.a2 * T);
+  const double b2 = (double)(axe - 2.0f * q.a2);
+  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+  const double c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
+  const double c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
+  const double det = (a00 * c00 + a01 * c01) + a02 * c02;
+  q.a3 = (float)(((c00 * b0 + c10 * b1) + c20 * b2) / det);
+  q.a4 = (float)(((c01 * b0 + c11 * b1) + c21 * b2) / det);
+  q.a5 = (float)(((c02 * b0 + c12 * b1) + c22 * b2) / det);
+  return q;
+}
+__device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, float vxe, float axe, float T) {
+  FrQuartic q;
+  q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
+  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td;
+  const double a00 = (double)(float)(3.0 * T2), a01 = (double)(float)(4.0 * T3), a10 = (double)(6.0f * T), a11 = (double)(float)(12.0 * T2);
+  const double b0 = (double)(vxe - q.a1 - 2.0f * q.a2 * T), b1 = (double)(axe - 2.0f * q.a2);
+  const double det = a00 * a11 - a01 * a10;
+  q.a3 = (float)((a11 * b0 - a01 * b1) / det);
+  q.a4 = (float)((a00 * b1 - a10 * b0) / det);
+  return q;
+}
+// the evaluation expressions of quintic_polynomial.h:44-62 / quartic_polynomial.h:44-60: float until the first pow, double after
+__device__ __forceinline__ float fr_q5_point(const FrQuintic& q, float t) {
+  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2, t5 = t4 * td;
+  return (float)(((((double)(q.a0 + q.a1 * t) + (double)q.a2 * t2) + (double)q.a3 * t3) + (double)q.a4 * t4) + (double)q.a5 * t5);
+}
+__device__ __forceinline__ float fr_q5_d1(const FrQuintic& q, float t) {
+  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2;
+  return (float)((((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * t2) + (double)(4.0f * q.a4) * t3) + (double)q.a5 * t4);
+}
+__device__ __forceinline__ float fr_q5_d2(const FrQuintic& q, float t) {
+  const double td = t, t2 = td * td, t3 = t2 * td;
+  return (float)(((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * t2) + (double)(20.0f * q.a5) * t3);
+}
+__device__ __forceinline__ float fr_q5_d3(const FrQuintic& q, float t) {
+  const double td = t, t2 = td * td;
+  return (float)((double)(6.0f * q.a3 + 24.0f * q.a4 * t) + (double)(60.0f * q.a5) * t2);
+}
+__device__ __forceinline__ float fr_q4_point(const FrQuartic& q, float t) {
+  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2;
+  return (float)((((double)(q.a0 + q.a1 * t) + (double)q.a2 * t2) + (double)q.a3 * t3) + (double)q.a4 * t4);
+}
+__device__ __forceinline__ float fr_q4_d1(const FrQuartic& q, float t) {
+  const double td = t, t2 = td * td, t3 = t2 * td;
+  return (float)(((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * t2) + (double)(4.0f * q.a4) * t3);
+}
+__device__ __forceinline__ float fr_q4_d2(const FrQuartic& q, float t) {
+  const double td = t, t2 = td * td;
+  return (float)((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * t2);
+}
+__device__ __forceinline__ float fr_q4_d3(const FrQuartic& q, float t) { return 6.0f * q.a3 + 24.0f * q.a4 * t; }
+
+// Spline::bisect, cubic_spline.h:118-128, iteratively
+__device__ __forceinline__ int fr_bisect(const float* __restrict__ x, float t, int start, int end) {
+  for (;;) {
+    const int mid = (start + end) / 2;
+    const float xm = x[mid];
+    if (t == xm || end - start <= 1) return mid;
+    if (t > xm) start = mid; else end = mid;
+  }
+}
+
+__global__ void __launch_bounds__(64 * kFrWavesPerBlock)
+frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* __restrict__ coef, int nx, float goal_x, float goal_y,
+                  const float* __restrict__ ob, int nob, FrenetCfg g, float* __restrict__ hist, int* __restrict__ ticks_done,
+                  int* __restrict__ status, int* __restrict__ best_idx, int* __restrict__ n_valid, float* __restrict__ path_cf,
+                  int* __restrict__ path_ok, int path_cap) {
+  __shared__ float s_coef[9 * kFrMaxKnots];      // rows s, ax,bx,cx,dx, ay,by,cy,dy
+  __shared__ float s_ob[2 * kFrMaxOb];
+  __shared__ float s_di[kFrMaxDi], s_Ti[kFrMaxTi], s_tv[kFrMaxTv], s_t[kFrMaxT];
+  __shared__ int s_nt[kFrMaxTi], s_cnt[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 9 * nx; i += blockDim.x) s_coef[i] = coef[i];
+  for (int i = threadIdx.x; i < 2 * nob; i += blockDim.x) s_ob[i] = ob[i];
+  if (threadIdx.x == 0) {     // the sample grids, by the reference's own float accumulation (:55-56,:58,:66-68); caps checked by the host
+    int ndi = 0, nTi = 0, ntv = 0, ntt = 0;
+    for (float di = (float)(-1 * g.max_road_width); di < g.max_road_width && ndi < kFrMaxDi; di += g.d_road_w) s_di[ndi++] = di;
+    for (float Ti = (float)g.mint; Ti < g.maxt && nTi < kFrMaxTi; Ti += g.dt) s_Ti[nTi++] = Ti;
+    for (float tv = (float)(g.target_speed - g.d_t_s * g.n_s_sample); tv < g.target_speed + g.d_t_s * g.n_s_sample && ntv < kFrMaxTv; tv += g.d_t_s) s_tv[ntv++] = tv;
+    const float Tmax = nTi ? s_Ti[nTi - 1] : 0.0f;
+    for (float t = 0; t < Tmax && ntt < kFrMaxT; t += g.dt) s_t[ntt++] = t;
+    for (int k = 0; k < nTi; ++k) { int c = 0; while (c < ntt && s_t[c] < s_Ti[k]) ++c; s_nt[k] = c; }
+    s_cnt[0] = ndi; s_cnt[1] = nTi; s_cnt[2] = ntv; s_cnt[3] = ntt;
+  }
+  __syncthreads();
+  const size_t a = (size_t)blockIdx.x * kFrWavesPerBlock + wv;
+  if (a >= (size_t)n) return;     // whole waves only: no block barrier below
+  const int nTi = s_cnt[1], ntv = s_cnt[2];
+  const int P = s_cnt[0] * nTi * ntv;
+  const float* sk = s_coef;
+  const float *cax = s_coef + nx, *cbx = s_coef + 2 * nx, *ccx = s_coef + 3 * nx, *cdx = s_coef + 4 * nx;
+  const float *cay = s_coef + 5 * nx, *cby = s_coef + 6 * nx, *ccy = s_coef + 7 * nx, *cdy = s_coef + 8 * nx;
+  const float s_front = sk[0], s_back = sk[nx - 1];
+  const double r2 = g.robot_radius * g.robot_radius;
+  const double half_pi = 3.14159265358979323846 / 2.0;    // M_PI/2.0
+  float s0 = state[5 * a], c_speed = state[5 * a + 1], c_d = state[5 * a + 2], c_d_d = state[5 * a + 3], c_d_dd = state[5 * a + 4];
+  int st = 0, ticks = 0, last_best = -1, last_valid = 0;
+  for (int tick = 0; tick < max_ticks; ++tick) {
+    float my_cost = FLT_MAX;          // min_cost :173
+    int my_idx = -1, my_valid = 0;
+    float w_s1 = 0, w_sd1 = 0, w_d1 = 0, w_dd1 = 0, w_ddd1 = 0, w_x1 = 0, w_y1 = 0;
+    for (int p = lane; p < P; p += 64) {
+      const int itv = p % ntv, pq = p / ntv, iTi = pq % nTi, idi = pq / nTi;
+      const float di = s_di[idi], Ti = s_Ti[iTi], tv = s_tv[itv];
+      const int nt = s_nt[iTi];
+      const FrQuintic lat = fr_quintic(c_d, c_d_d, c_d_dd, di, 0.0f, 0.0f, Ti);     // :57
+      const FrQuartic lon = fr_quartic(s0, c_speed, 0.0f, tv, 0.0f, Ti);            // :70
+      float max_speed = FLT_MIN, max_accel = FLT_MIN, max_curv = FLT_MIN, Jp = 0.0f, Js = 0.0f;
+      float s1 = 0, sd1 = 0, d1 = 0, dd1 = 0, ddd1 = 0, x1 = 0, y1 = 0, sd_last = 0, d_last = 0;
+      float px = 0, py = 0, pyaw = 0, pds = 0;       // previous global point, previous segment's heading and length
+      int m = 0;                                     // global points so far
+      bool walking = true, dropped = false, collide = false;
+      for (int i = 0; i < nt; ++i) {
+        const float t = s_t[i];
+        // longitudinal samples :74-85
+        const float s_i = fr_q4_point(lon, t), sd_i = fr_q4_d1(lon, t), sdd_i = fr_q4_d2(lon, t), sddd_i = fr_q4_d3(lon, t);
+        if (sd_i > max_speed) max_speed = sd_i;
+        if (sdd_i > max_accel) max_accel = sdd_i;
+        Js += sddd_i * sddd_i;
+        sd_last = sd_i;
+        // lateral samples :59-65; fp.d holds every sample twice, so entry i is the sample at t[i/2]
+        const float dddd_i = fr_q5_d3(lat, t);
+        Jp += dddd_i * dddd_i;
+        const float d_i = fr_q5_point(lat, s_t[g.single_d_push ? i : (i >> 1)]);
+        if (i == 1) { s1 = s_i; sd1 = sd_i; d1 = d_i; dd1 = fr_q5_d1(lat, t); ddd1 = fr_q5_d2(lat, t); }
+        if (i == nt - 1) d_last = fr_q5_point(lat, t);
+        // calc_global_paths :110-122
+        if (walking) {
+          if (s_i >= s_back) { walking = false; }
+          else if (s_i < s_front) { walking = false; dropped = true; st |= 4; }
+          else {
+            const int seg = fr_bisect(sk, s_i, 0, nx), segd = fr_bisect(sk, s_i, 0, nx - 1);
+            const float dx = s_i - sk[seg], dxd = s_i - sk[segd];
+            const float posx = cax[seg] + cbx[seg] * dx + ccx[seg] * dx * dx + cdx[seg] * dx * dx * dx;
+            const float posy = cay[seg] + cby[seg] * dx + ccy[seg] * dx * dx + cdy[seg] * dx * dx * dx;
+            const float ddx = cbx[segd] + 2.0f * ccx[segd] * dxd + 3.0f * cdx[segd] * dxd * dxd;
+            const float ddy = cby[segd] + 2.0f * ccy[segd] * dxd + 3.0f * cdy[segd] * dxd * dxd;
+            const float iyaw = atan2f_(ddy, ddx);
+            double sn, cs;
+            mpc_sincos((double)iyaw + half_pi, &sn, &cs);
+            const float x = (float)((double)posx + (double)d_i * cs);
+            const float y = (float)((double)posy + (double)d_i * sn);
+            if (i == 1) { x1 = x; y1 = y; }
+            // check_collision :144-154
+            for (int k = 0; k < nob; ++k) {
+              const double ex = (double)(x - s_ob[2 * k]), ey = (double)(y - s_ob[2 * k + 1]);
+              const float dist = (float)(ex * ex + ey * ey);
+              collide |= ((double)dist <= r2);
+            }
+            // headings, segment lengths, curvature :124-141, as a sliding window
+            if (m >= 1) {
+              const float gx = x - px, gy = y - py;
+              const float yaw = atan2f_(gy, gx), ds = sqrtf(gx * gx + gy * gy);
+              if (m >= 2) { const float c = (yaw - pyaw) / pds; if (c > max_curv) max_curv = c; }
+              pyaw = yaw; pds = ds;
+            }
+            px = x; py = y; ++m;
+          }
+        }
+      }
+      if (m >= 2) { const float c = (pyaw - pyaw) / pds; if (c > max_curv) max_curv = c; }   // the appended copy of the last heading :129-130
+      else dropped = true;
+      const float dsp = (float)(g.target_speed - (double)sd_last);                               // :89
+      const float cd = (float)((g.kj * (double)Jp + g.kt * (double)Ti) + g.kd * ((double)d_last * (double)d_last));
+      const float cv = (float)((g.kj * (double)Js + g.kt * (double)Ti) + g.kd * (double)dsp);
+      const float cf = (float)(g.klat * (double)cd + g.klon * (double)cv);
+      const bool ok = !dropped && (double)max_speed < g.max_speed && (double)max_accel < g.max_accel &&
+                      (double)max_curv < g.max_curvature && !collide;                            // :159
+      if (path_cf && p < path_cap) path_cf[a * path_cap + p] = cf;
+      if (path_ok && p < path_cap) path_ok[a * path_cap + p] = ok ? 1 : 0;
+      if (ok) {
+        ++my_valid;
+        if (my_cost >= cf) {                                                                     // :176 (within a lane the paths come in generation order)
+          my_cost = cf; my_idx = p;
+          w_s1 = s1; w_sd1 = sd1; w_d1 = d1; w_dd1 = dd1; w_ddd1 = ddd1; w_x1 = x1; w_y1 = y1;
+        }
+      }
+    }
+    // the last path in generation order attaining the minimum: (cost, -index) lexicographic minimum across the wave
+    float bc = my_cost;
+    int bi = my_idx, nv = my_valid;
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const float oc = __shfl_xor(bc, msk, 64);
+      const int oi = __shfl_xor(bi, msk, 64);
+      nv += __shfl_xor(nv, msk, 64);
+      if (oi >= 0 && (bi < 0 || oc < bc || (oc == bc && oi > bi))) { bc = oc; bi = oi; }
+    }
+    st |= __shfl_xor(st, 32, 64); st |= __shfl_xor(st, 16, 64); st |= __shfl_xor(st, 8, 64);
+    st |= __shfl_xor(st, 4, 64); st |= __shfl_xor(st, 2, 64); st |= __shfl_xor(st, 1, 64);
+    last_best = bi; last_valid = nv;
+    if (bi < 0) { st |= 1; break; }                  // no surviving path: the reference indexes an empty final_path
+    const int wl = bi & 63;                          // path p was evaluated by lane p % 64
+    s0 = __shfl(w_s1, wl, 64); c_speed = __shfl(w_sd1, wl, 64); c_d = __shfl(w_d1, wl, 64);
+    c_d_d = __shfl(w_dd1, wl, 64); c_d_dd = __shfl(w_ddd1, wl, 64);
+    const float fx = __shfl(w_x1, wl, 64), fy = __shfl(w_y1, wl, 64);
+    ticks = tick + 1;
+    if (hist && lane == 0) {
+      float* h = hist + ((size_t)tick * n + a) * 8;
+      h[0] = s0; h[1] = c_speed; h[2] = c_d; h[3] = c_d_d; h[4] = c_d_dd; h[5] = fx; h[6] = fy; h[7] = bc;
+    }
+    const double ex = (double)(fx - goal_x), ey = (double)(fy - goal_y);
+    if (ex * ex + ey * ey <= 1.0) break;             // :232
+  }
+  if (lane == 0) {
+    state[5 * a] = s0; state[5 * a + 1] = c_speed; state[5 * a + 2] = c_d; state[5 * a + 3] = c_d_d; state[5 * a + 4] = c_d_dd;
+    if (ticks_done) ticks_done[a] = ticks;
+    if (status) status[a] = st;
+    if (best_idx) best_idx[a] = last_best;
+    if (n_valid) n_valid[a] = last_valid;
+  }
+}
+
+}  // namespace crx

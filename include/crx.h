@@ -279,6 +279,42 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
                           const crx_dwa_config* cfg, float* traj_hist, int* ticks_done, int* status, int* best_idx,
                           int* n_samples, void* stream);
 
+/* ---- Frenet optimal-trajectory planner (src/frenet_optimal_trajectory.cpp) --------------------------
+ * The reference's main loop (:224-236) for n agents sharing one course and one obstacle set, ONE AGENT PER WAVEFRONT: per
+ * tick frenet_optimal_planning (calc_frenet_paths :52-106 -> calc_global_paths :108-142 -> check_paths :156-164 -> the
+ * cheapest survivor :173-180), the winner's second sample handed over as the new state, the goal test (:232).
+ * max_ticks = 1 is a single planning call.  Tolerance parity (1e-5), see DESIGN.md 5e.
+ *   coef  [9][nx]   the course's Spline2D (include/cubic_spline.h:130-187) as a coefficient table: rows s, then a,b,c,d of
+ *                   sx, then a,b,c,d of sy (b and d have nx-1 entries, the last column is padding); device pointer for
+ *                   the _dev call; built on the host by crx_frenet_spline_build (2 <= nx <= 128)
+ *   state [n][5]    (s0, c_speed, c_d, c_d_d, c_d_dd) in/out          ob [nob][2] shared, nob <= 256
+ *   goal            r_x.back(), r_y.back() of main :205-213, see crx_frenet_course_samples
+ *   hist            (may be NULL) [max_ticks][n][8] = (s0, c_speed, c_d, c_d_d, c_d_dd, x, y, cf) after each tick
+ *   status          bit 0: no candidate survived check_paths (the reference would index an empty path) — the episode ends
+ *                   with the state unchanged; bit 2: a candidate started before the course (Spline::calc would throw)
+ *   best_idx / n_valid  winner (generation order: di outer, Ti, tv inner) and survivor count of the LAST executed tick
+ *   path_cf / path_ok   (may be NULL) [n][path_cap] every candidate's cost and check_paths verdict in the last tick */
+typedef struct crx_frenet_config {   /* the #defines :20-38, as the double expressions they expand to */
+  double max_speed, max_accel, max_curvature, max_road_width, d_road_w, dt, maxt, mint, target_speed, d_t_s;
+  int n_s_sample, single_d_push;
+  double robot_radius, kj, kt, kd, klat, klon;
+} crx_frenet_config;
+/* single_d_push: 0 (default) = the reference, whose calc_frenet_paths pushes fp.d twice per time step (:60-61) so that d[i]
+ * is the lateral offset at t[i/2] and main's c_d = d[1] never moves; 1 = one push per step (d[i] at t[i]).  With 0 the
+ * reference's own scenario runs out of collision-free candidates after 48 ticks (status bit 0). */
+void crx_frenet_default_config(crx_frenet_config* c);
+/* number of candidate paths the configuration generates, or a negative crx error if it exceeds the kernel's grids */
+int crx_frenet_num_paths(const crx_frenet_config* cfg);
+/* host: Spline2D(wx, wy) -> coef[9][nx].  The nx-by-nx float system the reference hands to colPivHouseholderQr is solved
+ * in double (tridiagonal elimination) and rounded to float. */
+int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef);
+/* host: the course sampled as main :205-213 does (float i += 0.1); returns the sample count, fills up to cap of them */
+int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap);
+int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
+                             const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
+                             int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,7 +17,7 @@ _F = C.c_float
 
 def build(force=False):
     """g++ -O2 -ffp-contract=off (oracle/Makefile).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "dwa_ref.cpp", "eigen_order.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "dwa_ref.cpp", "frenet_ref.cpp", "eigen_order.h", "Makefile")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -385,3 +385,68 @@ def dwa_run(state, u, goal, max_ticks, ob=DWA_OBSTACLES, cfg=DWA_CONFIG, want_hi
     _dwa_lib().oracle_dwa_run(_I(n), _I(max_ticks), _p(state), _p(u), _p(goal), _p(ob), _I(ob.shape[0]), _p(cfg), _p(hist), _p(ticks),
                               _I(a0), _I(a1))
     return state, u, ticks, hist
+
+
+# ---- Frenet optimal trajectory (oracle/frenet_ref.cpp) -----------------------------------------------------
+class FrenetCfg(C.Structure):
+    _fields_ = ([(k, C.c_double) for k in ("max_speed", "max_accel", "max_curvature", "max_road_width", "d_road_w", "dt", "maxt",
+                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int), ("single_d_push", C.c_int)] +
+                [(k, C.c_double) for k in ("robot_radius", "kj", "kt", "kd", "klat", "klon")])
+
+
+def frenet_config(**kw):
+    """The #defines of src/frenet_optimal_trajectory.cpp:20-38."""
+    c = FrenetCfg(50.0 / 3.6, 2.0, 1.0, 7.0, 1.0, 0.2, 5.0, 4.0, 30.0 / 3.6, 5.0 / 3.6, 1, 0, 1.5, 0.1, 0.1, 1.0, 1.0, 1.0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+FRENET_WX = np.array([0.0, 10.0, 20.5, 35.0, 70.5], np.float32)     # main :186-187
+FRENET_WY = np.array([0.0, -6.0, 5.0, 6.5, 0.0], np.float32)
+FRENET_OBSTACLES = np.array([[20.0, 10.0], [30.0, 6.0], [30.0, 8.0], [35.0, 8.0], [50.0, 3.0]], np.float32)   # :188-194
+FRENET_STATE0 = np.array([0.0, 10.0 / 3.6, 2.0, 0.0, 0.0], np.float32)   # (s0, c_speed, c_d, c_d_d, c_d_dd) :215-219
+
+
+def frenet_spline_build(wx=FRENET_WX, wy=FRENET_WY):
+    wx, wy = _f32(wx), _f32(wy)
+    coef = np.zeros((9, wx.shape[0]), np.float32)
+    lib().oracle_frenet_spline_build(_p(wx), _p(wy), _I(wx.shape[0]), _p(coef))
+    return coef
+
+
+def frenet_course_samples(coef):
+    coef = _f32(coef)
+    l = lib()
+    l.oracle_frenet_course_samples.restype = _I
+    k = l.oracle_frenet_course_samples(_p(coef), _I(coef.shape[1]), None, None, _I(0))
+    rx, ry = np.zeros(k, np.float32), np.zeros(k, np.float32)
+    l.oracle_frenet_course_samples(_p(coef), _I(coef.shape[1]), _p(rx), _p(ry), _I(k))
+    return rx, ry
+
+
+def frenet_plan(state, coef, ob=FRENET_OBSTACLES, cfg=None, path_cap=4096):
+    """One frenet_optimal_planning per agent.  -> dict(out [n,8] = (s1, s_d1, d1, d_d1, d_dd1, x1, y1, cf), best, n_valid,
+    n_paths, status, path_cf [n,P], path_ok [n,P])."""
+    state, coef, ob = _f32(state), _f32(coef), _f32(ob)
+    cfg = cfg if cfg is not None else frenet_config()
+    n = state.shape[0]
+    out = np.zeros((n, 8), np.float32)
+    best, nv, npth, st = (np.zeros(n, np.int32) for _ in range(4))
+    pcf, pok = np.zeros((n, path_cap), np.float32), np.zeros((n, path_cap), np.int32)
+    lib().oracle_frenet_plan(_I(n), _p(state), _p(coef), _I(coef.shape[1]), _p(ob), _I(ob.shape[0]), C.byref(cfg), _p(out), _p(best),
+                             _p(nv), _p(npth), _p(st), _p(pcf), _p(pok), _I(path_cap))
+    P = int(npth.max()) if n else 0
+    return dict(out=out, best=best, n_valid=nv, n_paths=npth, status=st, path_cf=pcf[:, :P], path_ok=pok[:, :P])
+
+
+def frenet_run(state, coef, goal, max_ticks, ob=FRENET_OBSTACLES, cfg=None, want_hist=False):
+    """main :224-236.  -> dict(state, ticks, status, best_idx, n_valid, hist [max_ticks,n,8] or None)."""
+    state, coef, ob, goal = _f32(state).copy(), _f32(coef), _f32(ob), _f32(goal)
+    cfg = cfg if cfg is not None else frenet_config()
+    n = state.shape[0]
+    ticks, st, best, nv = (np.zeros(n, np.int32) for _ in range(4))
+    hist = np.zeros((max_ticks, n, 8), np.float32) if want_hist else None
+    lib().oracle_frenet_run(_I(n), _I(max_ticks), _p(state), _p(coef), _I(coef.shape[1]), _p(goal), _p(ob), _I(ob.shape[0]), C.byref(cfg),
+                            _p(hist), _p(ticks), _p(st), _p(best), _p(nv))
+    return dict(state=state, ticks=ticks, status=st, best_idx=best, n_valid=nv, hist=hist)

@@ -39,9 +39,54 @@ def cpu_parallel(fn, n, cores):
     return time.perf_counter() - t0
 
 
+def bench_frenet(quick):
+    # ---- Frenet optimal-trajectory planner: one agent per wavefront, 168 candidate paths per planning call ----------
+    import ctypes as C
+    O = oracle.oracle_lib
+    n, max_ticks = 8192, 10
+    course = crx.FrenetCourse(O.FRENET_WX, O.FRENET_WY)
+    rng = np.random.default_rng(21)
+    fst = np.stack([rng.uniform(0.0, 55.0, n), rng.uniform(1.0, 9.0, n), rng.uniform(-3.0, 3.0, n), rng.uniform(-0.8, 0.8, n),
+                    rng.uniform(-0.5, 0.5, n)], axis=1).astype(np.float32)
+    fsd, fob = torch.from_numpy(fst).cuda(), torch.from_numpy(O.FRENET_OBSTACLES).cuda()
+    course.to(fsd.device)
+    r = crx.frenet_run(fsd.clone(), course, fob, max_ticks)
+    t_fr = gpu_time(lambda: crx.frenet_run(fsd.clone(), course, fob, max_ticks), 1 if quick else 3)
+    tk = r["ticks"].cpu().numpy().astype(np.int64)
+    P = crx.frenet_num_paths()
+    ns = 512
+    gomp = C.CDLL("libgomp.so.1")
+    gomp.omp_get_max_threads.restype = C.c_int
+    nthreads = gomp.omp_get_max_threads()
+    t1 = time.perf_counter()
+    ro = oracle.frenet_run(fst[:ns], course.coef, course.goal, max_ticks)
+    t_cpu = time.perf_counter() - t1
+    gomp.omp_set_num_threads(1)
+    t1 = time.perf_counter()
+    r1 = oracle.frenet_run(fst[:16], course.coef, course.goal, max_ticks)
+    single = float(r1["ticks"].sum()) / (time.perf_counter() - t1)
+    gomp.omp_set_num_threads(nthreads)
+    # parity on one planning call of the first ns agents: costs, verdicts, winners
+    po = oracle.frenet_plan(fst[:ns], course.coef)
+    pg = crx.frenet_optimal_planning(fsd[:ns].clone(), course, fob, want_paths=True)
+    cfg_, cfo = pg["path_cf"].cpu().numpy(), po["path_cf"]
+    print(json.dumps({
+        "workload": f"Frenet optimal-trajectory planner, {n} agents, {max_ticks} planning ticks, {P} candidate paths x ~25 time steps x {len(O.FRENET_OBSTACLES)} obstacles per call, one agent per wavefront",
+        "plans_per_s": float(tk.sum()) / t_fr, "candidate_paths_per_s": float(tk.sum()) * P / t_fr, "ms": t_fr * 1e3,
+        "mean_ticks": float(tk.mean()), "no_survivor_frac": float((r["status"].cpu().numpy() & 1).mean()),
+        "cpu_baseline": {"value": float(ro["ticks"].sum()) / t_cpu, "unit": "plans/s", "cores": nthreads, "kind": "port",
+                         "sample": f"first {ns} agents (OpenMP over agents)", "single_thread_value": single},
+        "parity": {"path_cost_bit_identical_frac": float((cfg_.view(np.uint32) == cfo.view(np.uint32)).mean()),
+                   "path_cost_max_rel_err": float(np.nanmax(np.abs(cfg_ - cfo) / np.maximum(np.abs(cfo), 1e-30))),
+                   "verdicts_identical_frac": float((pg["path_ok"].cpu().numpy() == po["path_ok"]).mean()),
+                   "winner_identical_frac": float((pg["best_idx"].cpu().numpy() == po["best"]).mean())}}))
+
+
 def main():
     cores = os.cpu_count() or 1
     quick = "--quick" in sys.argv
+    if "--frenet-only" in sys.argv:
+        return bench_frenet(quick)
     # ---- DARE + dlqr, 16,384 agents (configs[2]) ------------------------------------------------------
     n = 16384
     v = lqr_speeds(n, 3)
@@ -219,6 +264,8 @@ def main():
         "cpu_baseline": {"value": float(tk[:ns].sum()) / t_cpu, "unit": "agent-steps/s", "cores": min(cores, ns), "kind": "port",
                          "sample": f"first {ns} agents", "single_thread_value": single},
         "parity": {"first_32_agents_bit_identical": same}}))
+
+    bench_frenet(quick)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,84 @@
+"""The Frenet oracle (oracle/frenet_ref.cpp) on the reference's own scenario, the host-side spline builder of the product
+against the oracle's, and the C ABI's argument validation (no GPU needed: validation runs before the device check)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_sample_grid_and_first_plan(oracle_mod):
+    O = oracle_mod.oracle_lib
+    coef = oracle_mod.frenet_spline_build()
+    p = oracle_mod.frenet_plan(O.FRENET_STATE0[None, :], coef)
+    # 14 lateral offsets x 6 horizons (the float accumulation 4.0, 4.2, ... stops at 4.9999995 < 5.0) x 2 target speeds
+    assert p["n_paths"][0] == 14 * 6 * 2
+    assert 0 < p["n_valid"][0] < p["n_paths"][0] and p["status"][0] == 0
+    out = p["out"][0]
+    assert out[2] == np.float32(2.0)                    # c_d = d[1] = the sample at t[0] (fp.d is pushed twice, :60-61)
+    assert 0.4 < out[0] < 0.7 and out[1] > O.FRENET_STATE0[1]     # moved ~0.56 m along the course, accelerating
+    best = p["best"][0]
+    ok = p["path_ok"][0].astype(bool)
+    cf = p["path_cf"][0]
+    assert ok[best] and cf[best] == cf[ok].min() and best == np.flatnonzero(ok & (cf == cf[ok].min())).max()
+
+
+def test_reference_scenario(oracle_mod):
+    O = oracle_mod.oracle_lib
+    coef = oracle_mod.frenet_spline_build()
+    rx, ry = oracle_mod.frenet_course_samples(coef)
+    assert len(rx) == 776 and abs(rx[-1] - 70.465) < 1e-2 and abs(ry[-1]) < 2e-2      # ~77.5 m of course every 0.1
+    goal = [rx[-1], ry[-1]]
+    # as written (fp.d pushed twice) the lateral state never moves and the episode dead-ends between the obstacles
+    r = oracle_mod.frenet_run(O.FRENET_STATE0[None, :], coef, goal, 500, want_hist=True)
+    assert r["status"][0] == 1 and r["n_valid"][0] == 0 and 30 < r["ticks"][0] < 80
+    assert (r["hist"][: r["ticks"][0], 0, 2] == np.float32(2.0)).all()
+    # with one push per step the planner threads the obstacles and reaches the goal
+    r = oracle_mod.frenet_run(O.FRENET_STATE0[None, :], coef, goal, 500, cfg=oracle_mod.frenet_config(single_d_push=1), want_hist=True)
+    t = r["ticks"][0]
+    assert r["status"][0] == 0 and 60 < t < 200
+    h = r["hist"][:t, 0]
+    assert np.hypot(h[-1, 5] - goal[0], h[-1, 6] - goal[1]) <= 1.0
+    d = np.sqrt(((h[:, None, 5:7] - O.FRENET_OBSTACLES[None]) ** 2).sum(axis=2))
+    assert d.min() > 1.5                                                              # never inside ROBOT_RADIUS
+    assert (np.diff(h[:, 0]) > 0).all() and h[:, 1].max() < 50.0 / 3.6
+
+
+def test_host_spline_builder_matches_oracle(oracle_mod):
+    import cpprobotics_amd as crx
+    rng = np.random.default_rng(5)
+    for nx in (2, 3, 5, 17, 128):
+        wx = np.cumsum(rng.uniform(2.0, 12.0, nx)).astype(np.float32)
+        wy = rng.uniform(-8.0, 8.0, nx).astype(np.float32)
+        a = crx.FrenetCourse(wx, wy)
+        b = oracle_mod.frenet_spline_build(wx, wy)
+        assert np.array_equal(a.coef[0], b[0])                                        # knots: identical float accumulation
+        scale = np.abs(b).max(axis=1, keepdims=True) + 1e-30
+        assert (np.abs(a.coef - b) / scale).max() < 2e-6                              # tridiagonal vs dense solve, both double
+        rx, ry = oracle_mod.frenet_course_samples(a.coef)
+        assert len(rx) == len(a.rx) and np.array_equal(rx, a.rx) and np.array_equal(ry, a.ry)
+        # natural spline: interpolates the way-points, zero curvature at both ends
+        assert np.array_equal(a.coef[1], wx) and np.array_equal(a.coef[5], wy)
+        assert abs(a.coef[3, 0]) < 1e-6 and abs(a.coef[3, -1]) < 1e-6
+
+
+def test_frenet_abi_validation():
+    import cpprobotics_amd as crx
+    from cpprobotics_amd import _lib as L
+    l = crx.lib()
+    assert crx.frenet_num_paths() == 168
+    c = crx.frenet_default_config()
+    assert abs(c.target_speed - 30.0 / 3.6) == 0 and c.n_s_sample == 1 and c.single_d_push == 0
+    c.dt = 0.0
+    assert l.crx_frenet_num_paths(C.byref(c)) < 0
+    c = crx.frenet_default_config(); c.d_road_w = 0.01                               # 1400 offsets: beyond the kernel's grid
+    assert l.crx_frenet_num_paths(C.byref(c)) < 0
+    c = crx.frenet_default_config(); c.mint = 0.1; c.maxt = 0.3                       # a horizon with a single time step
+    assert l.crx_frenet_num_paths(C.byref(c)) < 0
+    wx = np.array([0, 1, 1], np.float32); wy = np.array([0, 0, 0], np.float32)        # repeated way-point
+    coef = np.zeros((9, 3), np.float32)
+    assert l.crx_frenet_spline_build(wx.ctypes.data, wy.ctypes.data, 3, coef.ctypes.data) != 0
+    assert l.crx_frenet_spline_build(wx.ctypes.data, wy.ctypes.data, 1, coef.ctypes.data) != 0
+    goal = np.zeros(2, np.float32)
+    assert l.crx_frenet_run_batch_dev(4, 1, None, None, 5, goal.ctypes.data, None, 0, None, None, None, None, None, None, None, None, 0, None) != 0
+    with pytest.raises(crx.CrxError):
+        crx.FrenetCourse(wx, wy)

@@ -829,8 +829,10 @@ int frenet_check_cfg(const crx_frenet_config& q, FrenetGrid* out) {
   const FrenetGrid gr = frenet_grid(q);
   if (gr.ndi < 1 || gr.nTi < 1 || gr.ntv < 1) return fail(CRX_ERR_INVALID, "frenet: the configuration generates no candidate path");
   if (gr.ndi > crx::kFrMaxDi || gr.nTi > crx::kFrMaxTi || gr.ntv > crx::kFrMaxTv || gr.ntt > crx::kFrMaxT ||
-      gr.ndi * gr.nTi * gr.ntv > crx::kFrMaxPaths)
-    return fail(CRX_ERR_INVALID, "frenet: sample grid too large (<= 64 offsets, 32 horizons, 16 speeds, 128 time steps)");
+      gr.nTi * gr.ntv > crx::kFrMaxCombos || gr.ndi * gr.nTi * gr.ntv > crx::kFrMaxPaths ||
+      (size_t)gr.nTi * gr.ntv * gr.ntt * sizeof(crx::FrTab) > (size_t)crx::kFrTabLdsBytes)
+    return fail(CRX_ERR_INVALID, "frenet: sample grid too large (<= 64 offsets, horizons x speeds <= 64, <= 64 time steps, "
+                                 "horizons x speeds x time steps <= 2048)");
   if (gr.min_nt < 2) return fail(CRX_ERR_INVALID, "frenet: every horizon needs at least two time steps (mint > dt)");
   if (out) *out = gr;
   return CRX_OK;
@@ -856,7 +858,7 @@ int crx_frenet_num_paths(const crx_frenet_config* cfg) {
 }
 
 int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef) {
-  if (!wx || !wy || !coef || nx < 2 || nx > crx::kFrMaxKnots) return fail(CRX_ERR_INVALID, "frenet_spline_build: bad argument (2 <= nx <= 128)");
+  if (!wx || !wy || !coef || nx < 2 || nx > crx::kFrMaxKnots) return fail(CRX_ERR_INVALID, "frenet_spline_build: bad argument (2 <= nx <= 64)");
   float* s = coef;
   s[0] = 0.0f;                                   // Spline2D::calc_s :172-186
   float temp = 0;
@@ -893,18 +895,23 @@ int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* co
                              void* stream) {
   if (n < 0 || max_ticks < 0 || nob < 0 || nob > crx::kFrMaxOb || (nob && !ob) || nx < 2 || nx > crx::kFrMaxKnots || !coef ||
       !goal_xy || path_cap < 0 || (n && !state))
-    return fail(CRX_ERR_INVALID, "frenet_run: bad argument (2 <= nx <= 128, nob <= 256)");
+    return fail(CRX_ERR_INVALID, "frenet_run: bad argument (2 <= nx <= 64, nob <= 128)");
   crx_frenet_config q;
   if (cfg) q = *cfg; else crx_frenet_default_config(&q);
-  if (int rc = frenet_check_cfg(q, nullptr)) return rc;
+  FrenetGrid gr;
+  if (int rc = frenet_check_cfg(q, &gr)) return rc;
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx::FrenetCfg c;
   static_assert(sizeof(c) == sizeof(q), "config layouts must agree");
   std::memcpy(&c, &q, sizeof(c));
-  hipLaunchKernelGGL(crx::frenet_run_kernel, dim3(blocks_for(n, crx::kFrWavesPerBlock)), dim3(64 * crx::kFrWavesPerBlock), 0,
+  // the per-wave (combo, time step) table lives in dynamic LDS: as many waves per block as fit beside it
+  const int stride = gr.nTi * gr.ntv * gr.ntt;
+  int wpb = crx::kFrWavesPerBlock;
+  while (wpb > 1 && (size_t)wpb * stride * sizeof(crx::FrTab) > (size_t)crx::kFrTabLdsBytes) wpb >>= 1;
+  hipLaunchKernelGGL(crx::frenet_run_kernel, dim3(blocks_for(n, wpb)), dim3(64 * wpb), (size_t)wpb * stride * sizeof(crx::FrTab),
                      (hipStream_t)stream, n, max_ticks, state, coef, nx, goal_xy[0], goal_xy[1], ob, nob, c, hist, ticks_done,
-                     status, best_idx, n_valid, path_cf, path_ok, path_cap);
+                     status, best_idx, n_valid, path_cf, path_ok, path_cap, stride);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -1,9 +1,11 @@
 // frenet_kernels.hip.h — batched Frenet optimal-trajectory planner for gfx950: ONE AGENT PER WAVEFRONT, the candidate
-// paths of one planning call (14 lateral offsets x 5 horizons x 2 target speeds = 140 with the reference's constants)
-// spread over the 64 lanes.  Each lane builds its path's lateral quintic and longitudinal quartic, walks the time steps
-// once — polynomial samples, jerk sums, speed/acceleration maxima, the course spline lookup, the global point, the
-// heading/curvature sliding window and the obstacle test all in registers — and a wave-wide (cost, index) reduction picks
-// the reference's winner (the LAST path in generation order attaining the minimum cost among the survivors).  All ticks
+// paths of one planning call (14 lateral offsets x 6 horizons x 2 target speeds = 168 with the reference's constants:
+// the float accumulation 4.0, 4.2, ... of the horizon loop stops at 4.9999995 < MAXT) spread over the 64 lanes.
+// A planning call runs in three wave-synchronous phases (see frenet_run_kernel): what depends only on (horizon, target
+// speed) — the longitudinal quartic, its maxima and jerk sum, the course frame at every sample — is computed once per
+// call and parked in an LDS table; each lane then builds its candidate's lateral quintic and walks the table: global
+// point, heading/curvature sliding window and obstacle test in registers.  A wave-wide (cost, index) reduction picks the
+// reference's winner (the LAST candidate in generation order attaining the minimum cost among the survivors).  All ticks
 // of an episode are fused: plan -> hand the winner's second sample over as the new state -> goal test.
 //
 // Replaces, for n independent agents sharing one course and one obstacle set,
@@ -38,8 +40,8 @@ struct FrenetCfg {   // the #defines :20-38, as the double expressions they expa
 };
 
 constexpr int kFrWavesPerBlock = 4;
-constexpr int kFrMaxDi = 64, kFrMaxTi = 32, kFrMaxTv = 16, kFrMaxT = 128, kFrMaxKnots = 128, kFrMaxOb = 256;
-constexpr int kFrMaxPaths = 4096;
+constexpr int kFrMaxDi = 64, kFrMaxTi = 32, kFrMaxTv = 16, kFrMaxT = 64, kFrMaxKnots = 64, kFrMaxOb = 128;
+constexpr int kFrMaxPaths = 4096, kFrMaxCombos = 64, kFrTabLdsBytes = 48 * 1024;
 
 struct FrQuintic { float a0, a1, a2, a3, a4, a5; };
 struct FrQuartic { float a0, a1, a2, a3, a4; };
@@ -74,34 +76,33 @@ __device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, 
   q.a4 = (float)((a00 * b1 - a10 * b0) / det);
   return q;
 }
-// the evaluation expressions of quintic_polynomial.h:44-62 / quartic_polynomial.h:44-60: float until the first pow, double after
-__device__ __forceinline__ float fr_q5_point(const FrQuintic& q, float t) {
-  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2, t5 = t4 * td;
-  return (float)(((((double)(q.a0 + q.a1 * t) + (double)q.a2 * t2) + (double)q.a3 * t3) + (double)q.a4 * t4) + (double)q.a5 * t5);
-}
-__device__ __forceinline__ float fr_q5_d1(const FrQuintic& q, float t) {
-  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2;
-  return (float)((((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * t2) + (double)(4.0f * q.a4) * t3) + (double)q.a5 * t4);
-}
-__device__ __forceinline__ float fr_q5_d2(const FrQuintic& q, float t) {
-  const double td = t, t2 = td * td, t3 = t2 * td;
-  return (float)(((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * t2) + (double)(20.0f * q.a5) * t3);
-}
-__device__ __forceinline__ float fr_q5_d3(const FrQuintic& q, float t) {
+// the evaluation expressions of quintic_polynomial.h:44-62 / quartic_polynomial.h:44-60: float until the first pow, double
+// after.  The powers t^2..t^5 of the time grid are formed once per block (frenet_run_kernel) and read from LDS: FrPow.
+struct FrPow { double t2, t3, t4, t5; };
+__device__ __forceinline__ FrPow fr_pow(float t) {
   const double td = t, t2 = td * td;
-  return (float)((double)(6.0f * q.a3 + 24.0f * q.a4 * t) + (double)(60.0f * q.a5) * t2);
+  return FrPow{t2, t2 * td, t2 * t2, (t2 * t2) * td};
 }
-__device__ __forceinline__ float fr_q4_point(const FrQuartic& q, float t) {
-  const double td = t, t2 = td * td, t3 = t2 * td, t4 = t2 * t2;
-  return (float)((((double)(q.a0 + q.a1 * t) + (double)q.a2 * t2) + (double)q.a3 * t3) + (double)q.a4 * t4);
+__device__ __forceinline__ float fr_q5_point(const FrQuintic& q, float t, const FrPow& w) {
+  return (float)(((((double)(q.a0 + q.a1 * t) + (double)q.a2 * w.t2) + (double)q.a3 * w.t3) + (double)q.a4 * w.t4) + (double)q.a5 * w.t5);
 }
-__device__ __forceinline__ float fr_q4_d1(const FrQuartic& q, float t) {
-  const double td = t, t2 = td * td, t3 = t2 * td;
-  return (float)(((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * t2) + (double)(4.0f * q.a4) * t3);
+__device__ __forceinline__ float fr_q5_d1(const FrQuintic& q, float t, const FrPow& w) {
+  return (float)((((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * w.t2) + (double)(4.0f * q.a4) * w.t3) + (double)q.a5 * w.t4);
 }
-__device__ __forceinline__ float fr_q4_d2(const FrQuartic& q, float t) {
-  const double td = t, t2 = td * td;
-  return (float)((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * t2);
+__device__ __forceinline__ float fr_q5_d2(const FrQuintic& q, float t, const FrPow& w) {
+  return (float)(((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * w.t2) + (double)(20.0f * q.a5) * w.t3);
+}
+__device__ __forceinline__ float fr_q5_d3(const FrQuintic& q, float t, const FrPow& w) {
+  return (float)((double)(6.0f * q.a3 + 24.0f * q.a4 * t) + (double)(60.0f * q.a5) * w.t2);
+}
+__device__ __forceinline__ float fr_q4_point(const FrQuartic& q, float t, const FrPow& w) {
+  return (float)((((double)(q.a0 + q.a1 * t) + (double)q.a2 * w.t2) + (double)q.a3 * w.t3) + (double)q.a4 * w.t4);
+}
+__device__ __forceinline__ float fr_q4_d1(const FrQuartic& q, float t, const FrPow& w) {
+  return (float)(((double)(q.a1 + 2.0f * q.a2 * t) + (double)(3.0f * q.a3) * w.t2) + (double)(4.0f * q.a4) * w.t3);
+}
+__device__ __forceinline__ float fr_q4_d2(const FrQuartic& q, float t, const FrPow& w) {
+  return (float)((double)(2.0f * q.a2 + 6.0f * q.a3 * t) + (double)(12.0f * q.a4) * w.t2);
 }
 __device__ __forceinline__ float fr_q4_d3(const FrQuartic& q, float t) { return 6.0f * q.a3 + 24.0f * q.a4 * t; }
 
@@ -115,16 +116,31 @@ __device__ __forceinline__ int fr_bisect(const float* __restrict__ x, float t, i
   }
 }
 
+// What depends only on the (horizon, target speed) pair — 12 "longitudinal combos" with the reference's constants — is
+// computed once per planning call instead of once per candidate: phase A, one lane per combo: the quartic, its samples'
+// maxima and jerk sum, the hand-over samples and how many points lie on the course; phase B, one lane per (combo, time
+// step): the course position and the unit normal's (cos, sin) there (spline lookup, atan2f, double sincos), stored in an
+// LDS table; phase C, one lane per candidate: the lateral quintic and the walk along the table.
+struct FrTab { float px, py; double cs, sn; };   // poi[0], poi[1], cos(iyaw + pi/2), sin(iyaw + pi/2)   :115-119
+
+// Four waves per SIMD (128 VGPRs, a few spilled) beat the compiler's preferred two by 1.5x on the side bench: the kernel is
+// bound by per-wave instruction issue, so resident waves are what fills the VALU.
+#ifndef CRX_FR_WAVES
+#define CRX_FR_WAVES 4
+#endif
+__attribute__((amdgpu_waves_per_eu(CRX_FR_WAVES, CRX_FR_WAVES)))
 __global__ void __launch_bounds__(64 * kFrWavesPerBlock)
 frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* __restrict__ coef, int nx, float goal_x, float goal_y,
                   const float* __restrict__ ob, int nob, FrenetCfg g, float* __restrict__ hist, int* __restrict__ ticks_done,
                   int* __restrict__ status, int* __restrict__ best_idx, int* __restrict__ n_valid, float* __restrict__ path_cf,
-                  int* __restrict__ path_ok, int path_cap) {
+                  int* __restrict__ path_ok, int path_cap, int tab_stride) {
+  extern __shared__ FrTab s_tab_all[];           // [waves per block][tab_stride], tab_stride >= nTi * ntv * ntt
   __shared__ float s_coef[9 * kFrMaxKnots];      // rows s, ax,bx,cx,dx, ay,by,cy,dy
   __shared__ float s_ob[2 * kFrMaxOb];
   __shared__ float s_di[kFrMaxDi], s_Ti[kFrMaxTi], s_tv[kFrMaxTv], s_t[kFrMaxT];
+  __shared__ FrPow s_pw[kFrMaxT];
   __shared__ int s_nt[kFrMaxTi], s_cnt[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   for (int i = threadIdx.x; i < 9 * nx; i += blockDim.x) s_coef[i] = coef[i];
   for (int i = threadIdx.x; i < 2 * nob; i += blockDim.x) s_ob[i] = ob[i];
   if (threadIdx.x == 0) {     // the sample grids, by the reference's own float accumulation (:55-56,:58,:66-68); caps checked by the host
@@ -138,10 +154,14 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
     s_cnt[0] = ndi; s_cnt[1] = nTi; s_cnt[2] = ntv; s_cnt[3] = ntt;
   }
   __syncthreads();
-  const size_t a = (size_t)blockIdx.x * kFrWavesPerBlock + wv;
+  for (int i = threadIdx.x; i < s_cnt[3]; i += blockDim.x) s_pw[i] = fr_pow(s_t[i]);
+  __syncthreads();
+  const size_t a = (size_t)blockIdx.x * wpb + wv;
   if (a >= (size_t)n) return;     // whole waves only: no block barrier below
-  const int nTi = s_cnt[1], ntv = s_cnt[2];
-  const int P = s_cnt[0] * nTi * ntv;
+  FrTab* __restrict__ tab = s_tab_all + (size_t)wv * tab_stride;
+  const int nTi = s_cnt[1], ntv = s_cnt[2], ntt = s_cnt[3];
+  const int nC = nTi * ntv;        // longitudinal combos, <= 64 (host-checked): combo c = iTi * ntv + itv lives in lane c
+  const int P = s_cnt[0] * nC;
   const float* sk = s_coef;
   const float *cax = s_coef + nx, *cbx = s_coef + 2 * nx, *ccx = s_coef + 3 * nx, *cdx = s_coef + 4 * nx;
   const float *cay = s_coef + 5 * nx, *cby = s_coef + 6 * nx, *ccy = s_coef + 7 * nx, *cdy = s_coef + 8 * nx;
@@ -151,70 +171,103 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
   float s0 = state[5 * a], c_speed = state[5 * a + 1], c_d = state[5 * a + 2], c_d_d = state[5 * a + 3], c_d_dd = state[5 * a + 4];
   int st = 0, ticks = 0, last_best = -1, last_valid = 0;
   for (int tick = 0; tick < max_ticks; ++tick) {
-    float my_cost = FLT_MAX;          // min_cost :173
-    int my_idx = -1, my_valid = 0;
-    float w_s1 = 0, w_sd1 = 0, w_d1 = 0, w_dd1 = 0, w_ddd1 = 0, w_x1 = 0, w_y1 = 0;
-    for (int p = lane; p < P; p += 64) {
-      const int itv = p % ntv, pq = p / ntv, iTi = pq % nTi, idi = pq / nTi;
-      const float di = s_di[idi], Ti = s_Ti[iTi], tv = s_tv[itv];
+    // ---- phase A: lane c < nC owns combo c -----------------------------------------------------------------------
+    FrQuartic lon = FrQuartic{0, 0, 0, 0, 0};
+    float c_max_speed = FLT_MIN, c_max_accel = FLT_MIN, c_Js = 0.0f, c_sd_last = 0, c_s1 = 0, c_sd1 = 0;
+    int c_npts = 0, c_drop = 0;
+    if (lane < nC) {
+      const int iTi = lane / ntv, itv = lane - iTi * ntv;
       const int nt = s_nt[iTi];
-      const FrQuintic lat = fr_quintic(c_d, c_d_d, c_d_dd, di, 0.0f, 0.0f, Ti);     // :57
-      const FrQuartic lon = fr_quartic(s0, c_speed, 0.0f, tv, 0.0f, Ti);            // :70
-      float max_speed = FLT_MIN, max_accel = FLT_MIN, max_curv = FLT_MIN, Jp = 0.0f, Js = 0.0f;
-      float s1 = 0, sd1 = 0, d1 = 0, dd1 = 0, ddd1 = 0, x1 = 0, y1 = 0, sd_last = 0, d_last = 0;
-      float px = 0, py = 0, pyaw = 0, pds = 0;       // previous global point, previous segment's heading and length
-      int m = 0;                                     // global points so far
-      bool walking = true, dropped = false, collide = false;
-      for (int i = 0; i < nt; ++i) {
+      lon = fr_quartic(s0, c_speed, 0.0f, s_tv[itv], 0.0f, s_Ti[iTi]);            // :70
+      bool walking = true;
+      for (int i = 0; i < nt; ++i) {                                              // :74-85
         const float t = s_t[i];
-        // longitudinal samples :74-85
-        const float s_i = fr_q4_point(lon, t), sd_i = fr_q4_d1(lon, t), sdd_i = fr_q4_d2(lon, t), sddd_i = fr_q4_d3(lon, t);
-        if (sd_i > max_speed) max_speed = sd_i;
-        if (sdd_i > max_accel) max_accel = sdd_i;
-        Js += sddd_i * sddd_i;
-        sd_last = sd_i;
-        // lateral samples :59-65; fp.d holds every sample twice, so entry i is the sample at t[i/2]
-        const float dddd_i = fr_q5_d3(lat, t);
-        Jp += dddd_i * dddd_i;
-        const float d_i = fr_q5_point(lat, s_t[g.single_d_push ? i : (i >> 1)]);
-        if (i == 1) { s1 = s_i; sd1 = sd_i; d1 = d_i; dd1 = fr_q5_d1(lat, t); ddd1 = fr_q5_d2(lat, t); }
-        if (i == nt - 1) d_last = fr_q5_point(lat, t);
-        // calc_global_paths :110-122
-        if (walking) {
-          if (s_i >= s_back) { walking = false; }
-          else if (s_i < s_front) { walking = false; dropped = true; st |= 4; }
-          else {
-            const int seg = fr_bisect(sk, s_i, 0, nx), segd = fr_bisect(sk, s_i, 0, nx - 1);
-            const float dx = s_i - sk[seg], dxd = s_i - sk[segd];
-            const float posx = cax[seg] + cbx[seg] * dx + ccx[seg] * dx * dx + cdx[seg] * dx * dx * dx;
-            const float posy = cay[seg] + cby[seg] * dx + ccy[seg] * dx * dx + cdy[seg] * dx * dx * dx;
-            const float ddx = cbx[segd] + 2.0f * ccx[segd] * dxd + 3.0f * cdx[segd] * dxd * dxd;
-            const float ddy = cby[segd] + 2.0f * ccy[segd] * dxd + 3.0f * cdy[segd] * dxd * dxd;
-            const float iyaw = atan2f_(ddy, ddx);
-            double sn, cs;
-            mpc_sincos((double)iyaw + half_pi, &sn, &cs);
-            const float x = (float)((double)posx + (double)d_i * cs);
-            const float y = (float)((double)posy + (double)d_i * sn);
-            if (i == 1) { x1 = x; y1 = y; }
-            // check_collision :144-154
-            for (int k = 0; k < nob; ++k) {
-              const double ex = (double)(x - s_ob[2 * k]), ey = (double)(y - s_ob[2 * k + 1]);
-              const float dist = (float)(ex * ex + ey * ey);
-              collide |= ((double)dist <= r2);
-            }
-            // headings, segment lengths, curvature :124-141, as a sliding window
-            if (m >= 1) {
-              const float gx = x - px, gy = y - py;
-              const float yaw = atan2f_(gy, gx), ds = sqrtf(gx * gx + gy * gy);
-              if (m >= 2) { const float c = (yaw - pyaw) / pds; if (c > max_curv) max_curv = c; }
-              pyaw = yaw; pds = ds;
-            }
-            px = x; py = y; ++m;
-          }
+        const FrPow w = s_pw[i];
+        const float s_i = fr_q4_point(lon, t, w), sd_i = fr_q4_d1(lon, t, w), sdd_i = fr_q4_d2(lon, t, w), sddd_i = fr_q4_d3(lon, t);
+        if (sd_i > c_max_speed) c_max_speed = sd_i;
+        if (sdd_i > c_max_accel) c_max_accel = sdd_i;
+        c_Js += sddd_i * sddd_i;
+        c_sd_last = sd_i;
+        if (i == 1) { c_s1 = s_i; c_sd1 = sd_i; }
+        if (walking) {                                                            // :111-114
+          if (s_i >= s_back) walking = false;
+          else if (s_i < s_front) { walking = false; c_drop = 1; st |= 4; }
+          else c_npts = i + 1;
         }
       }
-      if (m >= 2) { const float c = (pyaw - pyaw) / pds; if (c > max_curv) max_curv = c; }   // the appended copy of the last heading :129-130
-      else dropped = true;
+    }
+    // ---- phase B: the course frame at every (combo, time step) ---------------------------------------------------
+    for (int e0 = 0; e0 < nC * ntt; e0 += 64) {
+      const int e = e0 + lane;
+      const bool live = e < nC * ntt;
+      const int c = live ? e / ntt : 0, i = live ? e - c * ntt : 0;
+      FrQuartic q;                                   // every lane takes part in the shuffles
+      q.a0 = __shfl(lon.a0, c, 64); q.a1 = __shfl(lon.a1, c, 64); q.a2 = __shfl(lon.a2, c, 64);
+      q.a3 = __shfl(lon.a3, c, 64); q.a4 = __shfl(lon.a4, c, 64);
+      if (!live) continue;
+      const float s_i = fr_q4_point(q, s_t[i], s_pw[i]);
+      const int seg = fr_bisect(sk, s_i, 0, nx), segd = fr_bisect(sk, s_i, 0, nx - 1);     // Spline::calc / calc_d
+      const float dx = s_i - sk[seg], dxd = s_i - sk[segd];
+      FrTab r;
+      r.px = cax[seg] + cbx[seg] * dx + ccx[seg] * dx * dx + cdx[seg] * dx * dx * dx;
+      r.py = cay[seg] + cby[seg] * dx + ccy[seg] * dx * dx + cdy[seg] * dx * dx * dx;
+      const float ddx = cbx[segd] + 2.0f * ccx[segd] * dxd + 3.0f * cdx[segd] * dxd * dxd;
+      const float ddy = cby[segd] + 2.0f * ccy[segd] * dxd + 3.0f * cdy[segd] * dxd * dxd;
+      const float iyaw = atan2f_(ddy, ddx);
+      mpc_sincos((double)iyaw + half_pi, &r.sn, &r.cs);
+      tab[e] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase C: one candidate per lane ---------------------------------------------------------------------------
+    float my_cost = FLT_MAX;          // min_cost :173
+    int my_idx = -1, my_valid = 0;
+    float w_d1 = 0, w_dd1 = 0, w_ddd1 = 0, w_x1 = 0, w_y1 = 0;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      const int p = p0 + lane;
+      const bool live = p < P;
+      const int c = live ? p % nC : 0, idi = live ? p / nC : 0, iTi = c / ntv;
+      // the combo's figures (every lane takes part in the shuffles)
+      const float max_speed = __shfl(c_max_speed, c, 64), max_accel = __shfl(c_max_accel, c, 64), Js = __shfl(c_Js, c, 64);
+      const float sd_last = __shfl(c_sd_last, c, 64);
+      const int npts = __shfl(c_npts, c, 64), drop = __shfl(c_drop, c, 64);
+      if (!live) continue;
+      const float di = s_di[idi], Ti = s_Ti[iTi];
+      const int nt = s_nt[iTi];
+      const FrQuintic lat = fr_quintic(c_d, c_d_d, c_d_dd, di, 0.0f, 0.0f, Ti);     // :57
+      // what main hands over (:227-231) is sample [1] of the winner; the costs need the last samples (:89-91); nt >= 2
+      const float dd1 = fr_q5_d1(lat, s_t[1], s_pw[1]), ddd1 = fr_q5_d2(lat, s_t[1], s_pw[1]);
+      const float d_last = fr_q5_point(lat, s_t[nt - 1], s_pw[nt - 1]);
+      float max_curv = FLT_MIN, Jp = 0.0f, d1 = 0, x1 = 0, y1 = 0;
+      float px = 0, py = 0, pyaw = 0, pds = 0;       // previous global point, previous segment's heading and length
+      bool collide = false;
+      const FrTab* __restrict__ row = tab + c * ntt;
+      for (int i = 0; i < nt; ++i) {
+        // lateral samples :59-65; fp.d holds every sample twice, so entry i is the sample at t[i/2]
+        const float dddd_i = fr_q5_d3(lat, s_t[i], s_pw[i]);
+        Jp += dddd_i * dddd_i;
+        if (i < npts) {                                                            // calc_global_paths :110-122
+          const int id = g.single_d_push ? i : (i >> 1);
+          const float d_i = fr_q5_point(lat, s_t[id], s_pw[id]);
+          const FrTab f = row[i];
+          const float x = (float)((double)f.px + (double)d_i * f.cs);
+          const float y = (float)((double)f.py + (double)d_i * f.sn);
+          if (i == 1) { d1 = d_i; x1 = x; y1 = y; }
+          for (int k = 0; k < nob; ++k) {                                          // check_collision :144-154
+            const double ex = (double)(x - s_ob[2 * k]), ey = (double)(y - s_ob[2 * k + 1]);
+            const float dist = (float)(ex * ex + ey * ey);
+            collide |= ((double)dist <= r2);
+          }
+          if (i >= 1) {                                                            // headings, lengths, curvature :124-141, sliding
+            const float gx = x - px, gy = y - py;
+            const float yaw = atan2f_(gy, gx), ds = sqrtf(gx * gx + gy * gy);
+            if (i >= 2) { const float cc = (yaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }
+            pyaw = yaw; pds = ds;
+          }
+          px = x; py = y;
+        }
+      }
+      if (npts >= 2) { const float cc = (pyaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }   // the appended copy of the last heading :129-130
+      const bool dropped = drop || npts < 2;
       const float dsp = (float)(g.target_speed - (double)sd_last);                               // :89
       const float cd = (float)((g.kj * (double)Jp + g.kt * (double)Ti) + g.kd * ((double)d_last * (double)d_last));
       const float cv = (float)((g.kj * (double)Js + g.kt * (double)Ti) + g.kd * (double)dsp);
@@ -225,13 +278,13 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       if (path_ok && p < path_cap) path_ok[a * path_cap + p] = ok ? 1 : 0;
       if (ok) {
         ++my_valid;
-        if (my_cost >= cf) {                                                                     // :176 (within a lane the paths come in generation order)
+        if (my_cost >= cf) {                                                                     // :176 (within a lane the candidates come in generation order)
           my_cost = cf; my_idx = p;
-          w_s1 = s1; w_sd1 = sd1; w_d1 = d1; w_dd1 = dd1; w_ddd1 = ddd1; w_x1 = x1; w_y1 = y1;
+          w_d1 = d1; w_dd1 = dd1; w_ddd1 = ddd1; w_x1 = x1; w_y1 = y1;
         }
       }
     }
-    // the last path in generation order attaining the minimum: (cost, -index) lexicographic minimum across the wave
+    // the last candidate in generation order attaining the minimum: (cost, -index) lexicographic minimum across the wave
     float bc = my_cost;
     int bi = my_idx, nv = my_valid;
 #pragma unroll
@@ -239,14 +292,13 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       const float oc = __shfl_xor(bc, msk, 64);
       const int oi = __shfl_xor(bi, msk, 64);
       nv += __shfl_xor(nv, msk, 64);
+      st |= __shfl_xor(st, msk, 64);
       if (oi >= 0 && (bi < 0 || oc < bc || (oc == bc && oi > bi))) { bc = oc; bi = oi; }
     }
-    st |= __shfl_xor(st, 32, 64); st |= __shfl_xor(st, 16, 64); st |= __shfl_xor(st, 8, 64);
-    st |= __shfl_xor(st, 4, 64); st |= __shfl_xor(st, 2, 64); st |= __shfl_xor(st, 1, 64);
     last_best = bi; last_valid = nv;
-    if (bi < 0) { st |= 1; break; }                  // no surviving path: the reference indexes an empty final_path
-    const int wl = bi & 63;                          // path p was evaluated by lane p % 64
-    s0 = __shfl(w_s1, wl, 64); c_speed = __shfl(w_sd1, wl, 64); c_d = __shfl(w_d1, wl, 64);
+    if (bi < 0) { st |= 1; break; }                  // no surviving candidate: the reference indexes an empty final_path
+    const int wl = bi & 63, wc = bi % nC;            // candidate p was evaluated by lane p % 64; its combo lives in lane p % nC
+    s0 = __shfl(c_s1, wc, 64); c_speed = __shfl(c_sd1, wc, 64); c_d = __shfl(w_d1, wl, 64);
     c_d_d = __shfl(w_dd1, wl, 64); c_d_dd = __shfl(w_ddd1, wl, 64);
     const float fx = __shfl(w_x1, wl, 64), fy = __shfl(w_y1, wl, 64);
     ticks = tick + 1;
@@ -254,6 +306,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       float* h = hist + ((size_t)tick * n + a) * 8;
       h[0] = s0; h[1] = c_speed; h[2] = c_d; h[3] = c_d_d; h[4] = c_d_dd; h[5] = fx; h[6] = fy; h[7] = bc;
     }
+    __builtin_amdgcn_wave_barrier();                 // the table is rewritten by the next tick's phase B
     const double ex = (double)(fx - goal_x), ey = (double)(fy - goal_y);
     if (ex * ex + ey * ey <= 1.0) break;             // :232
   }

@@ -286,8 +286,8 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
  * max_ticks = 1 is a single planning call.  Tolerance parity (1e-5), see DESIGN.md 5e.
  *   coef  [9][nx]   the course's Spline2D (include/cubic_spline.h:130-187) as a coefficient table: rows s, then a,b,c,d of
  *                   sx, then a,b,c,d of sy (b and d have nx-1 entries, the last column is padding); device pointer for
- *                   the _dev call; built on the host by crx_frenet_spline_build (2 <= nx <= 128)
- *   state [n][5]    (s0, c_speed, c_d, c_d_d, c_d_dd) in/out          ob [nob][2] shared, nob <= 256
+ *                   the _dev call; built on the host by crx_frenet_spline_build (2 <= nx <= 64)
+ *   state [n][5]    (s0, c_speed, c_d, c_d_d, c_d_dd) in/out          ob [nob][2] shared, nob <= 128
  *   goal            r_x.back(), r_y.back() of main :205-213, see crx_frenet_course_samples
  *   hist            (may be NULL) [max_ticks][n][8] = (s0, c_speed, c_d, c_d_d, c_d_dd, x, y, cf) after each tick
  *   status          bit 0: no candidate survived check_paths (the reference would index an empty path) — the episode ends
@@ -303,7 +303,8 @@ typedef struct crx_frenet_config {   /* the #defines :20-38, as the double expre
  * is the lateral offset at t[i/2] and main's c_d = d[1] never moves; 1 = one push per step (d[i] at t[i]).  With 0 the
  * reference's own scenario runs out of collision-free candidates after 48 ticks (status bit 0). */
 void crx_frenet_default_config(crx_frenet_config* c);
-/* number of candidate paths the configuration generates, or a negative crx error if it exceeds the kernel's grids */
+/* number of candidate paths the configuration generates, or a negative crx error if it exceeds the kernel's grids
+ * (<= 64 lateral offsets, horizons x target speeds <= 64, <= 64 time steps, horizons x speeds x time steps <= 2048) */
 int crx_frenet_num_paths(const crx_frenet_config* cfg);
 /* host: Spline2D(wx, wy) -> coef[9][nx].  The nx-by-nx float system the reference hands to colPivHouseholderQr is solved
  * in double (tridiagonal elimination) and rounded to float. */

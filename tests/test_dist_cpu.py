@@ -38,10 +38,19 @@ def _worker(rank, world, port, n, T, q):
     s1, ticks, *_ = oracle.lqr_closed_loop(st[lo:hi], course, goal, dim=5, max_ticks=300)
     sg = swarm.gather_agents(torch.from_numpy(s1), n)
     tg = swarm.gather_agents(torch.from_numpy(ticks), n)
+    # planner swarm: each rank plans for its shard of the agents (shared course and obstacles)
+    fr = oracle.frenet_run(_frenet_states(n)[lo:hi], oracle.frenet_spline_build(), [70.465, 0.007], 3)
+    fg = swarm.gather_agents(torch.from_numpy(fr["state"]), n)
     if rank == 0:
-        q.put((xg.numpy(), hg.numpy(), sg.numpy(), tg.numpy()))
+        q.put((xg.numpy(), hg.numpy(), sg.numpy(), tg.numpy(), fg.numpy()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _frenet_states(n):
+    rng = np.random.default_rng(13)
+    return np.stack([rng.uniform(0.0, 60.0, n), rng.uniform(1.0, 9.0, n), rng.uniform(-2.0, 2.0, n), rng.uniform(-0.5, 0.5, n),
+                     rng.uniform(-0.3, 0.3, n)], axis=1).astype(np.float32)
 
 
 def _free_port():
@@ -64,7 +73,7 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    xg, hg, sg, tg = q.get(timeout=240)
+    xg, hg, sg, tg, fg = q.get(timeout=240)
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
@@ -79,6 +88,8 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     st = tracking_agents(n, tuple(c[:100] for c in course), 11, spread=0.3)
     s1, ticks, *_ = oracle_mod.lqr_closed_loop(st, course, goal, dim=5, max_ticks=300)
     assert np.array_equal(sg, s1) and np.array_equal(tg, ticks)
+    fr = oracle_mod.frenet_run(_frenet_states(n), oracle_mod.frenet_spline_build(), [70.465, 0.007], 3)
+    assert np.array_equal(fg, fr["state"])
 
 
 def test_shard_range_partitions():

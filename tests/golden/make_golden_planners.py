@@ -1,0 +1,48 @@
+"""Generates tests/golden/planner_golden.npz: the dynamic-window and Frenet planners' oracle outputs on fixed inputs.
+
+Same role as make_golden.py (which see): the reference cannot run here, so the fixtures come from the CPU oracle; they pin
+it against drift and give the GPU tests a fixed target.  DWA uses the deterministic trig mode; the Frenet oracle calls the
+host libm (pow, cos/sin in double, atan2f) — the consumers compare it at the 1e-5 tolerance of its parity contract.
+Run from the repo root:  python tests/golden/make_golden_planners.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import oracle  # noqa: E402
+import oracle.oracle_lib as O  # noqa: E402
+
+O.trig_mode = lambda: 1
+out = {}
+# ---- dynamic window: agent 0 = the reference's start (src/dynamic_window_approach.cpp:161-176) --------------------------
+rng = np.random.default_rng(51)
+n = 12
+st = np.stack([rng.uniform(-1, 9, n), rng.uniform(-1, 9, n), rng.uniform(-3.2, 3.2, n), rng.uniform(-0.5, 1.0, n),
+               rng.uniform(-0.69, 0.69, n)], axis=1).astype(np.float32)
+st[0] = (0.0, 0.0, 3.141592653 / 8.0, 0.0, 0.0)
+u = st[:, 3:5].copy()
+goal = np.stack([rng.uniform(8, 12, n), rng.uniform(8, 12, n)], axis=1).astype(np.float32)
+goal[0] = (10.0, 10.0)
+u1, ns, bi = oracle.dwa_control(st, u, goal)
+s60, u60, t60, _ = oracle.dwa_run(st, u, goal, 60)
+out.update(dwa_state=st, dwa_u=u, dwa_goal=goal, dwa_u1=u1, dwa_ns=ns, dwa_best=bi, dwa_state60=s60, dwa_u60=u60, dwa_ticks60=t60)
+# ---- Frenet: agent 0 = the reference's start (src/frenet_optimal_trajectory.cpp:186-219) ---------------------------------
+coef = oracle.frenet_spline_build()
+rx, ry = oracle.frenet_course_samples(coef)
+n = 24
+fs = np.stack([rng.uniform(0.0, 65.0, n), rng.uniform(1.0, 9.0, n), rng.uniform(-3.0, 3.0, n), rng.uniform(-0.8, 0.8, n),
+               rng.uniform(-0.5, 0.5, n)], axis=1).astype(np.float32)
+fs[0] = O.FRENET_STATE0
+p = oracle.frenet_plan(fs, coef)
+out.update(fr_wx=O.FRENET_WX, fr_wy=O.FRENET_WY, fr_ob=O.FRENET_OBSTACLES, fr_coef=coef, fr_goal=np.array([rx[-1], ry[-1]], np.float32),
+           fr_nsamples=np.int32(len(rx)), fr_state=fs, fr_out=p["out"], fr_best=p["best"], fr_nvalid=p["n_valid"], fr_status=p["status"],
+           fr_path_cf=p["path_cf"], fr_path_ok=p["path_ok"])
+for push in (0, 1):
+    r = oracle.frenet_run(fs[:6], coef, out["fr_goal"], 120, cfg=oracle.frenet_config(single_d_push=push), want_hist=True)
+    out[f"fr_run{push}_state"], out[f"fr_run{push}_ticks"], out[f"fr_run{push}_status"] = r["state"], r["ticks"], r["status"]
+    out[f"fr_run{push}_hist0"] = r["hist"][: r["ticks"][0], 0]
+np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
+print("wrote planner_golden.npz", {k: v.shape for k, v in out.items()})

@@ -82,3 +82,27 @@ def test_frenet_abi_validation():
     assert l.crx_frenet_run_batch_dev(4, 1, None, None, 5, goal.ctypes.data, None, 0, None, None, None, None, None, None, None, None, 0, None) != 0
     with pytest.raises(crx.CrxError):
         crx.FrenetCourse(wx, wy)
+
+
+def test_planner_golden_fixture(oracle_mod):
+    """tests/golden/planner_golden.npz (make_golden_planners.py): the oracle keeps reproducing it — DWA bit for bit in the
+    deterministic trig mode, Frenet at its 1e-5 contract (it calls the host libm)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "planner_golden.npz"))
+    O = oracle_mod.oracle_lib
+    saved = O.trig_mode
+    O.trig_mode = lambda: 1
+    try:
+        u1, ns, bi = oracle_mod.dwa_control(g["dwa_state"], g["dwa_u"], g["dwa_goal"])
+        s60, u60, t60, _ = oracle_mod.dwa_run(g["dwa_state"], g["dwa_u"], g["dwa_goal"], 60)
+    finally:
+        O.trig_mode = saved
+    assert np.array_equal(u1.view(np.uint32), g["dwa_u1"].view(np.uint32)) and np.array_equal(ns, g["dwa_ns"]) and np.array_equal(bi, g["dwa_best"])
+    assert np.array_equal(s60.view(np.uint32), g["dwa_state60"].view(np.uint32)) and np.array_equal(t60, g["dwa_ticks60"])
+    coef = oracle_mod.frenet_spline_build(g["fr_wx"], g["fr_wy"])
+    assert np.allclose(coef, g["fr_coef"], rtol=1e-6, atol=1e-9)
+    p = oracle_mod.frenet_plan(g["fr_state"], g["fr_coef"], g["fr_ob"])
+    assert np.allclose(p["path_cf"], g["fr_path_cf"], rtol=1e-5, atol=1e-6, equal_nan=True)
+    assert (p["path_ok"] != g["fr_path_ok"]).mean() < 1e-3 and (p["best"] == g["fr_best"]).mean() > 0.95
+    same = p["best"] == g["fr_best"]
+    assert np.allclose(p["out"][same], g["fr_out"][same], rtol=1e-5, atol=1e-6)

@@ -57,18 +57,54 @@ __device__ __forceinline__ void store_P(const EkfState& s, float* __restrict__ P
 }
 
 // ---- single step: n vehicles, one ekf_estimation() each -------------------------------------
+// HBM-bound (176 B per update).  A wave's 64 covariances are one contiguous 4-KiB span; read or written straight from
+// per-lane registers, each 16-byte access lands in a different 64-byte block (32 cache lines per instruction).  Full
+// waves therefore move the span in four 1-KiB row pieces (16 contiguous bytes per lane) and transpose through a
+// wave-private LDS tile (lane stride 80 B: conflict-free b128 accesses); a ragged last wave uses the direct form.
+#ifndef CRX_EKF_STEP_LDS
+#define CRX_EKF_STEP_LDS 1
+#endif
 __global__ void __launch_bounds__(256)
 ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float* __restrict__ z,
                 const float* __restrict__ u, EkfConsts k) {
+  __shared__ v4f s_pt[CRX_EKF_STEP_LDS ? 4 * 64 * 5 : 1];
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const size_t wave0 = a - lane;                       // first vehicle of this wave
+  const bool full_wave = CRX_EKF_STEP_LDS && wave0 + 64 <= (size_t)n;
   if (a >= (size_t)n) return;
   EkfState s;
-  load_state(s, x, P, a);
+  v4f* __restrict__ tile = s_pt + wv * (64 * 5);
+  if (full_wave) {
+    const float4 xv = reinterpret_cast<const float4*>(x)[a];
+    s.x0 = xv.x; s.x1 = xv.y; s.x2 = xv.z; s.x3 = xv.w;
+    const v4f* __restrict__ row = reinterpret_cast<const v4f*>(P) + 4 * wave0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)] = row[64 * kk + lane];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const v4f c = tile[lane * 5u + j];
+      s.P[4 * j + 0] = c.x; s.P[4 * j + 1] = c.y; s.P[4 * j + 2] = c.z; s.P[4 * j + 3] = c.w;
+    }
+  } else {
+    load_state(s, x, P, a);
+  }
   const float2 zv = reinterpret_cast<const float2*>(z)[a];
   const float2 uv = reinterpret_cast<const float2*>(u)[a];
   ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);
   reinterpret_cast<float4*>(x)[a] = make_float4(s.x0, s.x1, s.x2, s.x3);
-  store_P(s, P, a);
+  if (full_wave) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[lane * 5u + j] = v4f{s.P[4 * j + 0], s.P[4 * j + 1], s.P[4 * j + 2], s.P[4 * j + 3]};
+    __builtin_amdgcn_wave_barrier();
+    v4f* __restrict__ row = reinterpret_cast<v4f*>(P) + 4 * wave0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) row[64 * kk + lane] = tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)];
+  } else {
+    store_P(s, P, a);
+  }
 }
 
 // ---- fused T steps: state/covariance stay in registers, z/u stream in, xEst streams out -----
@@ -82,6 +118,9 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
 // compiler's hazard recogniser only protects the no-soffset form).  Buffer offsets are 32-bit:
 // the host picks BUF only while every offset of a chunk stays below 2^31 (n <= kEkfBufMaxN).
 constexpr int kEkfBufMaxN = 1 << 22;
+#ifndef CRX_EKF_PHIST_LDS
+#define CRX_EKF_PHIST_LDS 1
+#endif
 
 #ifdef CRX_EKF_TIMING   // debug builds only (scripts/ubench): per-workgroup shader-clock / real-time deltas
 __device__ long long g_ekf_timing[4096][2];
@@ -99,6 +138,7 @@ __global__ void __launch_bounds__(CRX_EKF_RUN_BLOCK)
 ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
                const float* __restrict__ z, const float* __restrict__ u,
                float* __restrict__ x_hist, float* __restrict__ P_hist, EkfConsts k) {
+  __shared__ v4f s_pt[(PHIST && BUF && CRX_EKF_PHIST_LDS) ? CRX_EKF_RUN_BLOCK * 5 : 1];   // P_hist transpose staging (one wave)
   const size_t blk = (size_t)blockIdx.x * CRX_EKF_RUN_BLOCK;
   const unsigned lane = threadIdx.x;
   const size_t a = blk + lane;
@@ -111,6 +151,8 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
   const v2f* __restrict__ u2 = reinterpret_cast<const v2f*>(u) + blk;
   v4f* __restrict__ xh = reinterpret_cast<v4f*>(x_hist) + blk;
   v4f* __restrict__ Ph = reinterpret_cast<v4f*>(P_hist) + 4 * blk;
+  static_assert(!CRX_EKF_PHIST_LDS || CRX_EKF_RUN_BLOCK == 64, "the P_hist transpose assumes one wave per workgroup");
+  const bool full_wave = blk + 64 <= (size_t)n;   // a ragged last wave stores its covariances directly
   const EkfConstsP kp = pack_consts(k);
   const size_t ns = (size_t)n;
   const unsigned un = (unsigned)n;
@@ -162,13 +204,27 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
         else __builtin_nontemporal_store(xo, &(xh + t * ns)[lane]);
       }
       if (PHIST) {
+        if (BUF && CRX_EKF_PHIST_LDS && full_wave) {
+          // The wave's 64 covariances are one contiguous 4-KiB row of P_hist.  Written straight from registers, every
+          // store instruction scatters 64 16-byte pieces over 32 cache lines; transposed through LDS (lane stride 80 B:
+          // conflict-free b128 writes), store k instead covers bytes [1024 k, 1024 (k+1)) of the row, 16 per lane.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const v4f po = v4f{sp.Plo[j].x, sp.Plo[j].y, sp.Phi[j].x, sp.Phi[j].y};
-          // plain (not nontemporal) stores: a lane's 64-byte column block goes out as four 16-byte pieces
-          // that the L2 has to merge into full lines; streaming stores do not get merged (10x slower)
-          if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 64u + (unsigned)d * un * 64u + 16u * j, 0, 0);
-          else (Ph + 4 * t * ns)[4 * lane + j] = po;
+          for (int j = 0; j < 4; ++j)
+            s_pt[lane * 5u + j] = v4f{sp.Plo[j].x, sp.Plo[j].y, sp.Phi[j].x, sp.Phi[j].y};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            const v4f po = s_pt[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 16u + 1024u * kk + (unsigned)d * un * 64u, 0, 2);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const v4f po = v4f{sp.Plo[j].x, sp.Plo[j].y, sp.Phi[j].x, sp.Phi[j].y};
+            // plain (not nontemporal) stores: a lane's 64-byte column block goes out as four 16-byte pieces
+            // that the L2 has to merge into full lines; streaming stores do not get merged (10x slower)
+            if (BUF) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, po), rp, lane * 64u + (unsigned)d * un * 64u + 16u * j, 0, 0);
+            else (Ph + 4 * t * ns)[4 * lane + j] = po;
+          }
         }
       }
 #if CRX_EKF_PIN == 1

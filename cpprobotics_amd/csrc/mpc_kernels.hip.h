@@ -189,7 +189,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
   double mu = 0.0;
   const double mu_min = 1e-6, mu_max = 1e10;
   const int n_gn = 2;
-  int gn_left = n_gn;
+  int gn_left = n_gn, gn_run = n_gn;
   int status = 0, it = 0;
   bool done = !live;
 
@@ -295,12 +295,15 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
       double Quu10 = G[1][2] * bd + dt * Wxp[3][0] + Wpp01;
       double Quu11 = l_uu1 + G[1][3] * dt + dt * Wxp[3][1] + Wpp11;
-      if (exact) {   // V_s . d2F
+      if (exact) {   // V_s . d2F; the steering curvature e00 only where it leaves this stage's control Hessian positive
+                     // definite (a saturated steering input otherwise proposes a jump to a box corner)
+        const double e00 = lx[2] * v * dt_wb * 2.0 * tn * sec2;
+        const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = 0.5 * (Quu01 + Quu10);
         Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
         const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
         Qxx[2][3] += cross; Qxx[3][2] += cross;
         Qux[0][3] += lx[2] * sec2 * dt_wb;
-        Quu00 += lx[2] * v * dt_wb * 2.0 * tn * sec2;
+        if (g0 > 1e-12 && g0 * g3 - go * go > 1e-12 * g0) Quu00 += e00;
       }
       const double hod = 0.5 * (Quu01 + Quu10);
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
@@ -382,7 +385,8 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     bool accepted = false;
     double alpha = 1.0;
     const int nxt = cur ^ 1;
-    for (int ls = 0; ls < 10; ++ls) {
+    const int ls_max = exact ? 4 : 10;   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
+    for (int ls = 0; ls < ls_max; ++ls) {
       double Jn = 0.0;
       for (int i = 0; i < N; ++i) {
         const double* s = S[cur][i];
@@ -412,7 +416,8 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       if (alpha == 1.0) mu *= 0.1;
       if (mu < mu_min) mu = 0.0;
     } else if (exact) {
-      gn_left = n_gn;
+      gn_run = gn_run * 2 > 16 ? 16 : gn_run * 2;   // every failed Newton attempt doubles the Gauss-Newton run after it
+      gn_left = gn_run;
     } else {
       mu = (mu * 10.0 > 1e-3) ? mu * 10.0 : 1e-3;
       if (mu > mu_max) done = true;

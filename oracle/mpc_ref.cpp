@@ -180,12 +180,17 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     for (int a = 0; a < NU; ++a)
       for (int b = 0; b < NS; ++b) { double t = lus[a + NU * b]; for (int k = 0; k < NS; ++k) t += Fu[k + NS * a] * VF[k + NS * b]; Qus[a + NU * b] = t; }
     // second-order dynamics terms  Vs' . d2F
+    // The curvature the steering input picks up from the dynamics (e00) is left out of a stage whose control Hessian it
+    // would make indefinite — typically a steering input saturated along the horizon: the Newton step of such a stage is
+    // a jump to a box corner that the line search then rejects at every step length.  The state-side terms always go in.
     if (exact) {
+      const double e00 = Vs[2] * v / p.wb * dt * 2.0 * tn * sec2;
+      const double h0 = Quu[0] + e00 + mu, h3 = Quu[3] + mu, hod = 0.5 * (Quu[1] + Quu[2]);
       Qss[2 + NS * 2] += Vs[0] * (-v * c * dt) + Vs[1] * (-v * sn * dt);
       const double cross = Vs[0] * (-sn * dt) + Vs[1] * (c * dt);
       Qss[2 + NS * 3] += cross; Qss[3 + NS * 2] += cross;
       Qus[0 + NU * 3] += Vs[2] * sec2 / p.wb * dt;
-      Quu[0] += Vs[2] * v / p.wb * dt * 2.0 * tn * sec2;
+      if (h0 > 1e-12 && h0 * h3 - hod * hod > 1e-12 * h0) Quu[0] += e00;
     }
     // regularised control Hessian must be positive definite
     const double H[4] = {Quu[0] + mu, Quu[1], Quu[2], Quu[3] + mu};
@@ -249,6 +254,7 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
   const int n_gn = p_n_gn;
   const double lb[2] = {-p.max_steer, -p.max_accel}, ub[2] = {p.max_steer, p.max_accel};
   int gn_left = n_gn;   // Gauss-Newton iterations still to do before the next exact (Newton) attempt
+  int gn_run = n_gn;    // ... and how many follow a failed one: doubles (up to 16) with every failure
   for (it = 0; it < p.max_iter; ++it) {
     const bool exact = gn_left <= 0;
     double dV1, dV2, gnorm, deficit = 0.0;
@@ -266,7 +272,8 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
     const bool trust = -(dV1 + dV2) < noise;
     bool accepted = false;
     double alpha = 1.0;
-    for (int ls = 0; ls < 10; ++ls, alpha *= 0.5) {
+    const int ls_max = exact ? 4 : 10;   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
+    for (int ls = 0; ls < ls_max; ++ls, alpha *= 0.5) {
       std::memcpy(w.Sn.data(), w.S.data(), sizeof(double) * NS);
       for (int i = 0; i < N; ++i) {
         const double* s = w.S.data() + NS * i;
@@ -290,7 +297,8 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
       mu = (alpha == 1.0) ? mu * p_down : mu;
       if (mu < mu_min) mu = 0.0;
     } else if (exact) {
-      gn_left = n_gn;         // the Newton model was not trustworthy here: go back to Gauss-Newton for a while
+      gn_run = gn_run * 2 > 16 ? 16 : gn_run * 2;
+      gn_left = gn_run;       // the Newton model was not trustworthy here: go back to Gauss-Newton for a (growing) while
     } else {
       mu = mu * p_up > 1e-3 ? mu * p_up : 1e-3;
       if (mu > mu_max) break;

@@ -169,6 +169,25 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     sn[3] = s[3] + a * dt;
   };
 
+  struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
+  auto load_stage = [&](int c, int i) -> StageIn {
+    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
+  };
+
+  struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
+  auto load_roll = [&](int c, int i) -> RollIn {
+    RollIn q;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) q.s[a] = S[c][i][a];
+    q.u0 = U[c][i][0]; q.u1 = U[c][i][1]; q.k0 = kf[i][0]; q.k1 = kf[i][1];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) q.K[a] = Kf[i][a];
+    q.r = xr4[i];
+    return q;
+  };
+
+  const float4 rN = xr4[N];   // terminal reference: used by every sweep and every rollout
+
   int cur = 0;
   {
     const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
@@ -202,7 +221,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     double lx[4], lp0, lp1;          // V_s
     double Wxx[4][4], Wxp[4][2], Wpp00, Wpp01, Wpp11;  // V_ss (symmetric)
     {
-      const float4 r = xr4[N];
+      const float4 r = rN;
       const double* s = S[cur][N];
       lx[0] = -2.0 * p.qx * ((double)r.x - s[0]);
       lx[1] = -2.0 * p.qy * ((double)r.y - s[1]);
@@ -219,14 +238,26 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       Wpp00 = 0.0; Wpp01 = 0.0; Wpp11 = 0.0;
     }
     double dV1 = 0.0, dV2 = 0.0, gnorm = 0.0;
+    // The sweep's operands live in private memory (L2 / HBM latency once only a few waves are still iterating): stage
+    // i - 1's knot, trig and reference and stage i - 2's control are requested at the top of stage i and consumed one
+    // iteration later.
+    StageIn nx = load_stage(cur, N - 1);
+    double uc0 = U[cur][N - 1][0], uc1 = U[cur][N - 1][1];
+    double up0 = U[cur][N >= 2 ? N - 2 : 0][0], up1 = U[cur][N >= 2 ? N - 2 : 0][1];
     for (int i = N - 1; i >= 0; --i) {
-      const double* s = S[cur][i];
-      const double ud = U[cur][i][0], ua = U[cur][i][1];
+      const StageIn in = nx;
+      const double ud = uc0, ua = uc1;
       const bool inner = i >= 1;
-      const double pd = inner ? U[cur][i - 1][0] : 0.0, pa = inner ? U[cur][i - 1][1] : 0.0;
-      const double sn_ = TR[cur][i][0], cs_ = TR[cur][i][1];
+      const double pd = inner ? up0 : 0.0, pa = inner ? up1 : 0.0;
+      // unconditional (clamped index) so that the number of loads in flight is the same on every path: with a branch
+      // around them the compiler has to drain the memory queue (vmcnt(0)) before the first use of `in`
+      nx = load_stage(cur, i >= 1 ? i - 1 : 0);
+      uc0 = up0; uc1 = up1;
+      { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
+      const double s[4] = {in.s0, in.s1, in.s2, in.s3};
+      const double sn_ = in.sn, cs_ = in.cs;
       const double v = s[3];
-      const double tn = TR[cur][i][2], sec2 = 1.0 + tn * tn;
+      const double tn = in.tn, sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
       const double bd = v * sec2 * dt_wb;
       // stage cost derivatives
@@ -235,7 +266,7 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       double l_uu0 = 2.0 * p.r_d, l_uu1 = 2.0 * p.r_a;
       double l_p0 = 0.0, l_p1 = 0.0, l_pp0 = 0.0, l_pp1 = 0.0, l_up0 = 0.0, l_up1 = 0.0;
       if (inner) {
-        const float4 r = xr4[i];
+        const float4 r = in.r;
         q2[0] = 2.0 * p.qx; q2[1] = 2.0 * p.qy; q2[2] = 2.0 * p.qyaw; q2[3] = 2.0 * p.qv;
         l_x[0] = -q2[0] * ((double)r.x - s[0]);
         l_x[1] = -q2[1] * ((double)r.y - s[1]);
@@ -388,25 +419,45 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     const int ls_max = exact ? 4 : 10;   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
     for (int ls = 0; ls < ls_max; ++ls) {
       double Jn = 0.0;
+      // The candidate rollout carries its state and previous control in registers (they are also written to S[nxt],
+      // U[nxt] for the next backward sweep, but never read back here: a store-to-load round trip through private memory
+      // per stage would sit on the critical path), and requests stage i + 1's operands while stage i computes.
+      double xs[4] = {S[cur][0][0], S[cur][0][1], S[cur][0][2], S[cur][0][3]};
+      double pnd = 0.0, pna = 0.0, pcd = 0.0, pca = 0.0;       // previous stage's new / current controls
+      RollIn nx = load_roll(cur, 0);
       for (int i = 0; i < N; ++i) {
-        const double* s = S[cur][i];
-        double* sn = S[nxt][i];
-        const double d0 = sn[0] - s[0], d1 = sn[1] - s[1], d2 = sn[2] - s[2], d3 = sn[3] - s[3];
-        const double d4 = (i >= 1) ? U[nxt][i - 1][0] - U[cur][i - 1][0] : 0.0;
-        const double d5 = (i >= 1) ? U[nxt][i - 1][1] - U[cur][i - 1][1] : 0.0;
-        const double* Kc = Kf[i];
-        double du0 = alpha * kf[i][0];
-        du0 += Kc[0] * d0; du0 += Kc[2] * d1; du0 += Kc[4] * d2; du0 += Kc[6] * d3; du0 += Kc[8] * d4; du0 += Kc[10] * d5;
-        double du1 = alpha * kf[i][1];
-        du1 += Kc[1] * d0; du1 += Kc[3] * d1; du1 += Kc[5] * d2; du1 += Kc[7] * d3; du1 += Kc[9] * d4; du1 += Kc[11] * d5;
-        const double nd = clampd(U[cur][i][0] + du0, lb0, ub0);
-        const double na = clampd(U[cur][i][1] + du1, lb1, ub1);
+        const RollIn in = nx;
+        nx = load_roll(cur, i + 1 < N ? i + 1 : N - 1);      // unconditional, clamped: see the backward sweep
+        const double d0 = xs[0] - in.s[0], d1 = xs[1] - in.s[1], d2 = xs[2] - in.s[2], d3 = xs[3] - in.s[3];
+        const double d4 = (i >= 1) ? pnd - pcd : 0.0;
+        const double d5 = (i >= 1) ? pna - pca : 0.0;
+        double du0 = alpha * in.k0;
+        du0 += in.K[0] * d0; du0 += in.K[2] * d1; du0 += in.K[4] * d2; du0 += in.K[6] * d3; du0 += in.K[8] * d4; du0 += in.K[10] * d5;
+        double du1 = alpha * in.k1;
+        du1 += in.K[1] * d0; du1 += in.K[3] * d1; du1 += in.K[5] * d2; du1 += in.K[7] * d3; du1 += in.K[9] * d4; du1 += in.K[11] * d5;
+        const double nd = clampd(in.u0 + du0, lb0, ub0);
+        const double na = clampd(in.u1 + du1, lb1, ub1);
         U[nxt][i][0] = nd; U[nxt][i][1] = na;
-        Jn += ctrl(nxt, i);
-        if (i >= 1) Jn += track(sn, i);
-        step(sn, nd, na, S[nxt][i + 1], TR[nxt][i]);
+        double cv = p.r_d * nd * nd + p.r_a * na * na;              // ctrl(nxt, i)
+        if (i >= 1) {
+          const double dd = nd - pnd, da = na - pna;
+          cv += p.rd_d * dd * dd + p.rd_a * da * da;
+        }
+        Jn += cv;
+        if (i >= 1) {                                               // track(xs, i)
+          const double e0 = (double)in.r.x - xs[0], e1 = (double)in.r.y - xs[1], e2 = (double)in.r.z - xs[2], e3 = (double)in.r.w - xs[3];
+          Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
+        }
+        double xn[4];
+        step(xs, nd, na, xn, TR[nxt][i]);
+        S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
+        xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
+        pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
       }
-      Jn += track(S[nxt][N], N);
+      {                                                             // track(xs, N), terminal reference kept in registers
+        const double e0 = (double)rN.x - xs[0], e1 = (double)rN.y - xs[1], e2 = (double)rN.z - xs[2], e3 = (double)rN.w - xs[3];
+        Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
+      }
       if (Jn < J || (trust && Jn <= J + noise)) { J = Jn; accepted = true; break; }
       alpha *= 0.5;
     }

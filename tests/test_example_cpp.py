@@ -1,4 +1,4 @@
-"""examples/ekf_fleet.cpp: the reference's EKF demo for a whole fleet, in C++ against the C ABI."""
+"""examples/*.cpp: the reference's EKF demo and its two sampling planners for a whole fleet, in C++ against the C ABI."""
 import os
 import subprocess
 
@@ -7,13 +7,22 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def exe(tmp_path_factory, crx):
-    out = str(tmp_path_factory.mktemp("ex") / "ekf_fleet")
+def _build(tmp_path_factory, name):
+    out = str(tmp_path_factory.mktemp("ex") / name)
     libdir = os.path.join(ROOT, "cpprobotics_amd")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "ekf_fleet.cpp"),
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
                            "-o", out, "-L", libdir, "-lcrx", f"-Wl,-rpath,{libdir}"])
     return out
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory, crx):
+    return _build(tmp_path_factory, "ekf_fleet")
+
+
+@pytest.fixture(scope="module")
+def planner_exe(tmp_path_factory, crx):
+    return _build(tmp_path_factory, "planner_fleet")
 
 
 def test_example_builds_and_fails_loudly_without_gpu(exe):
@@ -29,3 +38,18 @@ def test_example_runs(exe):
     r = subprocess.run([exe, "4096", "200"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "EKF updates/s" in r.stdout
+
+
+def test_planner_example_builds_and_fails_loudly_without_gpu(planner_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([planner_exe, "64"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_planner_example_runs(planner_exe):
+    r = subprocess.run([planner_exe, "512"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Frenet (single_d_push=1)" in r.stdout and "DWA:" in r.stdout

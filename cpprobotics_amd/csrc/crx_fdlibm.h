@@ -10,6 +10,8 @@
 // algorithm; every operation is a plain fp32 operation in the order fdlibm writes it
 // (the engine is compiled with -ffp-contract=off).  OCML's device atan2f/tanf round differently.
 //
+// atanf_ is written branch-free and atan2f_ with a straight-line common case (same operations, same results: a wavefront
+// whose lanes fall into different argument ranges would otherwise run every range's branch in turn).
 // Verified against the host libm: atanf and tanf on all 2^32 inputs, atan2f on a 3 x 2^32-point
 // structured sweep (tests/tools/fdlibm_exhaustive.cpp; tests/test_fdlibm.py runs a strided subset).
 // (The constants were cross-checked against the .rodata of the libm.so.6 in this image.)
@@ -31,45 +33,44 @@ CRX_FD float fd_float(uint32_t u) { union { float f; uint32_t u; } v; v.u = u; r
 CRX_FD float fd_fabsf(float x) { return fd_float(fd_bits(x) & 0x7fffffffu); }
 
 // ---- atanf (s_atanf.c) --------------------------------------------------------------------------
+// Branch-free: fdlibm's four argument reductions differ only in the numerator and denominator of ONE division
+// (|x| < 7/16: x itself, written as x / 1, which is exact), so both are picked by range and a single division is issued;
+// the special cases (|x| >= 2^25, NaN, |x| < 2^-29) are selects on the result.  A wavefront whose lanes fall into
+// different ranges — headings of a candidate bundle do — otherwise runs every range's division in turn.
 CRX_FD float atanf_(float x) {
-  const float atanhi[4] = {fd_float(0x3eed6338u), fd_float(0x3f490fdau), fd_float(0x3f7b985eu), fd_float(0x3fc90fdau)};
-  const float atanlo[4] = {fd_float(0x31ac3769u), fd_float(0x33222168u), fd_float(0x33140fb4u), fd_float(0x33a22168u)};
   const float aT0 = fd_float(0x3eaaaaabu), aT1 = fd_float(0xbe4ccccdu), aT2 = fd_float(0x3e124925u),
               aT3 = fd_float(0xbde38e38u), aT4 = fd_float(0x3dba2e6eu), aT5 = fd_float(0xbd9d8795u),
               aT6 = fd_float(0x3d886b35u), aT7 = fd_float(0xbd6ef16bu), aT8 = fd_float(0x3d4bda59u),
               aT9 = fd_float(0xbd15a221u), aT10 = fd_float(0x3c8569d7u);
   const int32_t hx = (int32_t)fd_bits(x);
   const int32_t ix = hx & 0x7fffffff;
-  int id;
-  if (ix >= 0x4c000000) {             // |x| >= 2^25
-    if (ix > 0x7f800000) return x + x;  // NaN
-    if (hx > 0) return atanhi[3] + atanlo[3];
-    return -atanhi[3] - atanlo[3];
-  }
-  if (ix < 0x3ee00000) {              // |x| < 0.4375
-    if (ix < 0x31000000) return x;    // |x| < 2^-29
-    id = -1;
-  } else {
-    x = fd_fabsf(x);
-    if (ix < 0x3f980000) {            // |x| < 1.1875
-      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }   // 7/16 <= |x| < 11/16
-      else { id = 1; x = (x - 1.0f) / (x + 1.0f); }                          // 11/16 <= |x| < 19/16
-    } else {
-      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }   // |x| < 2.4375
-      else { id = 3; x = -1.0f / x; }                                        // 2.4375 <= |x| < 2^25
-    }
-  }
-  const float z = x * x;
+  const float ax = fd_fabsf(x);
+  const bool r0 = ix < 0x3ee00000;                 // |x| < 0.4375: no reduction (id = -1)
+  const bool r1 = ix < 0x3f300000;                 // < 11/16: id 0
+  const bool r2 = ix < 0x3f980000;                 // < 19/16: id 1
+  const bool r3 = ix < 0x401c0000;                 // < 2.4375: id 2, else id 3
+  //            id -1      id 0             id 1         id 2               id 3
+  const float num = r0 ? x : (r1 ? 2.0f * ax - 1.0f : (r2 ? ax - 1.0f : (r3 ? ax - 1.5f : -1.0f)));
+  const float den = r0 ? 1.0f : (r1 ? 2.0f + ax : (r2 ? ax + 1.0f : (r3 ? 1.0f + 1.5f * ax : ax)));
+  const float hi = r1 ? fd_float(0x3eed6338u) : (r2 ? fd_float(0x3f490fdau) : (r3 ? fd_float(0x3f7b985eu) : fd_float(0x3fc90fdau)));
+  const float lo = r1 ? fd_float(0x31ac3769u) : (r2 ? fd_float(0x33222168u) : (r3 ? fd_float(0x33140fb4u) : fd_float(0x33a22168u)));
+  const float t = num / den;
+  const float z = t * t;
   const float w = z * z;
   const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
   const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
-  if (id < 0) return x - x * (s1 + s2);
-  const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
-  return (hx < 0) ? -r : r;
+  const float small = t - t * (s1 + s2);                                  // id < 0
+  const float r = hi - ((t * (s1 + s2) - lo) - t);
+  float res = r0 ? small : ((hx < 0) ? -r : r);
+  res = (ix < 0x31000000) ? x : res;                                      // |x| < 2^-29
+  const float big = fd_float(0x3fc90fdau) + fd_float(0x33a22168u);        // atanhi[3] + atanlo[3]
+  res = (ix >= 0x4c000000) ? ((hx > 0) ? big : -fd_float(0x3fc90fdau) - fd_float(0x33a22168u)) : res;   // |x| >= 2^25
+  res = (ix > 0x7f800000) ? x + x : res;                                  // NaN
+  return res;
 }
 
 // ---- atan2f (e_atan2f.c) ------------------------------------------------------------------------
-CRX_FD float atan2f_(float y, float x) {
+CRX_FD float atan2f_general_(float y, float x) {
   const float tiny = 1.0e-30f, pi_o_4 = fd_float(0x3f490fdbu), pi_o_2 = fd_float(0x3fc90fdbu),
               pi = fd_float(0x40490fdbu), pi_lo = fd_float(0xb3bbbd2eu);
   const int32_t hx = (int32_t)fd_bits(x), hy = (int32_t)fd_bits(y);
@@ -114,6 +115,25 @@ CRX_FD float atan2f_(float y, float x) {
     case 2: return pi - (z - pi_lo);
     default: return (z - pi_lo) - pi;
   }
+}
+
+// Common case first — both arguments finite and non-zero, x != 1 — as straight-line code (one test, the ratio, atanf_,
+// selects for the |y/x| extremes and the quadrant); everything else goes through the case analysis above.
+CRX_FD float atan2f_(float y, float x) {
+  const float pi_o_2 = fd_float(0x3fc90fdbu), pi = fd_float(0x40490fdbu), pi_lo = fd_float(0xb3bbbd2eu);
+  const int32_t hx = (int32_t)fd_bits(x), hy = (int32_t)fd_bits(y);
+  const int32_t ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  // ix, iy in [1, 0x7f7fffff] (finite, non-zero) and x != 1.0
+  const bool plain = ((uint32_t)(ix - 1) < 0x7f7fffffu) & ((uint32_t)(iy - 1) < 0x7f7fffffu) & (hx != 0x3f800000);
+  if (!plain) return atan2f_general_(y, x);
+  const int32_t k = (iy - ix) >> 23;
+  float z = atanf_(fd_fabsf(y / x));
+  z = (hx < 0 && k < -60) ? 0.0f : z;                       // |y|/x < -2^60
+  z = (k > 60) ? pi_o_2 + 0.5f * pi_lo : z;                 // |y/x| > 2^60
+  const float zl = z - pi_lo;
+  const float pos = (hx < 0) ? pi - zl : z;                 // m = 2 : m = 0
+  const float neg = (hx < 0) ? zl - pi : fd_float(fd_bits(z) ^ 0x80000000u);   // m = 3 : m = 1
+  return (hy < 0) ? neg : pos;
 }
 
 // ---- acosf (e_acosf.c) --------------------------------------------------------------------------

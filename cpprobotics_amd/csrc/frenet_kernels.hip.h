@@ -239,7 +239,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       const float d_last = fr_q5_point(lat, s_t[nt - 1], s_pw[nt - 1]);
       float max_curv = FLT_MIN, Jp = 0.0f, d1 = 0, x1 = 0, y1 = 0;
       float px = 0, py = 0, pyaw = 0, pds = 0;       // previous global point, previous segment's heading and length
-      bool collide = false;
+      unsigned dmin = 0x7f800000u;                   // smallest squared obstacle distance so far (float bits), from +inf
       const FrTab* __restrict__ row = tab + c * ntt;
       for (int i = 0; i < nt; ++i) {
         // lateral samples :59-65; fp.d holds every sample twice, so entry i is the sample at t[i/2]
@@ -252,10 +252,14 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
           const float x = (float)((double)f.px + (double)d_i * f.cs);
           const float y = (float)((double)f.py + (double)d_i * f.sn);
           if (i == 1) { d1 = d_i; x1 = x; y1 = y; }
-          for (int k = 0; k < nob; ++k) {                                          // check_collision :144-154
+          // check_collision :144-154: `dist <= ROBOT_RADIUS^2` for some (point, obstacle) <=> the smallest dist passes.
+          // dist is a sum of squares (never -0): the minimum is taken on the bit patterns as unsigned integers — the float
+          // order, with every NaN above +inf, i.e. ignored exactly as a failed comparison is.
+          for (int k = 0; k < nob; ++k) {
             const double ex = (double)(x - s_ob[2 * k]), ey = (double)(y - s_ob[2 * k + 1]);
             const float dist = (float)(ex * ex + ey * ey);
-            collide |= ((double)dist <= r2);
+            const unsigned db = __float_as_uint(dist);
+            dmin = db < dmin ? db : dmin;
           }
           if (i >= 1) {                                                            // headings, lengths, curvature :124-141, sliding
             const float gx = x - px, gy = y - py;
@@ -268,6 +272,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       }
       if (npts >= 2) { const float cc = (pyaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }   // the appended copy of the last heading :129-130
       const bool dropped = drop || npts < 2;
+      const bool collide = (double)__uint_as_float(dmin) <= r2;
       const float dsp = (float)(g.target_speed - (double)sd_last);                               // :89
       const float cd = (float)((g.kj * (double)Jp + g.kt * (double)Ti) + g.kd * ((double)d_last * (double)d_last));
       const float cv = (float)((g.kj * (double)Js + g.kt * (double)Ti) + g.kd * (double)dsp);

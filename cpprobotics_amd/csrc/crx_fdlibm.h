@@ -138,6 +138,8 @@ CRX_FD float atan2f_(float y, float x) {
 
 // ---- acosf (e_acosf.c) --------------------------------------------------------------------------
 // std::acos(float) in the reference's DWA goal cost (/root/reference/src/dynamic_window_approach.cpp:107).
+// Branch-free like atanf_: the three ranges evaluate the same rational p(z)/q(z), at z = x*x or z = (1 -+ x)/2, and differ
+// in how it is combined; z is selected, p/q and the root are computed once, the combination is selected.
 CRX_FD float acosf_(float x) {
   const float pi = fd_float(0x40490fdau), pio2_hi = fd_float(0x3fc90fdau), pio2_lo = fd_float(0x33a22168u);
   const float pS0 = fd_float(0x3e2aaaabu), pS1 = fd_float(0xbea6b090u), pS2 = fd_float(0x3e4e0aa8u),
@@ -146,34 +148,22 @@ CRX_FD float acosf_(float x) {
               qS4 = fd_float(0x3d9dc62eu);
   const int32_t hx = (int32_t)fd_bits(x);
   const int32_t ix = hx & 0x7fffffff;
-  if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;   // |x| == 1
-  if (ix > 0x3f800000) return (x - x) / (x - x);                      // |x| > 1 or NaN -> NaN
-  if (ix < 0x3f000000) {                                              // |x| < 0.5
-    if (ix <= 0x23000000) return pio2_hi + pio2_lo;                   // |x| < 2^-57
-    const float z = x * x;
-    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = p / q;
-    return pio2_hi - (x - (pio2_lo - x * r));
-  } else if (hx < 0) {                                                // x < -0.5
-    const float z = (1.0f + x) * 0.5f;
-    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float s = __builtin_sqrtf(z);
-    const float r = p / q;
-    const float w = r * s - pio2_lo;
-    return pi - 2.0f * (s + w);
-  } else {                                                            // x > 0.5
-    const float z = (1.0f - x) * 0.5f;
-    const float s = __builtin_sqrtf(z);
-    const float df = fd_float(fd_bits(s) & 0xfffff000u);
-    const float c = (z - df * df) / (s + df);
-    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
-    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
-    const float r = p / q;
-    const float w = r * s + c;
-    return 2.0f * (df + w);
-  }
+  const bool inner = ix < 0x3f000000;                                   // |x| < 0.5
+  const float z = inner ? x * x : ((hx < 0) ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
+  const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+  const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+  const float r = p / q;
+  const float s = __builtin_sqrtf(z);
+  const float r_in = pio2_hi - (x - (pio2_lo - x * r));                 // |x| < 0.5
+  const float r_neg = pi - 2.0f * (s + (r * s - pio2_lo));              // x < -0.5
+  const float df = fd_float(fd_bits(s) & 0xfffff000u);                  // x > 0.5
+  const float c = (z - df * df) / (s + df);
+  const float r_pos = 2.0f * (df + (r * s + c));
+  float res = inner ? r_in : ((hx < 0) ? r_neg : r_pos);
+  res = (ix <= 0x23000000) ? pio2_hi + pio2_lo : res;                   // |x| < 2^-57
+  res = (ix == 0x3f800000) ? (hx > 0 ? 0.0f : pi + 2.0f * pio2_lo) : res;   // |x| == 1
+  res = (ix > 0x3f800000) ? (x - x) / (x - x) : res;                    // |x| > 1 or NaN -> NaN
+  return res;
 }
 
 // ---- tanf (s_tanf.c, k_tanf.c, the |x| < 2^7*pi/2 part of e_rem_pio2f.c) -------------------------

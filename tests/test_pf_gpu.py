@@ -52,3 +52,32 @@ def test_pf_episode_tracks_like_the_oracle(crx, oracle_mod):
     assert same.mean() > 0.5
     assert np.abs(nres.cpu().numpy().astype(int) - nreso).max() <= 0.05 * T
     assert np.allclose(pwd.cpu().numpy().sum(axis=1), 1.0, atol=1e-4)
+
+
+@pytest.mark.parametrize("NP", [64, 128])
+def test_pf_other_particle_counts(crx, oracle_mod, NP):
+    """The other two instantiations (one full wave of particles; two particles per lane), single ticks and a short episode,
+    including ticks in which a vehicle sees no landmark at all."""
+    n, T = 37, 40
+    rng = np.random.default_rng(NP)
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle_mod, n, T, NP, 77 + NP)
+    nobs = nobs.copy()
+    nobs[3] = 0                                                      # tick 3: nobody observes anything
+    pw = np.full((n, NP), 1.0 / NP, np.float32)
+    for t in (1, 3, 9):
+        px = (xth[t - 1][:, None, :] + rng.normal(0, 0.05, (n, NP, 4))).astype(np.float32)
+        pxo, pwo, xeo, Peo, reso, _ = oracle_mod.pf_step(px, pw, obs[t], nobs[t], ut[t], nrm[t], uni[t])
+        pxd, pwd = _t(px), _t(pw)
+        xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs[t:t + 1]), _t(nobs[t:t + 1]), _t(ut[t:t + 1]), _t(nrm[t:t + 1]), _t(uni[t:t + 1]))
+        assert np.allclose(xe.cpu().numpy(), xeo, rtol=1e-5, atol=1e-5)
+        assert np.allclose(Pe.cpu().numpy(), Peo, rtol=1e-3, atol=1e-6)
+        assert (nres.cpu().numpy() == reso).mean() >= 0.9
+    px, pw = np.zeros((n, NP, 4), np.float32), np.full((n, NP), 1.0 / NP, np.float32)
+    _, _, xeo, _, xho, nreso = oracle_mod.pf_run(px, pw, obs, nobs, ut, nrm, uni)
+    pxd, pwd = _t(px), _t(pw)
+    xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs), _t(nobs), _t(ut), _t(nrm), _t(uni))
+    h = hist.cpu().numpy()
+    err_g = np.hypot(h[..., 0] - xth[..., 0], h[..., 1] - xth[..., 1])
+    err_o = np.hypot(xho[..., 0] - xth[..., 0], xho[..., 1] - xth[..., 1])
+    assert abs(err_g.mean() - err_o.mean()) < 0.02 and err_g.mean() < 0.2
+    assert np.allclose(pwd.cpu().numpy().sum(axis=1), 1.0, atol=1e-4)

@@ -303,3 +303,30 @@ def test_ekf_fused_fuzz_wide_ranges(crx, oracle_mod):
         assert np.array_equal(Pd.cpu().numpy()[ok], Po[ok]) and np.array_equal(xd.cpu().numpy()[ok], xo[ok])
         bad = ~np.isfinite(xho[-1]).all(axis=1)
         assert not np.isfinite(xh.cpu().numpy()[-1][bad]).all(axis=1).any()
+
+
+def test_ekf_step_is_graph_capturable_and_bit_exact(crx, oracle_mod):
+    """The per-tick _dev entry point only enqueues (no allocation, no synchronisation): a HIP graph captured over K ticks
+    replays to the same bits as K plain launches and as the oracle."""
+    import torch
+    n, K = 1000, 12
+    Q, R = ekf_QR()
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, n, K, seed=99)
+    x, P = x0.copy(), P0.copy()
+    for t in range(K):
+        x, P = oracle_mod.ekf_step(x, P, z[t], ud[t], Q, R)
+    zd, udd = _t(z), _t(ud)
+    xd, Pd = _t(x0), _t(P0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                    # warm-up outside the capture
+        crx.ekf_estimation(xd.clone(), Pd.clone(), zd[0], udd[0], Q, R)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(K):
+            crx.ekf_estimation(xd, Pd, zd[t], udd[t], Q, R)
+    xd.copy_(_t(x0)); Pd.copy_(_t(P0))                               # capture does not execute: start from the initial state
+    g.replay()
+    torch.cuda.synchronize()
+    assert bit_equal(xd.cpu().numpy(), x) and bit_equal(Pd.cpu().numpy(), P)

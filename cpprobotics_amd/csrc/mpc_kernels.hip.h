@@ -87,38 +87,42 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, double g0, double g1, double lo0,
                                        double hi0, double lo1, double hi1, double& k0, double& k1, bool& f0,
                                        bool& f1) {
+  // Straight-line: every candidate is formed and scored, the winner is picked by selects in the order (and with the
+  // strict comparison) of the enumeration in oracle/mpc_ref.cpp — per-lane booleans carried through divergent branches
+  // cost more scalar mask bookkeeping than the arithmetic they skip.  Only the whole enumeration is skipped, when every
+  // lane of the wave has its interior stationary point inside the box.
   const double tiny = 1e-12;
   const double det = h00 * h11 - hod * hod;
-  if (h00 > tiny && det > tiny * h00) {
-    const double idet = 1.0 / det;
-    const double a = -(h11 * g0 - hod * g1) * idet;
-    const double b = -(-hod * g0 + h00 * g1) * idet;
-    if (a >= lo0 && a <= hi0 && b >= lo1 && b <= hi1) { k0 = a; k1 = b; f0 = true; f1 = true; return; }
-  }
-  double best = 1e300;
-  k0 = 0.0; k1 = 0.0; f0 = false; f1 = false;
-  auto consider = [&](double a, double b, bool fa, bool fb) {
+  const bool pd = h00 > tiny && det > tiny * h00;
+  const double idet = 1.0 / (pd ? det : 1.0);
+  const double ia = -(h11 * g0 - hod * g1) * idet, ib = -(-hod * g0 + h00 * g1) * idet;
+  const bool interior = pd && ia >= lo0 && ia <= hi0 && ib >= lo1 && ib <= hi1;
+  k0 = ia; k1 = ib; f0 = true; f1 = true;
+  if (__all(interior)) return;
+  double best = 1e300, b0 = 0.0, b1 = 0.0;
+  int bf = 0;                                  // bit 0: control 0 free, bit 1: control 1 free
+  auto consider = [&](double a, double b, int flags, bool valid) {
     const double obj = 0.5 * (h00 * a * a + 2.0 * hod * a * b + h11 * b * b) + g0 * a + g1 * b;
-    if (obj < best) { best = obj; k0 = a; k1 = b; f0 = fa; f1 = fb; }
+    const bool take = valid && obj < best;
+    best = take ? obj : best; b0 = take ? a : b0; b1 = take ? b : b1; bf = take ? flags : bf;
   };
-  const double ih11 = (h11 > tiny) ? 1.0 / h11 : 0.0, ih00 = (h00 > tiny) ? 1.0 / h00 : 0.0;   // one reciprocal per edge pair
+  const bool c11 = h11 > tiny, c00 = h00 > tiny;
+  const double ih11 = 1.0 / (c11 ? h11 : 1.0), ih00 = 1.0 / (c00 ? h00 : 1.0);   // one reciprocal per edge pair
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double c0 = b ? hi0 : lo0;
-    if (h11 > tiny) {
-      const double t = -(g1 + hod * c0) * ih11;
-      if (t >= lo1 && t <= hi1) consider(c0, t, false, true);
-    }
+    const double t1 = -(g1 + hod * c0) * ih11;
+    consider(c0, t1, 2, c11 && t1 >= lo1 && t1 <= hi1);
     const double c1 = b ? hi1 : lo1;
-    if (h00 > tiny) {
-      const double t = -(g0 + hod * c1) * ih00;
-      if (t >= lo0 && t <= hi0) consider(t, c1, true, false);
-    }
+    const double t0 = -(g0 + hod * c1) * ih00;
+    consider(t0, c1, 1, c00 && t0 >= lo0 && t0 <= hi0);
   }
 #pragma unroll
-  for (int b0 = 0; b0 < 2; ++b0)
+  for (int q0 = 0; q0 < 2; ++q0)
 #pragma unroll
-    for (int b1 = 0; b1 < 2; ++b1) consider(b0 ? hi0 : lo0, b1 ? hi1 : lo1, false, false);
+    for (int q1 = 0; q1 < 2; ++q1) consider(q0 ? hi0 : lo0, q1 ? hi1 : lo1, 0, true);
+  k0 = interior ? ia : b0; k1 = interior ? ib : b1;
+  f0 = interior || (bf & 1); f1 = interior || (bf & 2);
 }
 
 template <int MAXT>
@@ -369,12 +373,6 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       const double Quuk0 = Quu00 * k0 + hod * k1, Quuk1 = hod * k0 + Quu11 * k1;
       dV1 += k0 * Qu0 + k1 * Qu1;
       dV2 += 0.5 * (k0 * Quuk0 + k1 * Quuk1);
-      double QuuK[2][6];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        QuuK[0][b] = Quu00 * K[0][b] + hod * K[1][b];
-        QuuK[1][b] = hod * K[0][b] + Quu11 * K[1][b];
-      }
       const double t0 = Quuk0 + Qu0, t1 = Quuk1 + Qu1;
       double Vs[6];
 #pragma unroll
@@ -392,12 +390,18 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
           else if (a == 4 && b == 4) qss = l_pp0;
           else if (a == 5 && b == 5) qss = l_pp1;
           else qss = 0.0;
-          // K'QuuK + K'Qus + Qus'K is symmetric (Quu is symmetrised through `hod`); only the upper triangle is formed and
-          // mirrored below, so one evaluation per entry suffices
-          const double tab = (K[0][a] * QuuK[0][b] + K[1][a] * QuuK[1][b]) + (K[0][a] * Qus[0][b] + K[1][a] * Qus[1][b]) +
-                             (Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b]);
-          Vss[a][b] = qss + tab;
+          // V_ss = Q_ss + K'Quu K + K'Q_us + Q_us'K.  The gains solve (Quu + mu I)_FF K_F = -Q_us,F on the free controls
+          // (rows of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
+          //   V_ss = Q_ss + Q_us'K - mu K'K
+          // (the familiar Q_ss - Q_su Quu^-1 Q_us when mu = 0).  Only the upper triangle is formed and mirrored.
+          Vss[a][b] = qss + (Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b]);
         }
+      if (mu != 0.0) {      // rare: the regularised iterations
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) Vss[a][b] -= mu * (K[0][a] * K[0][b] + K[1][a] * K[1][b]);
+      }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         lx[a] = Vs[a];

@@ -221,23 +221,20 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     double Quuk[2] = {Quu[0] * k[0] + Quu[2] * k[1], Quu[1] * k[0] + Quu[3] * k[1]};
     *dV1 += k[0] * Qu[0] + k[1] * Qu[1];
     *dV2 += 0.5 * (k[0] * Quuk[0] + k[1] * Quuk[1]);
-    double QuuK[NU * NS];
-    for (int b = 0; b < NS; ++b) {
-      QuuK[0 + NU * b] = Quu[0] * K[0 + NU * b] + Quu[2] * K[1 + NU * b];
-      QuuK[1 + NU * b] = Quu[1] * K[0 + NU * b] + Quu[3] * K[1 + NU * b];
-    }
     for (int a = 0; a < NS; ++a) {
       Vs[a] = Qs[a] + (K[0 + NU * a] * Quuk[0] + K[1 + NU * a] * Quuk[1]) + (K[0 + NU * a] * Qu[0] + K[1 + NU * a] * Qu[1]) +
               (Qus[0 + NU * a] * k[0] + Qus[1 + NU * a] * k[1]);
     }
+    // V_ss = Q_ss + K'Quu K + K'Q_us + Q_us'K.  The gains solve (Quu + mu I)_FF K_F = -Q_us,F on the free controls (rows
+    // of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
+    //   V_ss = Q_ss + Q_us'K - mu K'K      (= Q_ss - Q_su Quu^-1 Q_us when mu = 0);
+    // the upper triangle is formed and mirrored (Q_ss symmetrised), as the kernel does.
     for (int a = 0; a < NS; ++a)
-      for (int b = 0; b < NS; ++b) {
-        Vss[a + NS * b] = Qss[a + NS * b] + (K[0 + NU * a] * QuuK[0 + NU * b] + K[1 + NU * a] * QuuK[1 + NU * b]) +
-                          (K[0 + NU * a] * Qus[0 + NU * b] + K[1 + NU * a] * Qus[1 + NU * b]) +
-                          (Qus[0 + NU * a] * K[0 + NU * b] + Qus[1 + NU * a] * K[1 + NU * b]);
+      for (int b = a; b < NS; ++b) {
+        double v = 0.5 * (Qss[a + NS * b] + Qss[b + NS * a]) + (Qus[0 + NU * a] * K[0 + NU * b] + Qus[1 + NU * a] * K[1 + NU * b]);
+        if (mu != 0.0) v -= mu * (K[0 + NU * a] * K[0 + NU * b] + K[1 + NU * a] * K[1 + NU * b]);
+        Vss[a + NS * b] = v; Vss[b + NS * a] = v;
       }
-    for (int a = 0; a < NS; ++a)  // keep it symmetric
-      for (int b = a + 1; b < NS; ++b) { const double m = 0.5 * (Vss[a + NS * b] + Vss[b + NS * a]); Vss[a + NS * b] = m; Vss[b + NS * a] = m; }
   }
   return true;
 }

@@ -45,7 +45,7 @@ class DwaConfig(C.Structure):
 
 class FrenetConfig(C.Structure):
     _fields_ = ([(k, C.c_double) for k in ("max_speed", "max_accel", "max_curvature", "max_road_width", "d_road_w", "dt", "maxt",
-                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int), ("single_d_push", C.c_int)] +
+                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int)] +
                 [(k, C.c_double) for k in ("robot_radius", "kj", "kt", "kd", "klat", "klon")])
 
 
@@ -62,6 +62,8 @@ _CP = C.POINTER(Course)
 # name -> (restype, argtypes); every symbol include/crx.h declares.
 _SIGNATURES = {
     "crx_version": (_I, []),
+    "crx_init": (_I, []),
+    "crx_shutdown": (_I, []),
     "crx_device_count": (_I, []),
     "crx_last_error": (C.c_char_p, []),
     "crx_ekf_default_params": (None, [C.POINTER(EkfParams)]),
@@ -156,6 +158,8 @@ def check(rc, what):
 
 
 def require_cuda(*tensors):
+    """Every tensor handed to a *_dev entry point: on the device, contiguous, float32 or int32 (the kernels reinterpret the
+    bytes as float4/float2/int — any other dtype would be silently misread) and 16-byte aligned (vector loads)."""
     import torch
     if not torch.cuda.is_available():
         raise CrxError("no HIP device visible: crx has no CPU fallback")
@@ -166,6 +170,24 @@ def require_cuda(*tensors):
             raise CrxError("crx *_dev entry points need device tensors")
         if not t.is_contiguous():
             raise CrxError("crx needs contiguous tensors")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise CrxError(f"crx needs float32 (or int32 index) tensors, got {t.dtype}")
+        if t.numel() and t.data_ptr() % 16:
+            raise CrxError("crx needs 16-byte aligned tensors (got an offset view; .clone() it)")
+
+
+def expect(name, t, kind, *shape, optional=False):
+    """Shape/dtype contract of one argument: kind 'f' = float32, 'i' = int32; shape entries may be None (any)."""
+    import torch
+    if t is None:
+        if optional:
+            return
+        raise CrxError(f"{name}: missing")
+    want = torch.float32 if kind == "f" else torch.int32
+    if t.dtype != want:
+        raise CrxError(f"{name}: expected {want}, got {t.dtype}")
+    if len(shape) != t.dim() or any(s is not None and int(s) != int(d) for s, d in zip(shape, t.shape)):
+        raise CrxError(f"{name}: expected shape {tuple('*' if s is None else s for s in shape)}, got {tuple(t.shape)}")
 
 
 def ptr(t):

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/crx.h"
 #include "dare_kernels.hip.h"
@@ -80,7 +81,20 @@ struct DevBuf {
 
 extern "C" {
 
-int crx_version(void) { return 100; }  // 0.1.0
+int crx_version(void) { return 200; }  // 0.2.0
+
+// The engine keeps no global state: crx_init only checks that a device is there and forces the HIP runtime + code object to
+// load now rather than in the first timed call; crx_shutdown drains the device.  Both are optional.
+int crx_init(void) {
+  if (int rc = check_device()) return rc;
+  CRX_HIP(hipFree(nullptr));
+  return CRX_OK;
+}
+int crx_shutdown(void) {
+  if (crx_device_count() == 0) return CRX_OK;
+  CRX_HIP(hipDeviceSynchronize());
+  return CRX_OK;
+}
 
 int crx_device_count(void) {
   int n = 0;
@@ -388,9 +402,8 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  return crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, iter_block()) == hipSuccess
-             ? CRX_OK
-             : hip_fail(hipGetLastError(), "mpc launch");
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, iter_block());
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
 
 int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
@@ -587,7 +600,7 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   for (int t = 0; t < loop->max_ticks; ++t) {
     hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, grid, block, 0, s, n, T, state, cv, dl, p.dt, nsearch, target_ind, xref,
                        (const int*)active);
-    if (crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, iter_block()) != hipSuccess) return hip_fail(hipGetLastError(), "mpc launch");
+    if (const hipError_t e = crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, iter_block())) return hip_fail(e, "mpc launch");
     hipLaunchKernelGGL(crx::mpc_tick_tail_kernel, grid, block, 0, s, n, T, t, state, sol, vp, loop->goal_x, loop->goal_y,
                        loop->goal_dis, active, ticks_done, traj_hist);
   }
@@ -717,7 +730,7 @@ int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, floa
       (n && (!px || !pw || !xEst || !PEst)) || (n && T && (!nobs || !u || !nrm || !uni || (L && !obs))))
     return fail(CRX_ERR_INVALID, "pf_run: bad argument (np must be 64, 100 or 128)");
   if (int rc = check_device()) return rc;
-  if (n == 0) return CRX_OK;
+  if (n == 0 || T == 0) return CRX_OK;                  // no tick: px, pw, xEst, PEst stay as they are
   crx_pf_params q;
   if (prm) q = *prm; else crx_pf_default_params(&q);
   const crx::PfParams p{q.rsim0, q.rsim1, q.Q, q.dt, q.nth > 0.0f ? q.nth : (float)(np / 2)};
@@ -772,7 +785,7 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
 // ---------------------------------------------------------------------------------------------
 namespace {
 
-// host mirror of cubic_spline.h's Spline: coefficients of one coordinate over the knots s (cubic_spline.h:54-66,:91-116)
+// host mirror of cubic_spline.h's Spline: coefficients of one coordinate over the knots s (cubic_spline.h:53-65,:95-116)
 void spline1d_build(const float* x, const float* y, int nx, float* a, float* b, float* c, float* d) {
   std::vector<float> h(nx - 1);
   for (int i = 1; i < nx; ++i) h[i - 1] = x[i] - x[i - 1];
@@ -801,7 +814,7 @@ void spline1d_build(const float* x, const float* y, int nx, float* a, float* b, 
   b[nx - 1] = 0.0f; d[nx - 1] = 0.0f;
 }
 
-int host_bisect(const float* x, float t, int start, int end) {   // cubic_spline.h:118-128
+int host_bisect(const float* x, float t, int start, int end) {   // cubic_spline.h:118-127
   for (;;) {
     const int mid = (start + end) / 2;
     if (t == x[mid] || end - start <= 1) return mid;
@@ -845,7 +858,7 @@ extern "C" {
 void crx_frenet_default_config(crx_frenet_config* c) {
   if (!c) return;
   c->max_speed = 50.0 / 3.6; c->max_accel = 2.0; c->max_curvature = 1.0; c->max_road_width = 7.0; c->d_road_w = 1.0;
-  c->dt = 0.2; c->maxt = 5.0; c->mint = 4.0; c->target_speed = 30.0 / 3.6; c->d_t_s = 5.0 / 3.6; c->n_s_sample = 1; c->single_d_push = 0;
+  c->dt = 0.2; c->maxt = 5.0; c->mint = 4.0; c->target_speed = 30.0 / 3.6; c->d_t_s = 5.0 / 3.6; c->n_s_sample = 1;
   c->robot_radius = 1.5; c->kj = 0.1; c->kt = 0.1; c->kd = 1.0; c->klat = 1.0; c->klon = 1.0;
 }
 

@@ -15,6 +15,18 @@
 // Verified against the host libm: atanf and tanf on all 2^32 inputs, atan2f on a 3 x 2^32-point
 // structured sweep (tests/tools/fdlibm_exhaustive.cpp; tests/test_fdlibm.py runs a strided subset).
 // (The constants were cross-checked against the .rodata of the libm.so.6 in this image.)
+//
+// Notice carried over from the fdlibm sources this restates (s_atanf.c, e_atan2f.c, k_tanf.c, s_tanf.c, e_rem_pio2f.c):
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
+// (float conversions of those files by Ian Lance Taylor, Cygnus Support; glibc's tanf argument reduction is glibc's own,
+// LGPL-2.1-or-later — restated here from its published description, not copied.)
 #pragma once
 #include <stdint.h>
 #include "crx_trig.h"

@@ -17,6 +17,12 @@
 // domain; tests/test_trig.py runs a strided subset plus the 34 discriminating inputs).
 //
 // Nothing in here touches memory besides two small constant tables.
+//
+// Origin of the algorithm and constants: Arm Optimized Routines, math/sinf.c, cosf.c, sincosf.h, sincosf_data.c —
+//   Copyright (c) 2018, Arm Limited.  SPDX-License-Identifier: MIT
+// as incorporated into glibc 2.28+ (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h; LGPL-2.1-or-later).
+// This header is an independent restatement of that published algorithm for host + gfx950; the notice above is kept as the
+// MIT licence asks.
 #pragma once
 #include <stdint.h>
 

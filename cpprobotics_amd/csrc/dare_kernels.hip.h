@@ -42,8 +42,12 @@ struct TreeSum<START, 1> {
 
 template <int K, int ORD>
 __device__ __forceinline__ float sum_terms(const float (&t)[K]) {
-  if constexpr (ORD == ORD_SSE4 && K == 4) {
-    return (t[0] + t[2]) + (t[1] + t[3]);
+  if constexpr (ORD == ORD_SSE4 && K >= 4 && K < 8) {
+    // vectorised redux (redux_impl<LinearVectorizedTraversal, CompleteUnrolling>): SSE2 predux of the one product packet,
+    // then the K % 4 remaining terms (redux_novec_unroller) are added
+    const float v = (t[0] + t[2]) + (t[1] + t[3]);
+    if constexpr (K == 4) return v;
+    else return v + TreeSum<4, K - 4>::run(t);
   } else if constexpr (ORD == ORD_TREE || ORD == ORD_SSE4) {
     return TreeSum<0, K>::run(t);
   } else {
@@ -83,13 +87,14 @@ __device__ __forceinline__ void inverse2(const float* m, float* r) {
 }
 
 // ---------- dense 5x5 ------------------------------------------------------------------------
-// Eigen order for 5-row shapes: every product falls on the coefficient path (TREE).
+// Eigen order for 5-row shapes: every product falls on the coefficient path; the redux is vectorised (SSE4: one packet +
+// the fifth term) where the left factor is a transposed view (A'*X, B'*X), the unrolled tree (TREE) elsewhere.
 __device__ __forceinline__ void dare5_dense_iter(const float* A, const float* B, const float* Q,
                                                  const float* R, const float* X, float* Xn) {
   float AtX[25], P1[25], BtX[10], G[4], Sg[4], Si[4], c1[10], c2[10], c3[25], c4[25], P2[25];
-  mm<5, 5, 5, true, false, ORD_TREE>(A, X, AtX);
+  mm<5, 5, 5, true, false, ORD_SSE4>(A, X, AtX);
   mm<5, 5, 5, false, false, ORD_TREE>(AtX, A, P1);
-  mm<2, 5, 5, true, false, ORD_TREE>(B, X, BtX);
+  mm<2, 5, 5, true, false, ORD_SSE4>(B, X, BtX);
   mm<2, 5, 2, false, false, ORD_TREE>(BtX, B, G);
 #pragma unroll
   for (int i = 0; i < 4; ++i) Sg[i] = R[i] + G[i];
@@ -106,7 +111,7 @@ __device__ __forceinline__ void dare5_dense_iter(const float* A, const float* B,
 __device__ __forceinline__ void dlqr5_dense_gain(const float* A, const float* B, const float* R,
                                                  const float* X, float* Kout) {
   float BtX[10], G[4], Sg[4], Si[4], BtXA[10];
-  mm<2, 5, 5, true, false, ORD_TREE>(B, X, BtX);
+  mm<2, 5, 5, true, false, ORD_SSE4>(B, X, BtX);
   mm<2, 5, 2, false, false, ORD_TREE>(BtX, B, G);
 #pragma unroll
   for (int i = 0; i < 4; ++i) Sg[i] = G[i] + R[i];

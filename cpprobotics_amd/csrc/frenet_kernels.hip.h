@@ -9,19 +9,18 @@
 // of an episode are fused: plan -> hand the winner's second sample over as the new state -> goal test.
 //
 // Replaces, for n independent agents sharing one course and one obstacle set,
-// /root/reference/src/frenet_optimal_trajectory.cpp: calc_frenet_paths :52-106, calc_global_paths :108-142,
-// check_collision :144-154, check_paths :156-164, frenet_optimal_planning :166-182, main loop :224-236; with
-// /root/reference/include/quintic_polynomial.h:34-62, quartic_polynomial.h:33-60 and the Spline evaluation of
-// cubic_spline.h:68-84,:118-128 (the spline coefficients are built once per course on the host, crx_frenet_spline_build).
+// /root/reference/src/frenet_optimal_trajectory.cpp: calc_frenet_paths :51-100, calc_global_paths :102-136,
+// check_collision :138-148, check_paths :150-158, frenet_optimal_planning :160-176, main loop :224-236; with
+// /root/reference/include/quintic_polynomial.h:39-69, quartic_polynomial.h:37-64 and the Spline evaluation of
+// cubic_spline.h:67-83,:118-127 (the spline coefficients are built once per course on the host, crx_frenet_spline_build).
 //
 // Arithmetic contract (tolerance parity, 1e-5 — see DESIGN.md §5e): every expression keeps the reference's C++ types
 // (float members, double macros, std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in
 // float).  Differences from the CPU oracle are confined to (a) pow(t,k) formed by exact-operand double products instead
 // of libm pow and (b) the double sin/cos (<= 1 ulp) — each can move a float result by one ulp only when the double lands
 // within 2^-29 of a rounding boundary.  The 3x3 / 2x2 coefficient solves are the oracle's cofactor expression, in double.
-// Reference quirks that decide the numbers are kept (the doubled fp.d push, the missing factor 5 in the quintic's first
-// derivative, maxima starting at FLT_MIN; FrenetCfg::single_d_push = 1 — off by default, not the reference — pushes
-// once); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
+// Reference quirks that decide the numbers are kept (the missing factor 5 in the quintic's first derivative,
+// quintic_polynomial.h:53; maxima starting at FLT_MIN); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
 // throw (s before the course) the path is dropped and status bit 2 is set.
 //
 // State per agent: (s0, c_speed, c_d, c_d_d, c_d_dd).  History row: (s0, c_speed, c_d, c_d_d, c_d_dd, x, y, cf).
@@ -35,7 +34,7 @@ namespace crx {
 
 struct FrenetCfg {   // the #defines :20-38, as the double expressions they expand to
   double max_speed, max_accel, max_curvature, max_road_width, d_road_w, dt, maxt, mint, target_speed, d_t_s;
-  int n_s_sample, single_d_push;
+  int n_s_sample;
   double robot_radius, kj, kt, kd, klat, klon;
 };
 
@@ -106,7 +105,7 @@ __device__ __forceinline__ float fr_q4_d2(const FrQuartic& q, float t, const FrP
 }
 __device__ __forceinline__ float fr_q4_d3(const FrQuartic& q, float t) { return 6.0f * q.a3 + 24.0f * q.a4 * t; }
 
-// Spline::bisect, cubic_spline.h:118-128, iteratively
+// Spline::bisect, cubic_spline.h:118-127, iteratively
 __device__ __forceinline__ int fr_bisect(const float* __restrict__ x, float t, int start, int end) {
   for (;;) {
     const int mid = (start + end) / 2;
@@ -121,7 +120,7 @@ __device__ __forceinline__ int fr_bisect(const float* __restrict__ x, float t, i
 // maxima and jerk sum, the hand-over samples and how many points lie on the course; phase B, one lane per (combo, time
 // step): the course position and the unit normal's (cos, sin) there (spline lookup, atan2f, double sincos), stored in an
 // LDS table; phase C, one lane per candidate: the lateral quintic and the walk along the table.
-struct FrTab { float px, py; double cs, sn; };   // poi[0], poi[1], cos(iyaw + pi/2), sin(iyaw + pi/2)   :115-119
+struct FrTab { float px, py; double cs, sn; };   // poi[0], poi[1], cos(iyaw + pi/2), sin(iyaw + pi/2)   :108-112
 
 // Four waves per SIMD (128 VGPRs, a few spilled) beat the compiler's preferred two by 1.5x on the side bench: the kernel is
 // bound by per-wave instruction issue, so resident waves are what fills the VALU.
@@ -189,7 +188,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
         c_Js += sddd_i * sddd_i;
         c_sd_last = sd_i;
         if (i == 1) { c_s1 = s_i; c_sd1 = sd_i; }
-        if (walking) {                                                            // :111-114
+        if (walking) {                                                            // :105-107
           if (s_i >= s_back) walking = false;
           else if (s_i < s_front) { walking = false; c_drop = 1; st |= 4; }
           else c_npts = i + 1;
@@ -219,7 +218,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
     }
     __builtin_amdgcn_wave_barrier();
     // ---- phase C: one candidate per lane ---------------------------------------------------------------------------
-    float my_cost = FLT_MAX;          // min_cost :173
+    float my_cost = FLT_MAX;          // min_cost :167
     int my_idx = -1, my_valid = 0;
     float w_d1 = 0, w_dd1 = 0, w_ddd1 = 0, w_x1 = 0, w_y1 = 0;
     for (int p0 = 0; p0 < P; p0 += 64) {
@@ -242,17 +241,16 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       unsigned dmin = 0x7f800000u;                   // smallest squared obstacle distance so far (float bits), from +inf
       const FrTab* __restrict__ row = tab + c * ntt;
       for (int i = 0; i < nt; ++i) {
-        // lateral samples :59-65; fp.d holds every sample twice, so entry i is the sample at t[i/2]
+        // lateral samples :58-64: one entry of d, d_d, d_dd, d_ddd per time step
         const float dddd_i = fr_q5_d3(lat, s_t[i], s_pw[i]);
         Jp += dddd_i * dddd_i;
-        if (i < npts) {                                                            // calc_global_paths :110-122
-          const int id = g.single_d_push ? i : (i >> 1);
-          const float d_i = fr_q5_point(lat, s_t[id], s_pw[id]);
+        if (i < npts) {                                                            // calc_global_paths :104-116
+          const float d_i = fr_q5_point(lat, s_t[i], s_pw[i]);
           const FrTab f = row[i];
           const float x = (float)((double)f.px + (double)d_i * f.cs);
           const float y = (float)((double)f.py + (double)d_i * f.sn);
           if (i == 1) { d1 = d_i; x1 = x; y1 = y; }
-          // check_collision :144-154: `dist <= ROBOT_RADIUS^2` for some (point, obstacle) <=> the smallest dist passes.
+          // check_collision :138-148: `dist <= ROBOT_RADIUS^2` for some (point, obstacle) <=> the smallest dist passes.
           // dist is a sum of squares (never -0): the minimum is taken on the bit patterns as unsigned integers — the float
           // order, with every NaN above +inf, i.e. ignored exactly as a failed comparison is.
           for (int k = 0; k < nob; ++k) {
@@ -261,7 +259,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
             const unsigned db = __float_as_uint(dist);
             dmin = db < dmin ? db : dmin;
           }
-          if (i >= 1) {                                                            // headings, lengths, curvature :124-141, sliding
+          if (i >= 1) {                                                            // headings, lengths, curvature :118-135, sliding
             const float gx = x - px, gy = y - py;
             const float yaw = atan2f_(gy, gx), ds = sqrtf(gx * gx + gy * gy);
             if (i >= 2) { const float cc = (yaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }
@@ -270,7 +268,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
           px = x; py = y;
         }
       }
-      if (npts >= 2) { const float cc = (pyaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }   // the appended copy of the last heading :129-130
+      if (npts >= 2) { const float cc = (pyaw - pyaw) / pds; if (cc > max_curv) max_curv = cc; }   // the appended copy of the last heading :123-124
       const bool dropped = drop || npts < 2;
       const bool collide = (double)__uint_as_float(dmin) <= r2;
       const float dsp = (float)(g.target_speed - (double)sd_last);                               // :89
@@ -278,12 +276,12 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       const float cv = (float)((g.kj * (double)Js + g.kt * (double)Ti) + g.kd * (double)dsp);
       const float cf = (float)(g.klat * (double)cd + g.klon * (double)cv);
       const bool ok = !dropped && (double)max_speed < g.max_speed && (double)max_accel < g.max_accel &&
-                      (double)max_curv < g.max_curvature && !collide;                            // :159
+                      (double)max_curv < g.max_curvature && !collide;                            // :153
       if (path_cf && p < path_cap) path_cf[a * path_cap + p] = cf;
       if (path_ok && p < path_cap) path_ok[a * path_cap + p] = ok ? 1 : 0;
       if (ok) {
         ++my_valid;
-        if (my_cost >= cf) {                                                                     // :176 (within a lane the candidates come in generation order)
+        if (my_cost >= cf) {                                                                     // :170 (within a lane the candidates come in generation order)
           my_cost = cf; my_idx = p;
           w_d1 = d1; w_dd1 = dd1; w_ddd1 = ddd1; w_x1 = x1; w_y1 = y1;
         }

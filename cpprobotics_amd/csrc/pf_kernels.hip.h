@@ -4,10 +4,10 @@
 // fused: the particle set lives in registers (LDS only while resampling), inputs stream in, xEst streams out.
 //
 // Replaces, for n independent vehicles, /root/reference/src/particle_filter.cpp:
-//   motion_model :25-39, gauss_likelihood :50-54, calc_covariance :56-68, pf_localization :70-108,
-//   cumsum :110-117, resampling :119-150.
+//   motion_model :26-40, gauss_likelihood :53-57, calc_covariance :59-71, pf_localization :73-109,
+//   cumsum :111-118, resampling :120-148.
 // Random numbers are inputs (the reference draws them from std::mt19937 inside these functions): nrm [T][n][NP][2]
-// standard normals for the motion noise (:86-87), uni [T][n][NP] uniforms in [1,2) for the resampling (:134, uni_d{1,2}).
+// standard normals for the motion noise (:87-88), uni [T][n][NP] uniforms in [1,2) for the resampling (:133, uni_d{1,2}).
 //
 // Parity is statistical / tolerance-based by construction: per-particle arithmetic follows the
 // reference statement by statement (double promotions included, cosf/sinf glibc-exact), but expf is OCML's and the
@@ -103,25 +103,25 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
   const float4* pxa = reinterpret_cast<const float4*>(px) + a * NP;
   if (v0) { x0 = pxa[p0]; w0 = pw[a * NP + p0]; }
   if (v1) { x1 = pxa[p1]; w1 = pw[a * NP + p1]; }
-  const float sig = sqrtf(p.Q);                                              // std::sqrt(Q) :99
-  const double lik_c = 1.0 / sqrt(2.0 * 3.141592653 * (double)sig * (double)sig);   // 1.0 / std::sqrt(2.0*PI*sigma*sigma) :51
+  const float sig = sqrtf(p.Q);                                              // std::sqrt(Q) :98
+  const double lik_c = 1.0 / sqrt(2.0 * 3.141592653 * (double)sig * (double)sig);   // 1.0 / std::sqrt(2.0*PI*sigma*sigma) :54
   const float lik_d = 2 * sig * sig;                                          // (2 * sigma * sigma), float
   float4 xe = make_float4(0, 0, 0, 0);
   float Pe[10];
   int nres = 0;
 
   auto advance = [&](float4& x, float& w, const float2 nz, const float u0, const float u1, const float* Z, int nob) {
-    const float ud0 = (float)((double)u0 + (double)nz.x * (double)p.rsim0);   // :86-87
+    const float ud0 = (float)((double)u0 + (double)nz.x * (double)p.rsim0);   // :87-88
     const float ud1 = (float)((double)u1 + (double)nz.y * (double)p.rsim1);
     float sn, cs;
-    sincosf_(x.z, &sn, &cs);                                                  // motion_model :25-39
+    sincosf_(x.z, &sn, &cs);                                                  // motion_model :26-40
     const float b0 = (float)(p.dt * (double)cs), b1 = (float)(p.dt * (double)sn), b2 = (float)p.dt;
     x = make_float4(x.x + b0 * ud0, x.y + b1 * ud0, x.z + b2 * ud1, x.w + ud0);
-    for (int i = 0; i < nob; ++i) {                                           // :91-99
+    for (int i = 0; i < nob; ++i) {                                           // :92-99
       const float dx = x.x - Z[3 * i + 1], dy = x.y - Z[3 * i + 2];
       const float prez = sqrtf(dx * dx + dy * dy);
       const float dz = prez - Z[3 * i];
-      const float pl = (float)(lik_c * (double)expf(-dz * dz / lik_d));        // gauss_likelihood :50-54
+      const float pl = (float)(lik_c * (double)expf(-dz * dz / lik_d));        // gauss_likelihood :53-57
       w = w * pl;
     }
   };
@@ -129,20 +129,20 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
   for (int t = 0; t < T; ++t) {
     const size_t o = (size_t)t * n + a;
     const float u0 = u[2 * o], u1 = u[2 * o + 1];
-    const int nob = nobs[o];
+    const int nob = min(max(nobs[o], 0), L);                 // a caller passing nobs > L would read past its obs rows
     const float* Z = obs + o * (size_t)L * 3;
     const float2* nz = reinterpret_cast<const float2*>(nrm) + o * NP;
     if (v0) advance(x0, w0, nz[p0], u0, u1, Z, nob);
     if (v1) advance(x1, w1, nz[p1], u0, u1, Z, nob);
-    // pw = pw / pw.sum()  :103
+    // pw = pw / pw.sum()  :104
     const float s = wave_sum(w0 + w1);
     w0 = w0 / s; w1 = w1 / s;
-    // xEst = px * pw  :105
+    // xEst = px * pw  :106
     xe.x = wave_sum(x0.x * w0 + x1.x * w1);
     xe.y = wave_sum(x0.y * w0 + x1.y * w1);
     xe.z = wave_sum(x0.z * w0 + x1.z * w1);
     xe.w = wave_sum(x0.w * w0 + x1.w * w1);
-    // calc_covariance :56-68 (symmetric: 10 sums)
+    // calc_covariance :59-71 (symmetric: 10 sums)
     {
       const float d0[4] = {x0.x - xe.x, x0.y - xe.y, x0.z - xe.z, x0.w - xe.w};
       const float d1[4] = {x1.x - xe.x, x1.y - xe.y, x1.z - xe.z, x1.w - xe.w};
@@ -153,12 +153,12 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
         for (int r = 0; r <= c; ++r) Pe[k++] = wave_sum((w0 * d0[r]) * d0[c] + (v1 ? (w1 * d1[r]) * d1[c] : 0.0f));
     }
     if (x_hist && lane == 0) reinterpret_cast<float4*>(x_hist)[o] = xe;
-    // resampling :119-150
+    // resampling :120-148
     const float ww = wave_sum(w0 * w0 + w1 * w1);
     const float Neff = (float)(1.0 / (double)ww);
     if (Neff < p.nth) {                                   // wave-uniform
       ++nres;
-      float c0 = wave_scan_add(w0, lane);                 // cumsum :110-117 (particles 0..63, then 64..NP-1)
+      float c0 = wave_scan_add(w0, lane);                 // cumsum :111-118 (particles 0..63, then 64..NP-1)
       const float tot0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c0), 63));
       float c1 = wave_scan_add(w1, lane) + tot0;
       if (v0) { s_wc[wv][p0] = c0; s_x[wv][p0] = x0; }
@@ -166,8 +166,8 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xc07f);                 // lgkmcnt(0): LDS writes of this wave visible to its own reads
       const float* un = uni + o * NP;
-      auto pick = [&](int pidx) -> int {                  // smallest ind with !(resampleid > wcum[ind]), capped at NP-1 (:140-142)
-        const float rid = (float)((double)s_base[pidx] + (double)un[pidx] / NP);   // :134
+      auto pick = [&](int pidx) -> int {                  // smallest ind with !(resampleid > wcum[ind]), capped at NP-1 (:139-141)
+        const float rid = (float)((double)s_base[pidx] + (double)un[pidx] / NP);   // :133
         int lo = 0, hi = NP - 1;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
@@ -183,7 +183,7 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
       i1 = i1 > m0 ? i1 : m0;
       if (v0) x0 = s_x[wv][i0];
       if (v1) x1 = s_x[wv][i1];
-      w0 = v0 ? inv : 0.0f; w1 = v1 ? inv : 0.0f;         // pw = Ones * 1.0/NP  :148
+      w0 = v0 ? inv : 0.0f; w1 = v1 ? inv : 0.0f;         // pw = Ones * 1.0/NP  :146
       __builtin_amdgcn_wave_barrier();
     }
   }

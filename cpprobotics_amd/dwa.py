@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's dynamic-window planner, batched over n agents (one agent per wavefront).
 
-/root/reference/src/dynamic_window_approach.cpp: dwa_control :148-155 and the main loop :190-192 / goal test :225.
+/root/reference/src/dynamic_window_approach.cpp: dwa_control :148-155 and the main loop :192-194 / goal test :225.
 state [n,5] = (x, y, yaw, v, yawrate), u [n,2], goal [n,2], ob [nob,2] — float32 CUDA tensors.
 """
 import ctypes as C
@@ -19,6 +19,7 @@ def dwa_run(state, u, goal, ob, max_ticks, config=None, want_hist=False):
     import torch
     L.require_cuda(state, u, goal, ob)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 5); L.expect("u", u, "f", n, 2); L.expect("goal", goal, "f", n, 2); L.expect("ob", ob, "f", None, 2)
     i32 = lambda: torch.zeros((n,), dtype=torch.int32, device=state.device)
     ticks, status, best, ns = i32(), i32(), i32(), i32()
     hist = torch.zeros((max_ticks, n, 5), dtype=torch.float32, device=state.device) if want_hist else None

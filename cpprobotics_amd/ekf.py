@@ -43,6 +43,7 @@ def motion_model(x, u, dt=0.1, out=None):
     import torch
     L.require_cuda(x, u, out)
     n = x.shape[0]
+    L.expect("x", x, "f", n, 4); L.expect("u", u, "f", n, 2); L.expect("out", out, "f", n, 4, optional=True)
     out = torch.empty_like(x) if out is None else out
     p = _params(dt)
     L.check(L.lib().crx_motion_model_batch_dev(n, L.ptr(x), L.ptr(u), L.ptr(out), C.byref(p), L.stream_ptr()),
@@ -55,6 +56,7 @@ def jacobF(x, u, dt=0.1):
     import torch
     L.require_cuda(x, u)
     n = x.shape[0]
+    L.expect("x", x, "f", n, 4); L.expect("u", u, "f", n, 2)
     out = torch.empty((n, 16), dtype=torch.float32, device=x.device)
     p = _params(dt)
     L.check(L.lib().crx_jacobF_batch_dev(n, L.ptr(x), L.ptr(u), L.ptr(out), C.byref(p), L.stream_ptr()),
@@ -67,6 +69,7 @@ def observation_model(x):
     import torch
     L.require_cuda(x)
     n = x.shape[0]
+    L.expect("x", x, "f", n, 4)
     out = torch.empty((n, 2), dtype=torch.float32, device=x.device)
     L.check(L.lib().crx_observation_model_batch_dev(n, L.ptr(x), L.ptr(out), L.stream_ptr()),
             "crx_observation_model_batch_dev")
@@ -84,6 +87,7 @@ def ekf_estimation(xEst, PEst, z, u, Q, R, dt=0.1):
     """ekf_estimation(xEst, PEst, z, u, Q, R) :64-78 — xEst [n,4] and PEst [n,16] updated IN PLACE."""
     L.require_cuda(xEst, PEst, z, u)
     n = xEst.shape[0]
+    L.expect("xEst", xEst, "f", n, 4); L.expect("PEst", PEst, "f", n, 16); L.expect("z", z, "f", n, 2); L.expect("u", u, "f", n, 2)
     q, r = _qr(Q, R)
     p = _params(dt)
     L.check(L.lib().crx_ekf_step_batch_dev(n, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u),
@@ -97,7 +101,8 @@ def ekf_run(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None, P_hist=None):
     P_hist [T,n,16] are optional outputs.  xEst/PEst updated in place."""
     L.require_cuda(xEst, PEst, z, u, x_hist, P_hist)
     T, n = z.shape[0], xEst.shape[0]
-    assert z.shape[1] == n and u.shape[0] == T and u.shape[1] == n
+    L.expect("xEst", xEst, "f", n, 4); L.expect("PEst", PEst, "f", n, 16); L.expect("z", z, "f", T, n, 2); L.expect("u", u, "f", T, n, 2)
+    L.expect("x_hist", x_hist, "f", T, n, 4, optional=True); L.expect("P_hist", P_hist, "f", T, n, 16, optional=True)
     q, r = _qr(Q, R)
     p = _params(dt)
     L.check(L.lib().crx_ekf_run_batch_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist),
@@ -117,6 +122,8 @@ def ekf_simulate_inputs(u_true, xTrue, xDR, w, dt=0.1, qsim=QSIM, rsim=RSIM, xTr
     import torch
     L.require_cuda(u_true, xTrue, xDR, w, xTrue_hist, xDR_hist)
     T, n = w.shape[0], w.shape[1]
+    L.expect("w", w, "f", T, n, 4); L.expect("u_true", u_true, "f", n, 2); L.expect("xTrue", xTrue, "f", n, 4); L.expect("xDR", xDR, "f", n, 4)
+    L.expect("xTrue_hist", xTrue_hist, "f", T, n, 4, optional=True); L.expect("xDR_hist", xDR_hist, "f", T, n, 4, optional=True)
     z = torch.empty((T, n, 2), dtype=torch.float32, device=w.device)
     ud = torch.empty((T, n, 2), dtype=torch.float32, device=w.device)
     q = L.host_floats(qsim, 2)

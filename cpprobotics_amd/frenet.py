@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's Frenet optimal-trajectory planner, batched over n agents (one agent per wavefront).
 
-/root/reference/src/frenet_optimal_trajectory.cpp: frenet_optimal_planning :166-182 and the main loop :224-236;
+/root/reference/src/frenet_optimal_trajectory.cpp: frenet_optimal_planning :160-176 and the main loop :224-236;
 /root/reference/include/cubic_spline.h: Spline2D :130-187 (built once per course on the host).
 state [n,5] = (s0, c_speed, c_d, c_d_d, c_d_dd), ob [nob,2] — float32 CUDA tensors; the course is a `FrenetCourse`.
 """
@@ -62,6 +62,7 @@ def frenet_run(state, course, ob, max_ticks, config=None, want_hist=False, want_
     import torch
     L.require_cuda(state, ob)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 5); L.expect("ob", ob, "f", None, 2)
     c = config if config is not None else frenet_default_config()
     i32 = lambda: torch.zeros((n,), dtype=torch.int32, device=state.device)
     ticks, status, best, nv = i32(), i32(), i32(), i32()

@@ -23,6 +23,7 @@ def _dare(A, B, Q, R, eps, maxiter, want_X, want_K):
     L.require_cuda(A, B, Q, R)
     n = A.shape[0]
     dim, m = _dims(A)
+    L.expect("A", A, "f", n, dim * dim); L.expect("B", B, "f", n, dim * m); L.expect("Q", Q, "f", n, dim * dim); L.expect("R", R, "f", n, m * m)
     X = torch.empty((n, dim * dim), dtype=torch.float32, device=A.device) if want_X else None
     K = torch.empty((n, m * dim), dtype=torch.float32, device=A.device) if want_K else None
     iters = torch.empty((n,), dtype=torch.int32, device=A.device)
@@ -53,6 +54,9 @@ def _from_v(v, dim, dt, Lw, eps, maxiter, want_X, want_K):
     import torch
     L.require_cuda(v)
     n = v.shape[0]
+    L.expect("v", v, "f", n)
+    if dim not in (4, 5):
+        raise L.CrxError("dim must be 4 or 5")
     m = 2 if dim == 5 else 1
     X = torch.empty((n, dim * dim), dtype=torch.float32, device=v.device) if want_X else None
     K = torch.empty((n, m * dim), dtype=torch.float32, device=v.device) if want_K else None

@@ -23,7 +23,7 @@ def mpc_solve(x0, xref, T, params=None, return_status=False):
     import torch
     L.require_cuda(x0, xref)
     n = x0.shape[0]
-    assert xref.shape[0] == n and xref.shape[1] == 4 * T
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
     p = params if params is not None else default_params()
     sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
     status = torch.empty((n,), dtype=torch.int32, device=x0.device)

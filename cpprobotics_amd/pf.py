@@ -1,6 +1,6 @@
 """Host-side mirror of the reference's particle-filter localisation, batched over n vehicles.
 
-/root/reference/src/particle_filter.cpp: pf_localization :70-108 + resampling :119-150, T fused ticks per launch,
+/root/reference/src/particle_filter.cpp: pf_localization :73-109 + resampling :120-148, T fused ticks per launch,
 one vehicle per wavefront.  All tensors float32 CUDA (nobs int32):
   px [n,NP,4], pw [n,NP] (updated in place), obs [T,n,L,3], nobs [T,n], u [T,n,2], nrm [T,n,NP,2], uni [T,n,NP].
 """
@@ -21,6 +21,8 @@ def pf_run(px, pw, obs, nobs, u, nrm, uni, params=None, want_hist=True):
     L.require_cuda(px, pw, obs, nobs, u, nrm, uni)
     n, NP = px.shape[0], px.shape[1]
     T, Lm = u.shape[0], obs.shape[2]
+    L.expect("px", px, "f", n, NP, 4); L.expect("pw", pw, "f", n, NP); L.expect("obs", obs, "f", T, n, Lm, 3); L.expect("nobs", nobs, "i", T, n)
+    L.expect("u", u, "f", T, n, 2); L.expect("nrm", nrm, "f", T, n, NP, 2); L.expect("uni", uni, "f", T, n, NP)
     xEst = torch.empty((n, 4), dtype=torch.float32, device=px.device)
     PEst = torch.empty((n, 16), dtype=torch.float32, device=px.device)
     hist = torch.empty((T, n, 4), dtype=torch.float32, device=px.device) if want_hist else None

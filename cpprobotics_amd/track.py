@@ -20,9 +20,8 @@ class Course:
     def __init__(self, cx, cy, cyaw, ck, sp):
         L.require_cuda(cx, cy, cyaw, ck, sp)
         n = cx.shape[0]
-        for t in (cy, cyaw, ck, sp):
-            if t.shape[0] != n:
-                raise L.CrxError("course arrays must have the same length")
+        for name, t in (("cx", cx), ("cy", cy), ("cyaw", cyaw), ("ck", ck), ("sp", sp)):
+            L.expect(name, t, "f", n)
         self.tensors = (cx, cy, cyaw, ck, sp)
         self.n = n
         self.c = L.Course(n, cx.data_ptr(), cy.data_ptr(), cyaw.data_ptr(), ck.data_ptr(), sp.data_ptr())
@@ -56,6 +55,7 @@ def calc_nearest_index(state, course, ind=None):
     import torch
     L.require_cuda(state, ind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("ind", ind, "i", n, optional=True)
     if ind is None:
         ind = torch.zeros((n,), dtype=torch.int32, device=state.device)
     e = torch.empty((n,), dtype=torch.float32, device=state.device)
@@ -70,6 +70,7 @@ def lqr_steering_control(state, course, pe, pth_e, dim=5, ind=None, dt=0.1, L_wh
     import torch
     L.require_cuda(state, pe, pth_e, ind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("pe", pe, "f", n); L.expect("pth_e", pth_e, "f", n); L.expect("ind", ind, "i", n, optional=True)
     if ind is None:
         ind = torch.zeros((n,), dtype=torch.int32, device=state.device)
     control = torch.empty((n, 2) if dim == 5 else (n,), dtype=torch.float32, device=state.device)
@@ -83,6 +84,8 @@ def lqr_steering_control(state, course, pe, pth_e, dim=5, ind=None, dt=0.1, L_wh
 def update(state, a, delta, params=None):
     """update(state, a, delta), in place."""
     L.require_cuda(state, a, delta)
+    n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("a", a, "f", n); L.expect("delta", delta, "f", n)
     p = params if params is not None else vehicle_params()
     L.check(L.lib().crx_update_batch_dev(state.shape[0], L.ptr(state), L.ptr(a), L.ptr(delta), C.byref(p), L.stream_ptr()),
             "crx_update_batch_dev")
@@ -103,6 +106,8 @@ def closed_loop_prediction(state, course, goal, dim=5, max_ticks=500, goal_dis=N
     import torch
     L.require_cuda(state, pe, pth_e, ind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("pe", pe, "f", n, optional=True); L.expect("pth_e", pth_e, "f", n, optional=True)
+    L.expect("ind", ind, "i", n, optional=True)
     if goal_dis is None:
         goal_dis = 0.3 if dim == 5 else 0.5
     ticks = torch.zeros((n,), dtype=torch.int32, device=state.device)
@@ -120,6 +125,7 @@ def calc_nearest_index_window(state, course, pind, nsearch=10):
     import torch
     L.require_cuda(state, pind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("pind", pind, "i", n)
     out = torch.empty((n,), dtype=torch.int32, device=state.device)
     L.check(L.lib().crx_calc_nearest_index_window_batch_dev(n, L.ptr(state), course.ref(), L.ptr(pind), int(nsearch), L.ptr(out),
                                                             L.stream_ptr()), "crx_calc_nearest_index_window_batch_dev")
@@ -131,6 +137,7 @@ def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10
     import torch
     L.require_cuda(state, target_ind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("target_ind", target_ind, "i", n)
     xref = torch.empty((n, 4 * T), dtype=torch.float32, device=state.device)
     L.check(L.lib().crx_calc_ref_trajectory_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), float(dt), int(nsearch),
                                                       L.ptr(target_ind), L.ptr(xref), L.stream_ptr()),
@@ -146,6 +153,7 @@ def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, n
     from .mpc import default_params
     L.require_cuda(state, target_ind)
     n = state.shape[0]
+    L.expect("state", state, "f", n, 4); L.expect("target_ind", target_ind, "i", n, optional=True)
     if target_ind is None:
         target_ind = torch.zeros((n,), dtype=torch.int32, device=state.device)
     p = params if params is not None else default_params()

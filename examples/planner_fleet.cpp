@@ -1,14 +1,10 @@
 // planner_fleet.cpp — the reference's two sampling planners for a whole fleet, in C++ against the C ABI:
-//   * Frenet optimal-trajectory planner, src/frenet_optimal_trajectory.cpp main() :184-236, on its own course and obstacles;
-//   * dynamic-window planner, src/dynamic_window_approach.cpp main() :158-226, on its own obstacle field.
+//   * Frenet optimal-trajectory planner, src/frenet_optimal_trajectory.cpp main() :186-236, on its own course and obstacles;
+//   * dynamic-window planner, src/dynamic_window_approach.cpp main() :166-238, on its own obstacle field.
 // One agent per wavefront, the whole episode of every agent in ONE kernel launch each.
 //
 //   hipcc -O2 -I include examples/planner_fleet.cpp -o planner_fleet -L cpprobotics_amd -lcrx -Wl,-rpath,$PWD/cpprobotics_amd
 //   ./planner_fleet [n=4096]
-//
-// The Frenet part runs twice: as the reference is written (fp.d pushed twice per time step, :60-61 — the lateral state
-// never moves and the reference's own start runs out of collision-free candidates after 48 ticks, where the reference
-// would index an empty path) and with crx_frenet_config.single_d_push = 1, which reaches the goal.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -51,10 +47,9 @@ int main(int argc, char** argv) {
   int *d_ticks = nullptr, *d_status = nullptr;
   HIP_OK(hipMalloc(&d_ticks, 4 * (size_t)n)); HIP_OK(hipMalloc(&d_status, 4 * (size_t)n));
   if (!d_coef || !d_ob) return 2;
-  for (int push = 0; push < 2; ++push) {
+  {
     crx_frenet_config cfg;
     crx_frenet_default_config(&cfg);
-    cfg.single_d_push = push;
     float* d_state = upload(st0);
     if (!d_state) return 2;
     const auto t0 = std::chrono::steady_clock::now();
@@ -67,14 +62,13 @@ int main(int argc, char** argv) {
     HIP_OK(hipMemcpy(status.data(), d_status, 4 * (size_t)n, hipMemcpyDeviceToHost));
     long plans = 0; int reached = 0;
     for (int a = 0; a < n; ++a) { plans += ticks[a]; reached += (status[a] & 1) == 0 && ticks[a] < 500; }
-    std::printf("Frenet (single_d_push=%d): %d agents, %ld planning calls in %.2f ms (%.2f M plans/s); agent 0: %d ticks, status %d; "
-                "%d agents reached the goal\n", push, n, plans, sec * 1e3, plans / sec / 1e6, ticks[0], status[0], reached);
-    if (push == 0 && !(status[0] & 1)) rc = 4;          // as written, the reference's own start dead-ends
-    if (push == 1 && (status[0] != 0 || ticks[0] >= 500)) rc = 4;
+    std::printf("Frenet: %d agents, %ld planning calls in %.2f ms (%.2f M plans/s); agent 0: %d ticks, status %d; "
+                "%d agents reached the goal\n", n, plans, sec * 1e3, plans / sec / 1e6, ticks[0], status[0], reached);
+    if (status[0] != 0 || ticks[0] >= 500) rc = 4;      // the reference's own start (agent 0) must reach the goal
     HIP_OK(hipFree(d_state));
   }
 
-  // ---- dynamic window: State x :161, goal :162, obstacles :164-175, Config :25-41
+  // ---- dynamic window: State x :167, goal :168, obstacles :169-180, Config :25-41
   const std::vector<float> dob{-1, -1, 0, 2, 4.0f, 2.0f, 5.0f, 4.0f, 5.0f, 5.0f, 5.0f, 6.0f, 5.0f, 9.0f, 8.0f, 9.0f, 7.0f, 9.0f, 12.0f, 12.0f};
   std::uniform_real_distribution<float> jit(-0.3f, 0.3f);
   std::vector<float> dst(5 * (size_t)n), du(2 * (size_t)n, 0.0f), dgoal(2 * (size_t)n);

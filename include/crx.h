@@ -38,6 +38,8 @@ typedef enum crx_status {
 
 /* ---- runtime ------------------------------------------------------------------------- */
 int crx_version(void);                 /* 10000*major + 100*minor + patch                 */
+int crx_init(void);                    /* optional: device check + runtime warm-up         */
+int crx_shutdown(void);                /* optional: hipDeviceSynchronize                   */
 int crx_device_count(void);            /* number of HIP devices visible (0 if none)       */
 const char* crx_last_error(void);      /* thread-local, never NULL                        */
 
@@ -243,12 +245,12 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
 
 
 /* ---- particle-filter localisation (src/particle_filter.cpp) ---------------------------------
- * pf_localization (:70-108) + resampling (:119-150) for n vehicles, T fused ticks, NP particles each (NP <= 128; the
+ * pf_localization (:73-109) + resampling (:120-148) for n vehicles, T fused ticks, NP particles each (NP <= 128; the
  * reference's `#define NP 100`).  One vehicle per wavefront.  The random numbers the reference draws from std::mt19937
  * inside these functions are inputs here.  Device pointers:
  *   px [n][NP][4] in/out (Eigen::Matrix<float,4,NP> column-major), pw [n][NP] in/out, xEst [n][4] out, PEst [n][16] out,
- *   obs [T][n][L][3] = (noisy range, landmark x, landmark y) with nobs [T][n] <= L valid rows (:252-261),
- *   u [T][n][2], nrm [T][n][NP][2] standard normals (:86-87), uni [T][n][NP] uniforms in [1,2) (:134, uni_d{1.0,2.0}),
+ *   obs [T][n][L][3] = (noisy range, landmark x, landmark y) with nobs [T][n] <= L valid rows (:258-267),
+ *   u [T][n][2], nrm [T][n][NP][2] standard normals (:87-88), uni [T][n][NP] uniforms in [1,2) (:133, uni_d{1.0,2.0} :242),
  *   x_hist [T][n][4] (may be NULL), n_resampled [n] (may be NULL; incremented by the number of resampling ticks).
  * Parity with the reference is statistical / tolerance-based: see pf_kernels.hip.h. */
 typedef struct crx_pf_params {
@@ -264,7 +266,7 @@ int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, floa
 
 
 /* ---- dynamic-window planner (src/dynamic_window_approach.cpp) -----------------------------------
- * The reference's main loop (:190-192, goal test :225) for n agents, max_ticks control steps at most, ONE AGENT PER
+ * The reference's main loop (:192-194, goal test :221) for n agents, max_ticks control steps at most, ONE AGENT PER
  * WAVEFRONT: per tick dwa_control (calc_dynamic_window, every (v, yawrate) sample rolled out and scored, the reference's
  * winner picked) -> motion -> goal test.  max_ticks = 1 is a single dwa_control + motion.
  * state [n][5] = (x, y, yaw, v, yawrate) in/out; u [n][2] in/out; goal [n][2]; ob [nob][2] shared (nob <= 256);
@@ -281,10 +283,10 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
 
 /* ---- Frenet optimal-trajectory planner (src/frenet_optimal_trajectory.cpp) --------------------------
  * The reference's main loop (:224-236) for n agents sharing one course and one obstacle set, ONE AGENT PER WAVEFRONT: per
- * tick frenet_optimal_planning (calc_frenet_paths :52-106 -> calc_global_paths :108-142 -> check_paths :156-164 -> the
- * cheapest survivor :173-180), the winner's second sample handed over as the new state, the goal test (:232).
+ * tick frenet_optimal_planning (calc_frenet_paths :51-100 -> calc_global_paths :102-136 -> check_paths :150-158 -> the
+ * cheapest survivor :167-174), the winner's second sample handed over as the new state, the goal test (:232).
  * max_ticks = 1 is a single planning call.  Tolerance parity (1e-5), see DESIGN.md 5e.
- *   coef  [9][nx]   the course's Spline2D (include/cubic_spline.h:130-187) as a coefficient table: rows s, then a,b,c,d of
+ *   coef  [9][nx]   the course's Spline2D (include/cubic_spline.h:130-178) as a coefficient table: rows s, then a,b,c,d of
  *                   sx, then a,b,c,d of sy (b and d have nx-1 entries, the last column is padding); device pointer for
  *                   the _dev call; built on the host by crx_frenet_spline_build (2 <= nx <= 64)
  *   state [n][5]    (s0, c_speed, c_d, c_d_d, c_d_dd) in/out          ob [nob][2] shared, nob <= 128
@@ -296,12 +298,9 @@ int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const fl
  *   path_cf / path_ok   (may be NULL) [n][path_cap] every candidate's cost and check_paths verdict in the last tick */
 typedef struct crx_frenet_config {   /* the #defines :20-38, as the double expressions they expand to */
   double max_speed, max_accel, max_curvature, max_road_width, d_road_w, dt, maxt, mint, target_speed, d_t_s;
-  int n_s_sample, single_d_push;
+  int n_s_sample;
   double robot_radius, kj, kt, kd, klat, klon;
 } crx_frenet_config;
-/* single_d_push: 0 (default) = the reference, whose calc_frenet_paths pushes fp.d twice per time step (:60-61) so that d[i]
- * is the lateral offset at t[i/2] and main's c_d = d[1] never moves; 1 = one push per step (d[i] at t[i]).  With 0 the
- * reference's own scenario runs out of collision-free candidates after 48 ticks (status bit 0). */
 void crx_frenet_default_config(crx_frenet_config* c);
 /* number of candidate paths the configuration generates, or a negative crx error if it exceeds the kernel's grids
  * (<= 64 lateral offsets, horizons x target speeds <= 64, <= 64 time steps, horizons x speeds x time steps <= 2048) */

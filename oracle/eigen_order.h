@@ -10,27 +10,38 @@
 // arch/SSE/PacketMath.h), not an execution of them.
 //
 // Eigen 3.3.9, x86-64 baseline (SSE2, no FMA: the reference sets no -march,
-// CMakeLists.txt:4-6), float, all dimensions < 8  =>  every `A*B` is a coefficient-based
-// lazy product evaluated into a temporary; `A*B*C` is `(A*B)*C`.  How one coefficient
-// sum_k A(i,k)*B(k,j) is accumulated depends on how the destination is traversed:
+// CMakeLists.txt:4-6; packet = 4 floats), float, all dimensions < 8  =>  every `A*B` is a
+// coefficient-based lazy product evaluated into a plain temporary (column-major, except that a
+// 1xN row vector is row-major); `A*B*C` is `(A*B)*C`.  How one coefficient sum_k A(i,k)*B(k,j)
+// is accumulated is decided by product_evaluator's enums and the assignment traversal
+// (product_order() below states the decision generically; r, c, k = rows, cols, inner size;
+// a factor is "row-major" if it is a .transpose() of a column-major object or a plain row vector):
 //
-//  (P) packet path — destination column-major with rows % 4 == 0 and a column-major
-//      (non-transposed) left factor: etor_product_packet_impl walks k upward,
+//   CanVectorizeLhs = lhs column-major && r % 4 == 0        CanVectorizeRhs = rhs row-major && c % 4 == 0
+//   EvalToRowMajor  = (r == 1 && c != 1) ? 1 : (c == 1 && r != 1) ? 0 : (rhs row-major && !CanVectorizeLhs)
+//   the assignment into the temporary uses packets iff the product has PacketAccessBit (either CanVectorize*),
+//   its storage order agrees with the temporary's, and the temporary's inner size is a multiple of 4.
+//
+//  (P) packet assignment: etor_product_packet_impl walks k upward,
 //      res = A(:,0)*B(0,j); res = A(:,k)*B(k,j) + res    (pmul, then pmul+padd)
 //      => per coefficient: (((t0 + t1) + t2) + t3) ...            "ASC"
 //  (C) coefficient path — anything else: coeff(i,j) =
 //      (lhs.row(i).transpose().cwiseProduct(rhs.col(j))).sum()
-//      (C1) if the left factor is a transposed (row-major) matrix, the right one column-major
-//           and the inner size is a multiple of 4, that .sum() is vectorised: one pmul of the
-//           two packets, then SSE2 predux: (t0 + t2) + (t1 + t3)     "SSE4"
-//           (inner size 8 would add the two product packets first; not needed here)
+//      (C1) the redux is vectorised (LinearVectorizedTraversal, complete unrolling) when the row of lhs AND the
+//           column of rhs are both contiguous (Block's MaskPacketAccessBit: lhs row-major, rhs column-major) and
+//           k >= 4: the k/4 product packets are added pairwise by redux_vec_unroller (halves), the result is reduced
+//           by the SSE2 predux (p0 + p2) + (p1 + p3), and the k % 4 remaining terms — summed by
+//           redux_novec_unroller — are added last.  k = 4: (t0 + t2) + (t1 + t3); k = 5: ((t0+t2)+(t1+t3)) + t4.   "VEC"
+//           (Round 1 applied this only for k = 4 and used (C2) for k = 5; re-derived from
+//           redux_impl<Func, Derived, LinearVectorizedTraversal, CompleteUnrolling> in round 2 — matters only for
+//           dense 5x5 inputs through A'*X and B'*X, never on the reference's own sparse A, B.)
 //      (C2) otherwise the redux is fully unrolled by redux_novec_unroller, which splits the
 //           range in halves recursively: sum(s,len) = sum(s,len/2) + sum(s+len/2,len-len/2)
 //           e.g. 5 terms: (t0 + t1) + (t2 + (t3 + t4))                "TREE"
 //
 // For the reference's call sites every sum that falls on path (C) has at most two non-zero
 // terms (the factors involved are the 0/1 selection matrix jH, or A/B with one or two
-// non-zeros per row/column), so ASC, SSE4 and TREE give identical results there — the tests
+// non-zeros per row/column), so ASC, VEC and TREE give identical results there — the tests
 // check that claim by running the oracle in all-ASC mode as well.
 #pragma once
 #include <cstring>
@@ -55,40 +66,65 @@ Mat<C, R> transpose(const Mat<R, C>& a) {
   return t;
 }
 
-inline float tree_sum(const float* t, int start, int len) {
+enum ProductOrder { PO_ASC = 0, PO_VEC = 1, PO_TREE = 2 };
+
+// The decision described in the header, for fixed sizes.
+inline ProductOrder product_order(int r, int c, int k, bool lhs_rm, bool rhs_rm) {
+  const bool can_vec_lhs = !lhs_rm && (r % 4 == 0);
+  const bool can_vec_rhs = rhs_rm && (c % 4 == 0);
+  const bool eval_rm = (r == 1 && c != 1) ? true : (c == 1 && r != 1) ? false : (rhs_rm && !can_vec_lhs);
+  const bool dst_rm = (r == 1 && c != 1);
+  const int inner = dst_rm ? c : r;
+  if ((can_vec_lhs || can_vec_rhs) && eval_rm == dst_rm && inner % 4 == 0) return PO_ASC;
+  if (lhs_rm && !rhs_rm && k >= 4) return PO_VEC;
+  return PO_TREE;
+}
+
+template <class S>
+inline S tree_sum(const S* t, int start, int len) {
   if (len == 1) return t[start];
   int half = len / 2;
-  float a = tree_sum(t, start, half);
-  float b = tree_sum(t, start + half, len - half);
+  S a = tree_sum(t, start, half);
+  S b = tree_sum(t, start + half, len - half);
   return a + b;
+}
+template <class S>
+inline void packet_tree(const S* t, int start, int npk, S out[4]) {   // redux_vec_unroller
+  if (npk == 1) { for (int l = 0; l < 4; ++l) out[l] = t[4 * start + l]; return; }
+  const int half = npk / 2;
+  S a[4], b[4];
+  packet_tree(t, start, half, a);
+  packet_tree(t, start + half, npk - half, b);
+  for (int l = 0; l < 4; ++l) out[l] = a[l] + b[l];
+}
+template <class S>
+inline S accumulate(const S* t, int k, ProductOrder o) {
+  if (k == 0) return S(0);
+  if (o == PO_ASC) { S s = t[0]; for (int i = 1; i < k; ++i) s = s + t[i]; return s; }
+  if (o == PO_VEC) {
+    const int npk = k / 4;
+    S p[4];
+    packet_tree(t, 0, npk, p);
+    S res = (p[0] + p[2]) + (p[1] + p[3]);                       // SSE2 predux
+    if (npk * 4 != k) res = res + tree_sum(t, npk * 4, k - npk * 4);
+    return res;
+  }
+  return tree_sum(t, 0, k);
 }
 
 // lhs_transposed / rhs_transposed: whether the factor, AS WRITTEN IN THE REFERENCE
-// EXPRESSION, is a `.transpose()` view of a stored (column-major) matrix.  A and B here
-// are already the logical (R x K) and (K x C) factors.
+// EXPRESSION, is row-major: a `.transpose()` view of a stored (column-major) matrix, or a
+// row-vector temporary.  A and B here are already the logical (R x K) and (K x C) factors.
 template <int R, int K, int C>
 Mat<R, C> mul(const Mat<R, K>& A, const Mat<K, C>& B, bool lhs_transposed, bool rhs_transposed,
               SumOrder order) {
   Mat<R, C> out;
-  // column-major packet path (CanVectorizeLhs), or — both factors transposed views — the
-  // row-major packet path (CanVectorizeRhs with EvalToRowMajor); both accumulate k upward.
-  const bool packet_path = ((R % 4 == 0) && !lhs_transposed) ||
-                           (lhs_transposed && rhs_transposed && (C % 4 == 0) && (C != 1));
-  const bool sse_inner = lhs_transposed && !rhs_transposed && (K % 4 == 0);
+  const ProductOrder po = (order == ORDER_ASC) ? PO_ASC : product_order(R, C, K, lhs_transposed, rhs_transposed);
   for (int j = 0; j < C; ++j)
     for (int i = 0; i < R; ++i) {
       float t[K];
       for (int k = 0; k < K; ++k) t[k] = A(i, k) * B(k, j);
-      float s;
-      if (order == ORDER_ASC || packet_path) {
-        s = t[0];
-        for (int k = 1; k < K; ++k) s = s + t[k];
-      } else if (sse_inner && K == 4) {
-        s = (t[0] + t[2]) + (t[1] + t[3]);
-      } else {
-        s = tree_sum(t, 0, K);
-      }
-      out(i, j) = s;
+      out(i, j) = accumulate(t, K, po);
     }
   return out;
 }

@@ -3,16 +3,12 @@
 // tests or golden vectors for this path and needs Eigen + OpenCV to build, neither of which is in this image).
 //
 // Follows /root/reference/src/frenet_optimal_trajectory.cpp:
-//   calc_frenet_paths :52-106, calc_global_paths :108-142, check_collision :144-154, check_paths :156-164,
-//   frenet_optimal_planning :166-182, main loop :224-236 (state hand-over and goal test),
-// and /root/reference/include/quintic_polynomial.h:34-62, quartic_polynomial.h:33-60, cubic_spline.h:54-128 (Spline),
-// :134-187 (Spline2D).  Every expression keeps the reference's C++ types: float members, the DT/MAX_* macros as double
+//   calc_frenet_paths :51-100, calc_global_paths :102-136, check_collision :138-148, check_paths :150-158,
+//   frenet_optimal_planning :160-176, main loop :224-236 (state hand-over and goal test),
+// and /root/reference/include/quintic_polynomial.h:39-69, quartic_polynomial.h:37-64, cubic_spline.h:39-128 (Spline),
+// :130-178 (Spline2D).  Every expression keeps the reference's C++ types: float members, the DT/MAX_* macros as double
 // literals, std::pow(float,int) and std::cos(float+double) evaluated in double, std::atan2/std::sqrt of floats in float.
 // Things the reference does that a reader might take for typos are kept, because they decide the numbers:
-//   * calc_frenet_paths pushes fp.d TWICE per time step (:60-61), so d[i] used by calc_global_paths and by main's
-//     c_d = final_path.d[1] is the lateral offset at time t[i/2]
-//     (FrenetCfg::single_d_push = 1, NOT the reference's behaviour and off by default, pushes once: with the doubled
-//     push c_d never changes and the reference's own scenario runs out of collision-free candidates at tick 48);
 //   * QuinticPolynomial::calc_first_derivative ends in a5*t^4, not 5*a5*t^4 (quintic_polynomial.h:53);
 //   * max_speed / max_accel / max_curvature start at numeric_limits<float>::min() (the smallest positive normal).
 // One deliberate difference, stated in DESIGN.md §5e: the reference solves the 3x3 / 2x2 / nx x nx float systems with
@@ -31,7 +27,7 @@ namespace {
 
 struct FrenetCfg {   // the #defines :20-38, as the double expressions they expand to
   double max_speed, max_accel, max_curvature, max_road_width, d_road_w, dt, maxt, mint, target_speed, d_t_s;
-  int n_s_sample, single_d_push;
+  int n_s_sample;
   double robot_radius, kj, kt, kd, klat, klon;
 };
 
@@ -55,7 +51,7 @@ void solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
   }
 }
 
-struct Spline {   // cubic_spline.h:40-128
+struct Spline {   // cubic_spline.h:39-128
   std::vector<float> x, a, b, c, d;
   int nx = 0;
   Spline() {}
@@ -63,7 +59,7 @@ struct Spline {   // cubic_spline.h:40-128
     std::vector<float> h(nx - 1);
     for (int i = 1; i < nx; ++i) h[i - 1] = x[i] - x[i - 1];
     std::vector<double> A((size_t)nx * nx, 0.0), B(nx, 0.0);
-    A[0] = 1.0;                                                     // calc_A :91-106 (float entries)
+    A[0] = 1.0;                                                     // calc_A :95-109 (float entries)
     for (int i = 0; i < nx - 1; ++i) {
       if (i != nx - 2) A[(i + 1) * nx + i + 1] = (double)(2 * (h[i] + h[i + 1]));
       A[(i + 1) * nx + i] = h[i];
@@ -72,40 +68,40 @@ struct Spline {   // cubic_spline.h:40-128
     A[1] = 0.0;
     A[(nx - 1) * nx + nx - 2] = 0.0;
     A[(nx - 1) * nx + nx - 1] = 1.0;
-    for (int i = 0; i < nx - 2; ++i)                                 // calc_B :107-113 (double expression, float entry)
+    for (int i = 0; i < nx - 2; ++i)                                 // calc_B :110-116 (double expression, float entry)
       B[i + 1] = (double)(float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
     solve_dense(nx, A, B);
     c.resize(nx);
     for (int i = 0; i < nx; ++i) c[i] = (float)B[i];
-    for (int i = 0; i < nx - 1; ++i) {                               // :62-65
+    for (int i = 0; i < nx - 1; ++i) {                               // :61-64
       d.push_back((float)((c[i + 1] - c[i]) / (3.0 * h[i])));
       b.push_back((float)((a[i + 1] - a[i]) / h[i] - h[i] * (c[i + 1] + 2 * c[i]) / 3.0));
     }
   }
-  int bisect(float t, int start, int end) const {                    // :118-128
+  int bisect(float t, int start, int end) const {                    // :118-127
     const int mid = (start + end) / 2;
     if (t == x[mid] || end - start <= 1) return mid;
     else if (t > x[mid]) return bisect(t, mid, end);
     else return bisect(t, start, mid);
   }
-  float calc(float t) const {                                        // :68-75
+  float calc(float t) const {                                        // :67-74
     const int seg = bisect(t, 0, nx);
     const float dx = t - x[seg];
     return a[seg] + b[seg] * dx + c[seg] * dx * dx + d[seg] * dx * dx * dx;
   }
-  float calc_d(float t) const {                                      // :77-84
+  float calc_d(float t) const {                                      // :76-83
     const int seg = bisect(t, 0, nx - 1);
     const float dx = t - x[seg];
     return b[seg] + 2 * c[seg] * dx + 3 * d[seg] * dx * dx;
   }
 };
 
-struct Spline2D {   // :130-187
+struct Spline2D {   // :130-178
   Spline sx, sy;
   std::vector<float> s;
   Spline2D() {}
   Spline2D(const std::vector<float>& x, const std::vector<float>& y) {
-    s.push_back(0.0f);                                               // calc_s :172-186
+    s.push_back(0.0f);                                               // calc_s :164-177
     float temp = 0;
     for (size_t i = 1; i < x.size(); ++i) {
       const float dx = x[i] - x[i - 1], dy = y[i] - y[i - 1];
@@ -158,7 +154,7 @@ void solve2(const float A[2][2], const float B[2], float x[2]) {
   x[1] = (float)((a00 * b1 - a10 * b0) / det);
 }
 
-struct Quintic {   // quintic_polynomial.h:34-62
+struct Quintic {   // quintic_polynomial.h:39-69
   float a0, a1, a2, a3, a4, a5;
   Quintic(float xs, float vxs, float axs, float xe, float vxe, float axe, float T) : a0(xs), a1(vxs), a2((float)(axs / 2.0)) {
     const float A[3][3] = {{(float)std::pow(T, 3), (float)std::pow(T, 4), (float)std::pow(T, 5)},
@@ -175,7 +171,7 @@ struct Quintic {   // quintic_polynomial.h:34-62
   float calc_third_derivative(float t) const { return (float)(6 * a3 + 24 * a4 * t + 60 * a5 * std::pow(t, 2)); }
 };
 
-struct Quartic {   // quartic_polynomial.h:33-60
+struct Quartic {   // quartic_polynomial.h:37-64
   float a0, a1, a2, a3, a4;
   Quartic(float xs, float vxs, float axs, float vxe, float axe, float T) : a0(xs), a1(vxs), a2((float)(axs / 2.0)) {
     const float A[2][2] = {{(float)(3 * std::pow(T, 2)), (float)(4 * std::pow(T, 3))}, {6 * T, (float)(12 * std::pow(T, 2))}};
@@ -204,7 +200,7 @@ float sum_of_power(const std::vector<float>& v) {   // :42-48
   return sum;
 }
 
-std::vector<FrenetPath> calc_frenet_paths(const FrenetCfg& g, float c_speed, float c_d, float c_d_d, float c_d_dd, float s0) {   // :52-106
+std::vector<FrenetPath> calc_frenet_paths(const FrenetCfg& g, float c_speed, float c_d, float c_d_d, float c_d_dd, float s0) {   // :51-100
   std::vector<FrenetPath> fp_list;
   for (float di = (float)(-1 * g.max_road_width); di < g.max_road_width; di += g.d_road_w) {
     for (float Ti = (float)g.mint; Ti < g.maxt; Ti += g.dt) {
@@ -213,7 +209,6 @@ std::vector<FrenetPath> calc_frenet_paths(const FrenetCfg& g, float c_speed, flo
       for (float t = 0; t < Ti; t += g.dt) {
         fp.t.push_back(t);
         fp.d.push_back(lat_qp.calc_point(t));
-        if (!g.single_d_push) fp.d.push_back(lat_qp.calc_point(t));     // twice, as the reference :60-61
         fp.d_d.push_back(lat_qp.calc_first_derivative(t));
         fp.d_dd.push_back(lat_qp.calc_second_derivative(t));
         fp.d_ddd.push_back(lat_qp.calc_third_derivative(t));
@@ -244,7 +239,7 @@ std::vector<FrenetPath> calc_frenet_paths(const FrenetCfg& g, float c_speed, flo
   return fp_list;
 }
 
-int calc_global_paths(std::vector<FrenetPath>& path_list, const Spline2D& csp) {   // :108-142
+int calc_global_paths(std::vector<FrenetPath>& path_list, const Spline2D& csp) {   // :102-136
   int st = 0;
   for (FrenetPath& p : path_list) {
     for (size_t i = 0; i < p.s.size(); ++i) {
@@ -275,7 +270,7 @@ int calc_global_paths(std::vector<FrenetPath>& path_list, const Spline2D& csp) {
   return st;
 }
 
-bool check_collision(const FrenetCfg& g, const FrenetPath& path, const float* ob, int nob) {   // :144-154
+bool check_collision(const FrenetCfg& g, const FrenetPath& path, const float* ob, int nob) {   // :138-148
   for (int k = 0; k < nob; ++k)
     for (size_t i = 0; i < path.x.size(); ++i) {
       const float dist = (float)(std::pow((path.x[i] - ob[2 * k]), 2) + std::pow((path.y[i] - ob[2 * k + 1]), 2));
@@ -289,7 +284,7 @@ struct PlanOut {
   float cf = 0, s1 = 0, d1 = 0, d_d1 = 0, d_dd1 = 0, s_d1 = 0, x1 = 0, y1 = 0;
 };
 
-// frenet_optimal_planning :166-182 (+ check_paths :156-164); path_cf / path_ok (may be null) receive every path's cost
+// frenet_optimal_planning :160-176 (+ check_paths :150-158); path_cf / path_ok (may be null) receive every path's cost
 // and whether it survived the checks, in generation order.
 PlanOut plan(const FrenetCfg& g, const Spline2D& csp, const float st5[5], const float* ob, int nob, float* path_cf, int* path_ok) {
   const float s0 = st5[0], c_speed = st5[1], c_d = st5[2], c_d_d = st5[3], c_d_dd = st5[4];

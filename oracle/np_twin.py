@@ -36,12 +36,23 @@ def _tree(t):
     return f32(_tree(t[:h]) + _tree(t[h:]))
 
 
+def _padd(ps):
+    if len(ps) == 1:
+        return ps[0]
+    m = len(ps) // 2
+    a, b = _padd(ps[:m]), _padd(ps[m:])
+    return [f32(a[l] + b[l]) for l in range(4)]
+
+
 def mul(A, B, lhs_t=False, rhs_t=False, order="eigen"):
     """A (R x K) times B (K x C), float32, one rounding per operation, Eigen's summation order."""
     R, K = A.shape
     C = B.shape[1]
-    packet = (R % 4 == 0 and not lhs_t) or (lhs_t and rhs_t and C % 4 == 0 and C != 1)
-    sse = lhs_t and (not rhs_t) and K % 4 == 0
+    can_l, can_r = (not lhs_t) and R % 4 == 0, rhs_t and C % 4 == 0
+    eval_rm = True if (R == 1 and C != 1) else False if (C == 1 and R != 1) else (rhs_t and not can_l)
+    dst_rm = R == 1 and C != 1
+    packet = (can_l or can_r) and eval_rm == dst_rm and (C if dst_rm else R) % 4 == 0
+    sse = lhs_t and (not rhs_t) and K >= 4
     out = np.zeros((R, C), dtype=f32)
     for j in range(C):
         for i in range(R):
@@ -50,8 +61,11 @@ def mul(A, B, lhs_t=False, rhs_t=False, order="eigen"):
                 s = t[0]
                 for k in range(1, K):
                     s = f32(s + t[k])
-            elif sse and K == 4:
-                s = f32(f32(t[0] + t[2]) + f32(t[1] + t[3]))
+            elif sse:                       # vectorised redux: packets pairwise (halves), SSE2 predux, then the k % 4 tail
+                p = _padd([t[4 * q:4 * q + 4] for q in range(K // 4)])
+                s = f32(f32(p[0] + p[2]) + f32(p[1] + p[3]))
+                if K % 4:
+                    s = f32(s + _tree(t[4 * (K // 4):]))
             else:
                 s = _tree(t)
             out[i, j] = s

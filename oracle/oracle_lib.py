@@ -390,13 +390,13 @@ def dwa_run(state, u, goal, max_ticks, ob=DWA_OBSTACLES, cfg=DWA_CONFIG, want_hi
 # ---- Frenet optimal trajectory (oracle/frenet_ref.cpp) -----------------------------------------------------
 class FrenetCfg(C.Structure):
     _fields_ = ([(k, C.c_double) for k in ("max_speed", "max_accel", "max_curvature", "max_road_width", "d_road_w", "dt", "maxt",
-                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int), ("single_d_push", C.c_int)] +
+                                           "mint", "target_speed", "d_t_s")] + [("n_s_sample", C.c_int)] +
                 [(k, C.c_double) for k in ("robot_radius", "kj", "kt", "kd", "klat", "klon")])
 
 
 def frenet_config(**kw):
     """The #defines of src/frenet_optimal_trajectory.cpp:20-38."""
-    c = FrenetCfg(50.0 / 3.6, 2.0, 1.0, 7.0, 1.0, 0.2, 5.0, 4.0, 30.0 / 3.6, 5.0 / 3.6, 1, 0, 1.5, 0.1, 0.1, 1.0, 1.0, 1.0)
+    c = FrenetCfg(50.0 / 3.6, 2.0, 1.0, 7.0, 1.0, 0.2, 5.0, 4.0, 30.0 / 3.6, 5.0 / 3.6, 1, 1.5, 0.1, 0.1, 1.0, 1.0, 1.0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

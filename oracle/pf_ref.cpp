@@ -2,12 +2,12 @@
 // Nothing under cpprobotics_amd/ may include, link or call this file.
 //
 // CPU restatement of the reference's particle-filter localisation, /root/reference/src/particle_filter.cpp:
-//   motion_model :25-39 (same as the EKF's), gauss_likelihood :50-54, calc_covariance :56-68,
-//   pf_localization :70-108, cumsum :110-117, resampling :119-150, and the observation side of main() :247-263.
+//   motion_model :26-40 (same as the EKF's), gauss_likelihood :53-57, calc_covariance :59-71,
+//   pf_localization :73-109, cumsum :111-118, resampling :120-148, and the observation side of main() :248-268.
 // The reference draws its noise from std::mt19937 inside these functions (and passes the generator BY VALUE, so
 // every call replays the same stream); here all random numbers are caller-supplied arrays, so that CPU and GPU
-// consume identical draws:  nrm[t][a][ip][2] standard normals (motion noise, :86-87),  uni[t][a][j] uniforms in
-// [1,2) (uni_d{1.0, 2.0} :240, used as uni/NP :134).
+// consume identical draws:  nrm[t][a][ip][2] standard normals (motion noise, :87-88),  uni[t][a][j] uniforms in
+// [1,2) (uni_d{1.0, 2.0} :242, used as uni/NP :133).
 // PARITY-UNPINNED, and statistical by construction: the reference's reductions (pw.sum(), px*pw, pw'*pw) go through
 // Eigen's vectorised redux / gemv kernels whose accumulation order is not restated here — sums below run in plain
 // index order — so the engine is compared with a tolerance, not bit for bit.
@@ -24,14 +24,14 @@ int g_trig = 0;
 inline float o_cos(float x) { return g_trig == 0 ? std::cos(x) : crx::cosf_(x); }
 inline float o_sin(float x) { return g_trig == 0 ? std::sin(x) : crx::sinf_(x); }
 
-// :25-39   x <- F*x + B*u ; B = [[DT cos, 0], [DT sin, 0], [0, DT], [1, 0]]
+// :26-40   x <- F*x + B*u ; B = [[DT cos, 0], [DT sin, 0], [0, DT], [1, 0]]
 void motion_model(float* x, const float* u, double DT) {
   const float b0 = (float)(DT * (double)o_cos(x[2])), b1 = (float)(DT * (double)o_sin(x[2])), b2 = (float)DT;
   const float n0 = x[0] + b0 * u[0], n1 = x[1] + b1 * u[0], n2 = x[2] + b2 * u[1], n3 = x[3] + u[0];
   x[0] = n0; x[1] = n1; x[2] = n2; x[3] = n3;
 }
 
-// :50-54
+// :53-57
 float gauss_likelihood(float x, float sigma) {
   float p = 1.0 / std::sqrt(2.0 * PI_ * sigma * sigma) * std::exp(-x * x / (2 * sigma * sigma));
   return p;
@@ -43,7 +43,7 @@ extern "C" {
 
 void oracle_pf_set_trig_mode(int m) { g_trig = m; }
 
-// One vehicle-tick for agents [a0,a1): pf_localization (:70-108) then resampling (:119-150).
+// One vehicle-tick for agents [a0,a1): pf_localization (:73-109) then resampling (:120-148).
 // px: [n][NP][4] (Eigen Matrix<float,4,NP> column-major = particle-major), pw: [n][NP], xEst [n][4], PEst [n][16] col-major,
 // obs: [n][L][3] = (dn, landmark x, landmark y), nobs[n] <= L, u [n][2], nrm [n][NP][2], uni [n][NP],
 // rsim[2] = (Rsim(0,0), Rsim(1,1)), Q, DT, nth = NP/2.  resampled[n] (may be NULL): 1 if the tick resampled.
@@ -56,15 +56,15 @@ void oracle_pf_step(int n, int NP, int L, float* px, float* pw, float* xEst, flo
     float* X = px + (size_t)a * NP * 4;
     float* W = pw + (size_t)a * NP;
     const float* Z = obs + (size_t)a * L * 3;
-    const float sig = std::sqrt(Q);                                   // std::sqrt(Q) :99
-    for (int ip = 0; ip < NP; ++ip) {                                 // :78
+    const float sig = std::sqrt(Q);                                   // std::sqrt(Q) :98
+    for (int ip = 0; ip < NP; ++ip) {                                 // :81
       float x[4] = {X[4 * ip], X[4 * ip + 1], X[4 * ip + 2], X[4 * ip + 3]};
       float w = W[ip];
       float ud[2];
-      ud[0] = u[2 * a] + (double)nrm[((size_t)a * NP + ip) * 2] * rsim[0];    // :86  gaussian_d(gen) is a double
+      ud[0] = u[2 * a] + (double)nrm[((size_t)a * NP + ip) * 2] * rsim[0];    // :87  gaussian_d(gen) is a double
       ud[1] = u[2 * a + 1] + (double)nrm[((size_t)a * NP + ip) * 2 + 1] * rsim[1];
-      motion_model(x, ud, DT);                                        // :89
-      for (int i = 0; i < nobs[a]; ++i) {                             // :91
+      motion_model(x, ud, DT);                                        // :90
+      for (int i = 0; i < nobs[a]; ++i) {                             // :92
         float dx = x[0] - Z[3 * i + 1];
         float dy = x[1] - Z[3 * i + 2];
         float prez = std::sqrt(dx * dx + dy * dy);
@@ -76,39 +76,39 @@ void oracle_pf_step(int n, int NP, int L, float* px, float* pw, float* xEst, flo
     }
     float s = 0.0f;
     for (int i = 0; i < NP; ++i) s += W[i];
-    for (int i = 0; i < NP; ++i) W[i] = W[i] / s;                     // pw = pw / pw.sum() :103
+    for (int i = 0; i < NP; ++i) W[i] = W[i] / s;                     // pw = pw / pw.sum() :104
     float xe[4] = {0, 0, 0, 0};
-    for (int i = 0; i < NP; ++i) for (int r = 0; r < 4; ++r) xe[r] += X[4 * i + r] * W[i];   // xEst = px * pw :105
+    for (int i = 0; i < NP; ++i) for (int r = 0; r < 4; ++r) xe[r] += X[4 * i + r] * W[i];   // xEst = px * pw :106
     float Pe[16]; std::memset(Pe, 0, sizeof(Pe));
-    for (int i = 0; i < NP; ++i) {                                    // calc_covariance :61-65
+    for (int i = 0; i < NP; ++i) {                                    // calc_covariance :64-68
       float dx[4]; for (int r = 0; r < 4; ++r) dx[r] = X[4 * i + r] - xe[r];
       for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) Pe[r + 4 * c] += (W[i] * dx[r]) * dx[c];
     }
     std::memcpy(xEst + 4 * (size_t)a, xe, sizeof(xe));
     std::memcpy(PEst + 16 * (size_t)a, Pe, sizeof(Pe));
-    // resampling :119-150
+    // resampling :120-148
     float ww = 0.0f;
     for (int i = 0; i < NP; ++i) ww += W[i] * W[i];
-    float Neff = 1.0 / ww;                                            // :125
+    float Neff = 1.0 / ww;                                            // :126
     int did = 0;
     if (anc) for (int i = 0; i < NP; ++i) anc[(size_t)a * NP + i] = i;
-    if (Neff < nth) {                                                 // :126
+    if (Neff < nth) {                                                 // :127
       did = 1;
       wcum[0] = W[0];
-      for (int i = 1; i < NP; ++i) wcum[i] = wcum[i - 1] + W[i];      // cumsum :110-117
+      for (int i = 1; i < NP; ++i) wcum[i] = wcum[i - 1] + W[i];      // cumsum :111-118
       const float inv = (float)(1.0 / NP);                            // Ones()*1.0/NP
       float c = W[0] * 0.0f + inv;                                    // pw*0.0 + Ones*1.0/NP
       base[0] = c - inv;
       for (int i = 1; i < NP; ++i) { c = c + (W[i] * 0.0f + inv); base[i] = c - inv; }
-      for (int j = 0; j < NP; ++j) rid[j] = base[j] + (double)uni[(size_t)a * NP + j] / NP;   // :134  uni_d(gen) is a double
+      for (int j = 0; j < NP; ++j) rid[j] = base[j] + (double)uni[(size_t)a * NP + j] / NP;   // :133  uni_d(gen) is a double
       int ind = 0;
-      for (int i = 0; i < NP; ++i) {                                  // :139-144
+      for (int i = 0; i < NP; ++i) {                                  // :138-143
         while (rid[i] > wcum[ind] && ind < NP - 1) ind += 1;
         std::memcpy(&out[4 * (size_t)i], &X[4 * ind], 16);
         if (anc) anc[(size_t)a * NP + i] = ind;
       }
       std::memcpy(X, out.data(), sizeof(float) * 4 * NP);
-      for (int i = 0; i < NP; ++i) W[i] = inv;                        // :148
+      for (int i = 0; i < NP; ++i) W[i] = inv;                        // :146
     }
     if (resampled) resampled[a] = did;
   }
@@ -129,7 +129,7 @@ void oracle_pf_run(int n, int NP, int L, int T, float* px, float* pw, float* xEs
   }
 }
 
-// The observation side of main() (:247-263): ud, xTrue, xDR and the range observations of the landmarks within MAX_RANGE.
+// The observation side of main() (:248-268): ud, xTrue, xDR and the range observations of the landmarks within MAX_RANGE.
 // w_u [T][n][2] normals for ud, w_z [T][n][L] normals for the range noise.  Outputs: ud [T][n][2], obs, nobs, xTrue_hist.
 void oracle_pf_simulate_inputs(int n, int T, int L, const float* u_true, float* xTrue, float* xDR, const float* rfid,
                                const float* w_u, const float* w_z, const float* rsim, float Qsim, float max_range,

@@ -1,0 +1,67 @@
+#!/bin/bash
+# oracle/ref_build.sh — TEST INFRASTRUCTURE.  Builds oracle/_ref/libref.so from the reference's OWN source lines.
+#
+#   oracle/ref_build.sh [/root/reference]
+#
+# The hot-path functions of the reference live in the translation units of its demo executables, next to main() and the OpenCV
+# drawing code, and include <Eigen/Eigen> (plus <cppad/...> for the MPC) — none of which exists in this image, and the reference's
+# own build system (cmake + find_package(Eigen3/OpenCV)) cannot run here.  So this recipe cuts the cited line ranges out of the
+# reference sources WHERE THEY LIE (sed, into oracle/_ref/gen/, which is git-ignored: no reference source enters this repository),
+# and compiles them, unmodified, inside the thin wrappers of oracle/ref_shim/*.cpp, which export them as C symbols (ref_*).
+# Headers that need nothing but Eigen (cubic_spline.h, motion_model.h, quintic/quartic_polynomial.h, frenet_path.h,
+# cpprobotics_types.h) are included directly from $REF/include.
+#   * <Eigen/Eigen>: the host's Eigen if it has one (then this is the literal reference arithmetic), otherwise the stand-in
+#     oracle/ref_shim/Eigen/Eigen, which restates Eigen 3.3.9's evaluation order (see its header).  `ref_eigen_kind()` in the
+#     library says which one was used; tests report it.
+#   * CppAD / IPOPT: oracle/ref_shim/cppad_standin.h — AD<double> = double, ipopt::solve captures the problem it is handed.
+# Flags: -std=gnu++11 as the reference's CMakeLists.txt:4 (no -march: SSE2, no FMA); -O1 -ffp-contract=off changes no result.
+set -euo pipefail
+REF=${1:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+GEN=$OUT/gen
+[ -d "$REF/src" ] || { echo "ref_build: $REF/src not found — nothing to do"; exit 0; }
+mkdir -p "$GEN"
+ext() { sed -n "$2,$3p" "$REF/$1" > "$GEN/$4"; }          # file first last out
+
+# ---- src/extended_kalman_filter.cpp
+ext src/extended_kalman_filter.cpp 16 18 ekf_defs.inc            # SIM_TIME, DT, PI
+ext src/extended_kalman_filter.cpp 21 78 ekf_fns.inc             # motion_model … ekf_estimation
+ext src/extended_kalman_filter.cpp 112 161 ekf_main_setup.inc    # u, xDR, xTrue, xEst, PEst, Q, R, Qsim, Rsim
+ext src/extended_kalman_filter.cpp 172 188 ekf_main_body.inc     # one pass of the while loop up to hz.push_back(z)
+# ---- src/lqr_speed_steer_control.cpp (5-state)
+ext src/lqr_speed_steer_control.cpp 20 30 lqr5_defs.inc          # DT, L, KP, MAX_STEER, matrix aliases
+ext src/lqr_speed_steer_control.cpp 65 164 lqr5_fns.inc          # calc_nearest_index, solve_DARE, dlqr, lqr_steering_control, update
+ext src/lqr_speed_steer_control.cpp 167 171 lqr5_loop_setup.inc  # T, goal_dis, stop_speed, State state(...)
+ext src/lqr_speed_steer_control.cpp 185 186 lqr5_loop_e.inc      # e, e_th
+ext src/lqr_speed_steer_control.cpp 195 205 lqr5_loop_body.inc   # control, update, goal test
+# ---- src/lqr_steer_control.cpp (4-state)
+ext src/lqr_steer_control.cpp 20 23 lqr4_defs.inc
+ext src/lqr_steer_control.cpp 55 146 lqr4_fns.inc               # calc_nearest_index, solve_DARE, dlqr, lqr_steering_control, update
+ext src/lqr_steer_control.cpp 149 153 lqr4_loop_setup.inc
+ext src/lqr_steer_control.cpp 167 169 lqr4_loop_e.inc            # e, e_th, ind
+ext src/lqr_steer_control.cpp 187 198 lqr4_loop_body.inc
+# ---- src/model_predictive_control.cpp
+ext src/model_predictive_control.cpp 26 48 mpc_defs.inc          # DT … WB (without NX/T, which the wrapper sets)
+ext src/model_predictive_control.cpp 50 60 mpc_globals.inc       # using …, M_XREF, x_start … a_start
+ext src/model_predictive_control.cpp 69 81 mpc_update.inc
+ext src/model_predictive_control.cpp 107 186 mpc_ref_traj.inc    # calc_nearest_index (window), calc_ref_trajectory, smooth_yaw
+ext src/model_predictive_control.cpp 188 346 mpc_nlp.inc         # FG_EVAL, mpc_solve
+ext src/model_predictive_control.cpp 349 360 mpc_sim_setup.inc   # State state(...), yaw wrap, goal_dis, target_ind, smooth_yaw
+ext src/model_predictive_control.cpp 372 385 mpc_sim_body.inc    # calc_ref_trajectory, mpc_solve, update, goal test
+
+if echo '#include <Eigen/Eigen>' | g++ -x c++ -fsyntax-only - 2>/dev/null; then EIGEN_INC=""; KIND=1
+elif [ -f /usr/include/eigen3/Eigen/Eigen ]; then EIGEN_INC="-I/usr/include/eigen3"; KIND=1
+else EIGEN_INC="-I$HERE/ref_shim"; KIND=0; fi
+CXXFLAGS="-std=gnu++11 -O1 -ffp-contract=off -fPIC -w -I$GEN -I$REF/include $EIGEN_INC -DREF_EIGEN_KIND=$KIND"
+OBJS=()
+for f in "$HERE"/ref_shim/ref_*.cpp; do
+  o="$OUT/$(basename "${f%.cpp}").o"
+  g++ $CXXFLAGS -c "$f" -o "$o"
+  OBJS+=("$o")
+done
+# the MPC unit once more for the BASELINE horizon (the reference's macro T is 6)
+g++ $CXXFLAGS -DREF_MPC_T=21 -c "$HERE/ref_shim/ref_mpc.cpp" -o "$OUT/ref_mpc_T21.o"
+# the reference headers define non-inline functions (cubic_spline.h, motion_model.h): every unit carries an identical copy
+g++ -shared -Wl,--allow-multiple-definition -o "$OUT/libref.so" "${OBJS[@]}" "$OUT/ref_mpc_T21.o" -lm
+echo "ref_build: $OUT/libref.so (Eigen: $([ $KIND = 1 ] && echo host || echo stand-in))"

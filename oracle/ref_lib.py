@@ -1,0 +1,242 @@
+"""ctypes front-end of oracle/_ref/libref.so — TEST INFRASTRUCTURE ONLY.
+
+libref.so is the reference's own source lines (cut out of /root/reference at build time by oracle/ref_build.sh) compiled
+against the host's Eigen when there is one, else against the stand-in oracle/ref_shim/Eigen/Eigen.  It is what the oracle is
+pinned against: tests/test_oracle_vs_ref.py runs both on the same inputs, tests/golden/make_ref_golden.py stores its outputs
+as fixtures for hosts that have neither /root/reference nor the built library.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "libref.so")
+_lib = None
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+
+SOLVER_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p, C.POINTER(C.c_double))
+
+
+def available():
+    return os.path.exists(_SO)
+
+
+def build(reference_root="/root/reference"):
+    """Runs oracle/ref_build.sh when the reference sources are present; returns whether libref.so exists afterwards."""
+    if os.path.isdir(os.path.join(reference_root, "src")):
+        subprocess.check_call(["bash", os.path.join(_HERE, "ref_build.sh"), reference_root], stdout=subprocess.DEVNULL)
+    return available()
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(_SO)
+        _lib.ref_eigen_kind.restype = _I
+    return _lib
+
+
+def eigen_kind():
+    return "host Eigen" if lib().ref_eigen_kind() == 1 else "stand-in (oracle/ref_shim/Eigen/Eigen)"
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+# ---- EKF (src/extended_kalman_filter.cpp) -------------------------------------------------------------------------------
+def motion_model(x, u):
+    x, u = _f32(x), _f32(u)
+    out = np.empty_like(x)
+    lib().ref_motion_model(_I(len(x)), _p(x), _p(u), _p(out))
+    return out
+
+
+def jacobF(x, u):
+    x, u = _f32(x), _f32(u)
+    out = np.empty((len(x), 16), np.float32)
+    lib().ref_jacobF(_I(len(x)), _p(x), _p(u), _p(out))
+    return out
+
+
+def observation_model(x):
+    x = _f32(x)
+    out = np.empty((len(x), 2), np.float32)
+    lib().ref_observation_model(_I(len(x)), _p(x), _p(out))
+    return out
+
+
+def jacobH():
+    out = np.empty(8, np.float32)
+    lib().ref_jacobH(_p(out))
+    return out
+
+
+def ekf_run(x, P, z, u, Q, R, want_phist=False):
+    x, P, z, u, Q, R = _f32(x).copy(), _f32(P).copy(), _f32(z), _f32(u), _f32(Q), _f32(R)
+    T, n = z.shape[0], x.shape[0]
+    xh = np.zeros((T, n, 4), np.float32)
+    ph = np.zeros((T, n, 16), np.float32) if want_phist else None
+    lib().ref_ekf_run(_I(n), _I(T), _p(x), _p(P), _p(z), _p(u), _p(xh), _p(ph), _p(Q), _p(R))
+    return x, P, xh, ph
+
+
+def ekf_main(noise):
+    """main() of the reference for len(noise) passes of its loop; noise [steps,4] = the four N(0,1) draws of each pass."""
+    w = np.ascontiguousarray(noise, dtype=np.float64)
+    s = w.shape[0]
+    o = dict(hxTrue=np.zeros((s, 4), np.float32), hxDR=np.zeros((s, 4), np.float32), hxEst=np.zeros((s, 4), np.float32),
+             hz=np.zeros((s, 2), np.float32), hud=np.zeros((s, 2), np.float32), PEst=np.zeros(16, np.float32),
+             Q=np.zeros(16, np.float32), R=np.zeros(4, np.float32), Qsim=np.zeros(4, np.float32), Rsim=np.zeros(4, np.float32))
+    lib().ref_ekf_main(_I(s), _p(w), *[_p(o[k]) for k in ("hxTrue", "hxDR", "hxEst", "hz", "hud", "PEst", "Q", "R", "Qsim", "Rsim")])
+    return o
+
+
+# ---- LQR (src/lqr_speed_steer_control.cpp, src/lqr_steer_control.cpp) ------------------------------------------------------
+def dare(A, B, Q, R):
+    """solve_DARE and dlqr of the file matching the dimension; returns (X, K)."""
+    A, B, Q, R = _f32(A), _f32(B), _f32(Q), _f32(R)
+    n = A.shape[0]
+    dim = 5 if A.shape[1] == 25 else 4
+    X = np.zeros((n, dim * dim), np.float32)
+    K = np.zeros((n, (2 if dim == 5 else 1) * dim), np.float32)
+    (lib().ref_dare5 if dim == 5 else lib().ref_dare4)(_I(n), _p(A), _p(B), _p(Q), _p(R), _p(X), _p(K))
+    return X, K
+
+
+def _course(course):
+    return tuple(_f32(a) for a in course)
+
+
+def lqr_steering_control(state, course, pe, pth_e, dim=5, ind=None):
+    state = _f32(state)
+    n = len(state)
+    cx, cy, cyaw, ck, sp = _course(course)
+    pe, pth_e = _f32(pe).copy(), _f32(pth_e).copy()
+    if dim == 5:
+        control = np.zeros((n, 2), np.float32)
+        lib().ref_lqr5_steering_control(_I(n), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp), _p(pe), _p(pth_e), _p(control))
+        return control, None, pe, pth_e
+    ind = np.zeros(n, np.int32) if ind is None else np.ascontiguousarray(ind, np.int32).copy()
+    delta = np.zeros(n, np.float32)
+    lib().ref_lqr4_steering_control(_I(n), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(ind), _p(pe), _p(pth_e), _p(delta))
+    return delta, ind, pe, pth_e
+
+
+def calc_nearest_index(state, course):
+    state = _f32(state)
+    n = len(state)
+    cx, cy, cyaw, ck, sp = _course(course)
+    ind = np.zeros(n, np.int32); e = np.zeros(n, np.float32)
+    lib().ref_lqr5_nearest_index(_I(n), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ind), _p(e))
+    return ind, e
+
+
+def lqr_update(state, a, delta):
+    state, a, delta = _f32(state).copy(), _f32(a), _f32(delta)
+    lib().ref_lqr5_update(_I(len(state)), _p(state), _p(a), _p(delta))
+    return state
+
+
+def lqr_closed_loop(state, course, goal, dim=5, max_ticks=500):
+    state = _f32(state).copy()
+    n = len(state)
+    cx, cy, cyaw, ck, sp = _course(course)
+    traj = np.zeros((max_ticks, n, 4), np.float32)
+    ticks = np.zeros(n, np.int32)
+    f = lib().ref_lqr5_closed_loop if dim == 5 else lib().ref_lqr4_closed_loop
+    f(_I(n), _I(max_ticks), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp), _F(goal[0]), _F(goal[1]), _p(traj), _p(ticks))
+    return state, ticks, traj
+
+
+# ---- MPC (src/model_predictive_control.cpp) ------------------------------------------------------------------------------
+def _mpc(T, name):
+    assert T in (6, 21), "libref is built for the reference's horizon macro T = 6 and for T = 21"
+    return getattr(lib(), f"ref_mpc{T}_{name}")
+
+
+def mpc_layout(T):
+    out = np.zeros(6, np.int32)
+    _mpc(T, "layout")(_p(out))
+    return dict(zip(("x", "y", "yaw", "v", "delta", "a"), out.tolist()))
+
+
+def mpc_fg_eval(xref, vars_, T):
+    """FG_EVAL::operator(): fg[0] = cost, fg[1:] = the 4T constraint functions, at the point vars_ (reference layout)."""
+    xref = _f32(xref); v = np.ascontiguousarray(vars_, np.float64)
+    fg = np.zeros(1 + 4 * T, np.float64)
+    _mpc(T, "fg_eval")(_p(xref), _p(v), _p(fg))
+    return fg
+
+
+def mpc_solve(x0, xref, T, solver=None):
+    """mpc_solve(): returns what it hands to IPOPT and what it returns.  solver: python callable
+    (x0[4] float64, xref[4T] float32) -> sol[n_vars] float64, standing in for IPOPT; None -> zeros."""
+    x0, xref = _f32(x0), _f32(xref)
+    nv, ng = 4 * T + 2 * (T - 1), 4 * T
+    o = dict(xi=np.zeros(nv), xl=np.zeros(nv), xu=np.zeros(nv), gl=np.zeros(ng), gu=np.zeros(ng), result=np.zeros(nv, np.float32))
+    opts = C.create_string_buffer(512)
+    cb = _wrap_solver(T, solver)
+    _mpc(T, "solve")(_p(x0), _p(xref), cb, _p(o["xi"]), _p(o["xl"]), _p(o["xu"]), _p(o["gl"]), _p(o["gu"]), _p(o["result"]), opts, _I(512))
+    o["options"] = opts.value.decode()
+    return o
+
+
+def _wrap_solver(T, solver):
+    if solver is None:
+        return C.cast(None, SOLVER_FN)
+    lay = mpc_layout(T)
+
+    def cb(n_vars, n_con, xi, xl, xu, gl, gu, ctx, x_out):
+        xref = np.zeros(4 * T, np.float32)
+        _mpc(T, "context_xref")(C.c_void_p(ctx), _p(xref))
+        x0 = np.array([gl[lay["x"]], gl[lay["y"]], gl[lay["yaw"]], gl[lay["v"]]], np.float64)
+        sol = np.asarray(solver(x0, xref), np.float64)
+        for i in range(n_vars):
+            x_out[i] = sol[i]
+    return SOLVER_FN(cb)
+
+
+def mpc_update(state, a, delta, T=6):
+    state, a, delta = _f32(state).copy(), _f32(a), _f32(delta)
+    _mpc(T, "update")(_I(len(state)), _p(state), _p(a), _p(delta))
+    return state
+
+
+def calc_nearest_index_window(state, course, pind, T=6):
+    state = _f32(state)
+    cx, cy, cyaw, ck, sp = _course(course)
+    pind = np.ascontiguousarray(pind, np.int32); out = np.zeros(len(state), np.int32)
+    _mpc(T, "nearest_index_window")(_I(len(state)), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(pind), _p(out))
+    return out
+
+
+def calc_ref_trajectory(state, course, target_ind, T, dl=1.0):
+    state = _f32(state)
+    cx, cy, cyaw, ck, sp = _course(course)
+    tind = np.ascontiguousarray(target_ind, np.int32).copy()
+    xref = np.zeros((len(state), 4 * T), np.float32)
+    _mpc(T, "calc_ref_trajectory")(_I(len(state)), _p(state), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp), _F(dl), _p(tind), _p(xref))
+    return xref, tind
+
+
+def smooth_yaw(cyaw, T=6):
+    c = _f32(cyaw).copy()
+    _mpc(T, "smooth_yaw")(_I(len(c)), _p(c))
+    return c
+
+
+def mpc_simulation(course, goal, T, max_ticks, solver):
+    cx, cy, cyaw, ck, sp = _course(course)
+    traj = np.zeros((max_ticks, 4), np.float32); ctl = np.zeros((max_ticks, 2), np.float32); cs = np.zeros(len(cx), np.float32)
+    f = _mpc(T, "simulation"); f.restype = _I
+    cb = _wrap_solver(T, solver)
+    ticks = f(_I(max_ticks), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp), _F(goal[0]), _F(goal[1]), cb, _p(traj), _p(ctl), _p(cs))
+    return ticks, traj[:ticks], ctl[:ticks], cs

@@ -17,7 +17,7 @@ import oracle.oracle_lib as O  # noqa: E402
 
 O.trig_mode = lambda: 1
 out = {}
-# ---- dynamic window: agent 0 = the reference's start (src/dynamic_window_approach.cpp:161-176) --------------------------
+# ---- dynamic window: agent 0 = the reference's start (src/dynamic_window_approach.cpp:167-181) --------------------------
 rng = np.random.default_rng(51)
 n = 12
 st = np.stack([rng.uniform(-1, 9, n), rng.uniform(-1, 9, n), rng.uniform(-3.2, 3.2, n), rng.uniform(-0.5, 1.0, n),
@@ -40,9 +40,8 @@ p = oracle.frenet_plan(fs, coef)
 out.update(fr_wx=O.FRENET_WX, fr_wy=O.FRENET_WY, fr_ob=O.FRENET_OBSTACLES, fr_coef=coef, fr_goal=np.array([rx[-1], ry[-1]], np.float32),
            fr_nsamples=np.int32(len(rx)), fr_state=fs, fr_out=p["out"], fr_best=p["best"], fr_nvalid=p["n_valid"], fr_status=p["status"],
            fr_path_cf=p["path_cf"], fr_path_ok=p["path_ok"])
-for push in (0, 1):
-    r = oracle.frenet_run(fs[:6], coef, out["fr_goal"], 120, cfg=oracle.frenet_config(single_d_push=push), want_hist=True)
-    out[f"fr_run{push}_state"], out[f"fr_run{push}_ticks"], out[f"fr_run{push}_status"] = r["state"], r["ticks"], r["status"]
-    out[f"fr_run{push}_hist0"] = r["hist"][: r["ticks"][0], 0]
+r = oracle.frenet_run(fs[:6], coef, out["fr_goal"], 120, want_hist=True)
+out["fr_run_state"], out["fr_run_ticks"], out["fr_run_status"] = r["state"], r["ticks"], r["status"]
+out["fr_run_hist0"] = r["hist"][: r["ticks"][0], 0]
 np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
 print("wrote planner_golden.npz", {k: v.shape for k, v in out.items()})

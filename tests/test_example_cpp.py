@@ -52,4 +52,4 @@ def test_planner_example_builds_and_fails_loudly_without_gpu(planner_exe):
 def test_planner_example_runs(planner_exe):
     r = subprocess.run([planner_exe, "512"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "Frenet (single_d_push=1)" in r.stdout and "DWA:" in r.stdout
+    assert "Frenet:" in r.stdout and "DWA:" in r.stdout

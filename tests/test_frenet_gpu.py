@@ -41,13 +41,13 @@ def _cfg(crx, **kw):
     return c
 
 
-@pytest.mark.parametrize("n,push", [(1, 0), (5, 0), (203, 0), (203, 1)])
-def test_frenet_single_plan(crx, oracle_mod, n, push):
+@pytest.mark.parametrize("n", [1, 5, 203])
+def test_frenet_single_plan(crx, oracle_mod, n):
     course, ob = _course(crx, oracle_mod)
     st = _states(n, 10 + n)
-    o = oracle_mod.frenet_plan(st, course.coef, ob, cfg=oracle_mod.frenet_config(single_d_push=push))
+    o = oracle_mod.frenet_plan(st, course.coef, ob)
     sd = _t(st)
-    r = crx.frenet_optimal_planning(sd, course, _t(ob), _cfg(crx, single_d_push=push), want_paths=True)
+    r = crx.frenet_optimal_planning(sd, course, _t(ob), _cfg(crx), want_paths=True)
     P = o["n_paths"][0]
     assert P == 168 and r["path_cf"].shape[1] == P
     cf, ok = r["path_cf"].cpu().numpy(), r["path_ok"].cpu().numpy()
@@ -70,21 +70,21 @@ def test_frenet_single_plan(crx, oracle_mod, n, push):
     assert np.array_equal(sd.cpu().numpy()[stuck], st[stuck]) and (status[stuck] & 1).all()
 
 
-@pytest.mark.parametrize("push", [0, 1])
-def test_frenet_reference_episode(crx, oracle_mod, push):
+def test_frenet_reference_episode(crx, oracle_mod):
     course, ob = _course(crx, oracle_mod)
     O = oracle_mod.oracle_lib
     n, max_ticks = 9, 300
     st = np.repeat(O.FRENET_STATE0[None, :], n, axis=0)
     st[1:, 2] += np.linspace(-1.5, 1.5, n - 1).astype(np.float32)          # neighbours of the reference's start
-    o = oracle_mod.frenet_run(st, course.coef, course.goal, max_ticks, ob, cfg=oracle_mod.frenet_config(single_d_push=push), want_hist=True)
+    o = oracle_mod.frenet_run(st, course.coef, course.goal, max_ticks, ob, want_hist=True)
     sd = _t(st)
-    r = crx.frenet_run(sd, course, _t(ob), max_ticks, _cfg(crx, single_d_push=push), want_hist=True)
+    r = crx.frenet_run(sd, course, _t(ob), max_ticks, _cfg(crx), want_hist=True)
     ticks = r["ticks"].cpu().numpy()
     h = r["hist"].cpu().numpy()
     # the reference's own start (agent 0): same length, same fate, same trajectory
     assert ticks[0] == o["ticks"][0] and r["status"].cpu().numpy()[0] == o["status"][0]
-    assert (o["status"][0] == 1) if push == 0 else (o["status"][0] == 0 and ticks[0] < max_ticks)
+    assert o["status"][0] == 0 and ticks[0] < max_ticks                   # the reference's start must reach the goal
+    assert np.hypot(h[ticks[0] - 1, 0, 5] - course.goal[0], h[ticks[0] - 1, 0, 6] - course.goal[1]) <= 1.0
     assert np.allclose(h[: ticks[0], 0], o["hist"][: ticks[0], 0], rtol=1e-4, atol=1e-4)
     # the neighbours: a long closed loop amplifies one-ulp differences only through a changed winner; demand agreement for most
     same = ticks == o["ticks"]

@@ -3,7 +3,7 @@ import numpy as np
 
 
 def test_reference_scenario_reaches_goal(oracle_mod):
-    st = np.array([[0.0, 0.0, 3.141592653 / 8.0, 0.0, 0.0]], np.float32)          # main() :161
+    st = np.array([[0.0, 0.0, 3.141592653 / 8.0, 0.0, 0.0]], np.float32)          # main() :167
     u = np.zeros((1, 2), np.float32)
     goal = np.array([[10.0, 10.0]], np.float32)
     un, ns, bi = oracle_mod.dwa_control(st, u, goal)

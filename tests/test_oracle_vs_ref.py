@@ -1,0 +1,238 @@
+"""The oracle against the reference's own source lines.
+
+oracle/_ref/libref.so (oracle/ref_build.sh, built by __graft_entry__.build() whenever /root/reference is present) is the
+reference's hot-path code cut out of its files and compiled unmodified — against the host's Eigen if there is one, else against the
+Eigen stand-in of oracle/ref_shim (which restates Eigen's evaluation order; see its header).  Bit equality is demanded wherever
+the oracle claims it.  Skipped when the library has not been built (a host with neither /root/reference nor the shipped .so);
+tests/test_ref_golden.py then still checks the oracle against the committed outputs of this library.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from common import ekf_QR, ekf_agents, ekf_noise, lqr_course, lqr_speeds, mpc_course_f32, mpc_problem, tracking_agents
+
+from oracle import ref_lib as R
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+
+
+def _eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.fixture()
+def host_trig(oracle_mod, monkeypatch):
+    """The reference calls the host libm; make the oracle do the same whatever flavour this host's libm is."""
+    monkeypatch.setattr(oracle_mod.oracle_lib, "trig_mode", lambda: 0)
+    return oracle_mod
+
+
+def test_which_eigen():
+    print("libref.so built against:", R.eigen_kind())
+
+
+# ---- EKF ---------------------------------------------------------------------------------------------------------------------
+def test_ekf_small_functions(host_trig):
+    o = host_trig
+    rng = np.random.default_rng(0)
+    n = 4000
+    x = np.stack([rng.normal(0, 50, n), rng.normal(0, 50, n), rng.uniform(-200, 200, n), rng.normal(0, 5, n)], axis=1).astype(np.float32)
+    x[:8, 2] = [0.0, -0.0, 1e-30, 3.1415927, -3.1415927, 1e6, 119.9, 120.1]
+    u = np.stack([rng.normal(1, 2, n), rng.normal(0, 1, n)], axis=1).astype(np.float32)
+    assert _eq(o.motion_model(x, u, trig=0), R.motion_model(x, u))
+    assert _eq(o.jacobF(x, u, trig=0), R.jacobF(x, u))
+    assert _eq(o.observation_model(x), R.observation_model(x))
+    assert _eq(o.jacobH(), R.jacobH())
+
+
+@pytest.mark.parametrize("single", [True, False])
+def test_ekf_estimation_bit_exact(host_trig, single):
+    o = host_trig
+    Q, Rm = ekf_QR()
+    n, T = (1, 1000) if single else (96, 300)
+    u, x0, P0 = ekf_agents(n, 3, single_vehicle=single)
+    z, ud, *_ = o.ekf_simulate_inputs(u, x0, x0, ekf_noise(T, n, 4), trig=0)
+    for order in (0, 1):                                       # Eigen's order and all-ascending: identical on this path
+        xo, Po, xho, pho = o.ekf_run(x0, P0, z, ud, Q, Rm, trig=0, sum_order=order, want_phist=True)
+        xr, Pr, xhr, phr = R.ekf_run(x0, P0, z, ud, Q, Rm, want_phist=True)
+        assert _eq(xho, xhr) and _eq(pho, phr) and _eq(xo, xr) and _eq(Po, Pr)
+
+
+def test_ekf_wide_range_inputs(host_trig):
+    """Magnitudes over 40 decades, random dense (non-symmetric) P, Q, R: every finite run equal bit for bit."""
+    o = host_trig
+    rng = np.random.default_rng(5)
+    n, T = 400, 40
+    mag = lambda lo, hi, shape: (10.0 ** rng.uniform(lo, hi, shape) * rng.choice([-1, 1], shape)).astype(np.float32)
+    x0 = mag(-6, 6, (n, 4)); P0 = mag(-8, 4, (n, 16)); z = mag(-6, 6, (T, n, 2)); u = mag(-6, 3, (T, n, 2))
+    Q = mag(-6, 0, 16); Rm = np.array([1.0, 0.1, 0.2, 2.0], np.float32)
+    xo, Po, xho, pho = o.ekf_run(x0, P0, z, u, Q, Rm, trig=0, want_phist=True)
+    xr, Pr, xhr, phr = R.ekf_run(x0, P0, z, u, Q, Rm, want_phist=True)
+    fin = np.isfinite(phr).all(axis=(0, 2)) & np.isfinite(xhr).all(axis=(0, 2))
+    assert fin.mean() > 0.5
+    assert _eq(xho[:, fin], xhr[:, fin]) and _eq(pho[:, fin], phr[:, fin])
+
+
+def test_ekf_main_loop_and_constants(host_trig):
+    """main() :110-188: the constants it builds and the input side (ud, xTrue, xDR, z) of every pass, then the estimate."""
+    o = host_trig
+    T = 501                                                    # SIM_TIME / DT passes, as the reference runs
+    w = ekf_noise(T, 1, 9)[:, 0, :]                            # float draws, promoted exactly to the double the reference multiplies
+    m = R.ekf_main(w.astype(np.float64))
+    Q, Rm = ekf_QR()
+    assert _eq(m["Q"], Q) and _eq(m["R"], Rm)
+    qsim = (1.0, (30.0 / 180 * math.pi) * (30.0 / 180 * math.pi))
+    assert _eq(m["Qsim"], np.array([qsim[0], 0, 0, qsim[1]], np.float32)) and _eq(m["Rsim"], np.array([0.25, 0, 0, 0.25], np.float32))
+    u = np.array([[1.0, 0.1]], np.float32); x0 = np.zeros((1, 4), np.float32)
+    z, ud, _, _, xth, xdh = o.ekf_simulate_inputs(u, x0, x0, w[:, None, :], trig=0, want_hist=True)
+    assert _eq(ud[:, 0], m["hud"]) and _eq(z[:, 0], m["hz"]) and _eq(xth[:, 0], m["hxTrue"]) and _eq(xdh[:, 0], m["hxDR"])
+    P0 = np.eye(4, dtype=np.float32).reshape(1, 16)
+    xo, Po, xho, _ = o.ekf_run(x0, P0, z, ud, Q, Rm, trig=0)
+    assert _eq(xho[:, 0], m["hxEst"]) and _eq(Po[0], m["PEst"])
+
+
+# ---- DARE / dlqr ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [5, 4])
+def test_dare_on_the_references_own_matrices(oracle_mod, dim):
+    v = lqr_speeds(600, 11)
+    v[:4] = [0.0, 1e-3, -1e-3, 2.7777777]
+    A, B, Q, Rm = oracle_mod.lqr_build(v, dim)
+    Xo, Ko, it = oracle_mod.dare(A, B, Q, Rm)
+    Xr, Kr = R.dare(A, B, Q, Rm)
+    assert _eq(Xo, Xr) and _eq(Ko, Kr)
+    assert it.min() >= 2 and it.max() == 150                  # includes the iteration-cap exit (returns X, not Xn)
+
+
+@pytest.mark.parametrize("dim", [5, 4])
+def test_dare_dense_random_matrices(oracle_mod, dim):
+    """Dense A, B, Q, R — beyond the reference's call sites; here the accumulation order of every product matters."""
+    rng = np.random.default_rng(12 + dim)
+    n, m = 300, (2 if dim == 5 else 1)
+    A = (np.eye(dim)[None] * 0.9 + rng.normal(0, 0.15, (n, dim, dim))).astype(np.float32).reshape(n, -1)
+    B = rng.normal(0, 0.5, (n, dim * m)).astype(np.float32)
+    Qh = rng.normal(0, 0.4, (n, dim, dim)); Q = (Qh @ Qh.transpose(0, 2, 1) + 0.1 * np.eye(dim)).astype(np.float32).reshape(n, -1)
+    if dim == 5:
+        Rh = rng.normal(0, 0.4, (n, 2, 2)); Rm = (Rh @ Rh.transpose(0, 2, 1) + 0.5 * np.eye(2)).astype(np.float32).reshape(n, -1)
+    else:
+        Rm = rng.uniform(0.3, 2.0, (n, 1)).astype(np.float32)
+    Xo, Ko, it = oracle_mod.dare(A, B, Q, Rm)
+    Xr, Kr = R.dare(A, B, Q, Rm)
+    fin = np.isfinite(Xr).all(axis=1)
+    assert fin.mean() > 0.9 and _eq(Xo[fin], Xr[fin]) and _eq(Ko[fin], Kr[fin])
+
+
+# ---- tracking front-end, vehicle update, closed loops -----------------------------------------------------------------------------
+def test_nearest_index_and_steering_control(host_trig):
+    o = host_trig
+    course, _ = lqr_course()
+    st = tracking_agents(500, course, 21)
+    ind_o, e_o = o.calc_nearest_index(st, course)
+    ind_r, e_r = R.calc_nearest_index(st, course)
+    assert _eq(ind_o, ind_r) and _eq(e_o, e_r)
+    rng = np.random.default_rng(22)
+    pe = rng.normal(0, 0.3, len(st)).astype(np.float32); pth = rng.normal(0, 0.2, len(st)).astype(np.float32)
+    c_o, _, pe_o, pth_o = o.lqr_steering_control(st, course, pe, pth, dim=5)
+    c_r, _, pe_r, pth_r = R.lqr_steering_control(st, course, pe, pth, dim=5)
+    assert _eq(c_o, c_r) and _eq(pe_o, pe_r) and _eq(pth_o, pth_r)
+    d_o, i_o, pe_o, pth_o = o.lqr_steering_control(st, course, pe, pth, dim=4)
+    d_r, i_r, pe_r, pth_r = R.lqr_steering_control(st, course, pe, pth, dim=4)
+    assert _eq(d_o, d_r) and _eq(i_o, i_r) and _eq(pe_o, pe_r) and _eq(pth_o, pth_r)
+
+
+def test_update_both_variants(host_trig):
+    o = host_trig
+    rng = np.random.default_rng(23)
+    n = 3000
+    st = np.stack([rng.normal(0, 30, n), rng.normal(0, 30, n), rng.uniform(-10, 10, n), rng.uniform(-8, 18, n)], axis=1).astype(np.float32)
+    a = rng.uniform(-2, 2, n).astype(np.float32); d = rng.uniform(-1.5, 1.5, n).astype(np.float32)
+    d[:3] = [np.float32(math.pi / 4), -np.float32(math.pi / 4), 0.0]
+    assert _eq(o.update(st, a, d), R.lqr_update(st, a, d))                                             # LQR files: DT 0.1, L 0.5
+    assert _eq(o.update(st, a, d, dt=0.2, wheelbase=2.5, clamp_speed=True), R.mpc_update(st, a, d))   # MPC file: + speed clamp
+
+
+@pytest.mark.parametrize("dim", [5, 4])
+def test_lqr_closed_loop_every_tick(host_trig, dim):
+    o = host_trig
+    course, goal = lqr_course()
+    st = np.zeros((10, 4), np.float32)                                      # agent 0: the reference's own start (:171 / :153)
+    st[1:] = tracking_agents(9, tuple(c[:80] for c in course), 31, spread=0.3)
+    so, to, ho, *_ = o.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=700, want_hist=True)
+    sr, tr, hr = R.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=700)
+    assert _eq(to, tr) and (tr < 700).all()
+    for a in range(len(st)):
+        assert _eq(ho[: to[a], a], hr[: tr[a], a])
+    assert _eq(so, sr)
+
+
+# ---- MPC: layout, NLP functions, bounds, the callers ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("T", [6, 21])
+def test_mpc_problem_definition(oracle_mod, T):
+    """FG_EVAL (:199-252) and the problem mpc_solve hands to IPOPT (:263-328) against the oracle's statement of the NLP."""
+    lay = R.mpc_layout(T)
+    assert lay == dict(x=0, y=T, yaw=2 * T, v=3 * T, delta=4 * T, a=4 * T + T - 1)
+    x0, xref = mpc_problem(40, T, seed=41)
+    rng = np.random.default_rng(42)
+    P = oracle_mod.MPC_DEFAULTS
+    for a in range(len(x0)):
+        U = np.stack([rng.uniform(-0.9, 0.9, T - 1), rng.uniform(-1.2, 1.2, T - 1)], axis=1)      # (delta, a) per stage
+        J, S = oracle_mod.mpc_cost(x0[a], xref[a], T, U)                                         # rollout: S[i] = (x, y, yaw, v, ...) at knot i
+        vars_ = np.concatenate([S[:, 0], S[:, 1], S[:, 2], S[:, 3], U[:, 0], U[:, 1]])
+        fg = R.mpc_fg_eval(xref[a], vars_, T)
+        assert abs(fg[0] - J) <= 1e-12 * max(1.0, abs(J))                                       # same objective
+        # on a rollout the dynamics constraints vanish and the four initial-state functions return the state itself
+        assert np.allclose(fg[1 + np.array([0, T, 2 * T, 3 * T])], x0[a].astype(np.float64), rtol=0, atol=0)
+        dyn = np.delete(fg[1:], [0, T, 2 * T, 3 * T])
+        assert np.abs(dyn).max() < 1e-12
+        # off the rollout the constraint functions are the defects: perturb one knot
+        v2 = vars_.copy(); v2[lay["yaw"] + 2] += 0.125
+        fg2 = R.mpc_fg_eval(xref[a], v2, T)
+        assert abs(fg2[1 + lay["yaw"] + 2] - (fg[1 + lay["yaw"] + 2] + 0.125)) < 1e-12
+    cap = R.mpc_solve(x0[0], xref[0], T)
+    nv = 4 * T + 2 * (T - 1)
+    assert cap["xi"][lay["x"]] == x0[0, 0] and cap["xi"][lay["v"]] == x0[0, 3] and np.count_nonzero(cap["xi"]) <= 4   # zero start :266-274
+    lo, hi = cap["xl"], cap["xu"]
+    sl = lambda k, m: slice(lay[k], lay[k] + m)
+    assert (lo[sl("delta", T - 1)] == -P["max_steer"]).all() and (hi[sl("delta", T - 1)] == P["max_steer"]).all()
+    assert (lo[sl("a", T - 1)] == -P["max_accel"]).all() and (hi[sl("a", T - 1)] == P["max_accel"]).all()
+    assert (lo[sl("v", T)] == P["min_speed"]).all() and (hi[sl("v", T)] == P["max_speed"]).all()       # every knot, :298-301
+    assert (lo[: 3 * T] == -1e7).all() and (hi[: 3 * T] == 1e7).all()
+    g = np.zeros(4 * T); g[[0, T, 2 * T, 3 * T]] = x0[0].astype(np.float64)
+    assert _eq(cap["gl"], g) and _eq(cap["gu"], g)
+    assert "max_iter      50" in cap["options"] and "max_cpu_time          0.05" in cap["options"]
+    # what mpc_solve returns is the solver's answer rounded to float, in the same layout (:341-345)
+    sol = rng.normal(0, 1, nv)
+    assert _eq(R.mpc_solve(x0[0], xref[0], T, solver=lambda x, r: sol)["result"], sol.astype(np.float32))
+
+
+@pytest.mark.parametrize("T", [6, 21])
+def test_calc_ref_trajectory_and_window_search(host_trig, T):
+    o = host_trig
+    course, _ = mpc_course_f32()
+    nc = len(course[0])
+    rng = np.random.default_rng(51)
+    st = tracking_agents(400, course, 52, spread=1.0)
+    st[:, 3] = rng.uniform(-3, 15, len(st)).astype(np.float32)
+    pind = rng.integers(0, nc - 10, len(st)).astype(np.int32)              # the reference reads cx[pind .. pind+9] unchecked
+    assert _eq(o.calc_nearest_index_window(st, course, pind), R.calc_nearest_index_window(st, course, pind, T=T))
+    xo, to = o.calc_ref_trajectory(st, course, pind, T)
+    xr, tr = R.calc_ref_trajectory(st, course, pind, T)
+    assert _eq(xo, xr) and _eq(to, tr)
+
+
+def test_mpc_simulation_loop_with_the_oracle_solver(host_trig):
+    """mpc_simulation (:348-385) as written, IPOPT replaced by the oracle's solver: the oracle's own closed loop must walk
+    the same trajectory, tick for tick (same solver on both sides, so this pins the loop, update and the indices it reads)."""
+    o = host_trig
+    T = 6
+    course, goal = mpc_course_f32()
+    cx, cy, cyaw, ck, sp = course
+    def solver(x0, xref):
+        sol, st, _ = o.mpc_solve(x0.astype(np.float32)[None], xref[None], T)
+        return sol[0].astype(np.float64)
+    ticks, traj, ctl, cs = R.mpc_simulation(course, goal, T, 60, solver)
+    assert _eq(cs, cyaw)                                                     # smooth_yaw leaves an already smooth course alone
+    st0 = np.array([[cx[0], cy[0], cyaw[0], sp[0]]], np.float32)
+    so, to, ho, _ = o.mpc_closed_loop(st0, course, goal, T, 60, want_hist=True)
+    assert ticks == to[0] == 60 and _eq(ho[:60, 0], traj)

@@ -3,12 +3,14 @@
 // Replaces, for n independent agents at once, mpc_solve() of the reference
 //   (/root/reference/src/model_predictive_control.cpp:255-346), i.e. the NLP that FG_EVAL (:199-252)
 // defines: variables [x|y|yaw|v|delta|a], bicycle-model equality constraints (:242-245), input
-// and input-rate costs (:203-209), tracking cost (:247-250), box bounds (:288-301).
+// and input-rate costs (:203-209), tracking cost (:247-250), box bounds on steering, acceleration and speed (:288-301).
 // The reference hands that NLP to CppAD+IPOPT (double precision); crx solves the same NLP with a
 // solver of its own, built for one-problem-per-lane execution:
 //
 //   * single shooting — the equality constraints are eliminated by rolling the model forward,
-//     leaving the 2(T-1) controls as unknowns with their box bounds;
+//     leaving the 2(T-1) controls as unknowns with their box bounds; the speed bounds of the knots
+//     become a state-dependent box on the acceleration (v+ = v + a*DT), enforced exactly in every
+//     rollout and carried through the backward sweep as a feedback row where they are active;
 //   * stage-wise Newton (control-limited DDP): a backward Riccati sweep over the T-1 stages on the
 //     state augmented by the previous control (the input-rate cost couples consecutive controls),
 //     exact second derivatives of the dynamics once Gauss-Newton steps have brought the iterate
@@ -83,6 +85,22 @@ struct MpcP {
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Trust box of a Newton step (see the backward sweep) — the same constants as the twin, oracle/mpc_ref.cpp.
+constexpr double kMpcTrustSteer = 0.4, kMpcTrustAccel = 0.5;
+
+// The reference bounds every speed knot, v in [MIN_SPEED, MAX_SPEED] (:298-301).  With v+ = v + a*DT (:245) that is exactly
+// a state-dependent box on the acceleration at a knot of speed v, intersected with |a| <= MAX_ACCEL (:293-296); the
+// acceleration limits win if the two are incompatible (a start speed outside the speed bounds; reported in status bit 1).
+struct AccelBox { double lo, hi; bool sp_lo, sp_hi; };
+__device__ __forceinline__ AccelBox accel_box(const MpcP& p, double inv_dt, double v) {
+  const double a_lo = (p.min_speed - v) * inv_dt, a_hi = (p.max_speed - v) * inv_dt;
+  AccelBox b;
+  b.sp_lo = a_lo > -p.max_accel; b.sp_hi = a_hi < p.max_accel;
+  b.lo = clampd(a_lo, -p.max_accel, p.max_accel);
+  b.hi = clampd(a_hi, -p.max_accel, p.max_accel);
+  return b;
+}
+
 // min 1/2 k'Hk + g'k over the box, H = [h00 hod; hod h11] possibly indefinite.  See file header.
 __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, double g0, double g1, double lo0,
                                        double hi0, double lo1, double hi1, double& k0, double& k1, bool& f0,
@@ -144,7 +162,8 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
-  const double lb0 = -p.max_steer, ub0 = p.max_steer, lb1 = -p.max_accel, ub1 = p.max_accel;
+  const double inv_dt = 1.0 / dt;
+  const double lb0 = -p.max_steer, ub0 = p.max_steer;
 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
   // rolls controls U[c] from x0 and returns fg[0]
@@ -201,11 +220,14 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     S[0][0][3] = S[1][0][3] = (double)xi.w;
   }
   double J = 0.0;
-  for (int i = 0; i < N; ++i) {          // zero initial guess (:266-269), rolled out
-    U[0][i][0] = 0.0; U[0][i][1] = 0.0;
+  for (int i = 0; i < N; ++i) {          // zero initial guess (:266-269), rolled out; projected on the acceleration box of each
+                                         // knot (which moves it only if the start speed violates the speed bounds)
+    const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
+    const double a0 = clampd(0.0, ab.lo, ab.hi);
+    U[0][i][0] = 0.0; U[0][i][1] = a0;
     J += ctrl(0, i);
     if (i >= 1) J += track(S[0][i], i);
-    step(S[0][i], 0.0, 0.0, S[0][i + 1], TR[0][i]);
+    step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
   }
   J += track(S[0][N], N);
 
@@ -342,8 +364,23 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
       }
       const double hod = 0.5 * (Quu01 + Quu10);
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
+      // the box of the step: steering limits; the acceleration box of this knot's (nominal) speed = acceleration limits and
+      // the speed bounds of knot i+1; and, for a Newton step, a trust box around the current controls — with the exact
+      // (possibly indefinite) Hessian an unrestricted stage proposes a jump to the far corner of the box, which the line
+      // search rejects at every step length, and the solver falls back to linearly converging Gauss-Newton steps: that is
+      // the whole tail of the iteration-count distribution.  Gauss-Newton steps are not restricted.
+      AccelBox ab = accel_box(p, inv_dt, v);
+      double lo0 = lb0 - ud, hi0 = ub0 - ud, lo1 = ab.lo - ua, hi1 = ab.hi - ua;
+      if (exact) {
+        lo0 = fmax(lo0, -kMpcTrustSteer); hi0 = fmin(hi0, kMpcTrustSteer);
+        if (lo1 < -kMpcTrustAccel) { lo1 = -kMpcTrustAccel; ab.sp_lo = false; }
+        if (hi1 > kMpcTrustAccel) { hi1 = kMpcTrustAccel; ab.sp_hi = false; }
+      }
       double k0, k1; bool f0, f1;
-      boxqp2(h00, hod, h11, Qu0, Qu1, lb0 - ud, ub0 - ud, lb1 - ua, ub1 - ua, k0, k1, f0, f1);
+      boxqp2(h00, hod, h11, Qu0, Qu1, lo0, hi0, lo1, hi1, k0, k1, f0, f1);
+      // the acceleration rests on a SPEED bound: it is then a function of the state, a = (v_bound - v)/DT — a feedback row
+      // -1/DT on v (the next knot's speed stays on the bound whatever v does) — and the steering gains see that row
+      const bool sp = !f1 && ((k1 == hi1 && ab.sp_hi) || (k1 == lo1 && ab.sp_lo));
       // feedback K = -H_ff^-1 Q_us,f  over the 6 columns [Qux | l_up on the diagonal]
       double Qus[2][6];
 #pragma unroll
@@ -363,6 +400,16 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
         for (int b = 0; b < 6; ++b) {
           K[0][b] = -(i00 * Qus[0][b] + i01 * Qus[1][b]);
           K[1][b] = -(i01 * Qus[0][b] + i11 * Qus[1][b]);
+        }
+        if (__any(sp)) {          // rare (never on the reference's scenario: 10 km/h against bounds of -20 / +55 km/h)
+          if (sp) {
+            const double ih = f0 ? 1.0 / h00 : 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+              K[1][b] = (b == 3) ? -inv_dt : 0.0;
+              K[0][b] = -(Qus[0][b] + hod * K[1][b]) * ih;
+            }
+          }
         }
       }
       kf[i][0] = k0; kf[i][1] = k1;
@@ -400,7 +447,18 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int b = a; b < 6; ++b) Vss[a][b] -= mu * (K[0][a] * K[0][b] + K[1][a] * K[1][b]);
+          for (int b = a; b < 6; ++b) Vss[a][b] -= sp ? 0.0 : mu * (K[0][a] * K[0][b] + K[1][a] * K[1][b]);
+      }
+      if (__any(sp)) {      // a prescribed feedback row: the identity above does not hold, the general form is evaluated
+        if (sp) {
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) {
+              const double qk0 = Quu00 * K[0][b] + hod * K[1][b], qk1 = hod * K[0][b] + Quu11 * K[1][b];
+              Vss[a][b] += (K[0][a] * qk0 + K[1][a] * qk1) + (K[0][a] * Qus[0][b] + K[1][a] * Qus[1][b]);
+            }
+        }
       }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -439,8 +497,9 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
         du0 += in.K[0] * d0; du0 += in.K[2] * d1; du0 += in.K[4] * d2; du0 += in.K[6] * d3; du0 += in.K[8] * d4; du0 += in.K[10] * d5;
         double du1 = alpha * in.k1;
         du1 += in.K[1] * d0; du1 += in.K[3] * d1; du1 += in.K[5] * d2; du1 += in.K[7] * d3; du1 += in.K[9] * d4; du1 += in.K[11] * d5;
+        const AccelBox nb = accel_box(p, inv_dt, xs[3]);            // the box of a_i at the NEW speed of knot i
         const double nd = clampd(in.u0 + du0, lb0, ub0);
-        const double na = clampd(in.u1 + du1, lb1, ub1);
+        const double na = clampd(in.u1 + du1, nb.lo, nb.hi);
         U[nxt][i][0] = nd; U[nxt][i][1] = na;
         double cv = p.r_d * nd * nd + p.r_a * na * na;              // ctrl(nxt, i)
         if (i >= 1) {

@@ -30,6 +30,7 @@ struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the re
   int max_iter;
 };
 
+constexpr double kTrustSteer = 0.4, kTrustAccel = 0.5;   // trust box of a Newton step, see backward()
 constexpr int NS = 6;  // x, y, yaw, v, previous delta, previous a
 constexpr int NU = 2;  // delta, a
 
@@ -76,6 +77,17 @@ double rollout(const MpcParams& p, int T, const float* x0, const float* xref, co
 }
 
 inline double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The box of the acceleration at a knot whose speed is v.  The reference bounds every speed knot, v in [MIN_SPEED, MAX_SPEED]
+// (:298-301); with v+ = v + a*DT (:245) that is exactly a state-dependent box on a, intersected with |a| <= MAX_ACCEL
+// (:293-296).  Should the two be incompatible (a start speed outside the speed bounds) the acceleration limits win and the
+// violated speed bound is reported in status bit 1.  sp_lo / sp_hi: the respective end of the box is the speed bound's.
+inline void accel_box(const MpcParams& p, double v, double* lo, double* hi, bool* sp_lo, bool* sp_hi) {
+  const double a_lo = (p.min_speed - v) / p.dt, a_hi = (p.max_speed - v) / p.dt;
+  *sp_lo = a_lo > -p.max_accel; *sp_hi = a_hi < p.max_accel;
+  *lo = clampd(a_lo, -p.max_accel, p.max_accel);
+  *hi = clampd(a_hi, -p.max_accel, p.max_accel);
+}
 
 // 2-variable box QP  min 1/2 k'Hk + g'k,  lo <= k <= hi  (H symmetric, possibly indefinite) by
 // enumerating the candidate minimisers: the interior stationary point (only if H is positive
@@ -194,13 +206,34 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     }
     // regularised control Hessian must be positive definite
     const double H[4] = {Quu[0] + mu, Quu[1], Quu[2], Quu[3] + mu};
-    double lo[2] = {lb[0] - u[0], lb[1] - u[1]}, hi[2] = {ub[0] - u[0], ub[1] - u[1]};
+    double a_lo, a_hi; bool sp_lo, sp_hi;
+    accel_box(p, v, &a_lo, &a_hi, &sp_lo, &sp_hi);           // speed bounds of knot i+1 as a box on a_i at the nominal v_i
+    double lo[2] = {lb[0] - u[0], a_lo - u[1]}, hi[2] = {ub[0] - u[0], a_hi - u[1]};
+    // A Newton step is searched inside a trust box around the current controls (|d delta| <= 0.4 rad, |d a| <= 0.5 m/s^2): with
+    // the exact (possibly indefinite) Hessian an unconstrained stage proposes a jump to the far box corner, which the line
+    // search then rejects at every step length, and the solver falls back to linearly converging Gauss-Newton steps — the
+    // whole tail of the iteration-count distribution (on the BASELINE batch: 50-iteration cap hit by 3 agents, 22+ by 8;
+    // with the trust box every agent converges in <= 21).  Gauss-Newton steps (positive definite) are not restricted.
+    if (exact) {
+      lo[0] = lo[0] < -kTrustSteer ? -kTrustSteer : lo[0]; hi[0] = hi[0] > kTrustSteer ? kTrustSteer : hi[0];
+      if (lo[1] < -kTrustAccel) { lo[1] = -kTrustAccel; sp_lo = false; }     // that end of the box is no longer the speed bound's
+      if (hi[1] > kTrustAccel) { hi[1] = kTrustAccel; sp_hi = false; }
+    }
     double k[2]; int fr[2];
     boxqp2(H, Qu, lo, hi, k, fr);
     (void)deficit;
+    // the acceleration rests on a SPEED bound: it is then a function of the state, a = (v_bound - v)/DT, i.e. a feedback row
+    // -1/DT on v (the next knot's speed stays on the bound whatever v does), and the steering gains see that row
+    const bool sp = !fr[1] && ((k[1] == hi[1] && sp_hi) || (k[1] == lo[1] && sp_lo));
     double K[NU * NS];
     std::memset(K, 0, sizeof(K));
-    if (fr[0] && fr[1]) {
+    if (sp) {
+      K[1 + NU * 3] = -1.0 / dt;
+      if (fr[0]) {
+        const double hod = 0.5 * (H[1] + H[2]);
+        for (int b = 0; b < NS; ++b) K[0 + NU * b] = -(Qus[0 + NU * b] + hod * K[1 + NU * b]) / H[0];
+      }
+    } else if (fr[0] && fr[1]) {
       const double hod = 0.5 * (H[1] + H[2]);
       const double det = H[0] * H[3] - hod * hod;
       for (int b = 0; b < NS; ++b) {
@@ -229,10 +262,17 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     // of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
     //   V_ss = Q_ss + Q_us'K - mu K'K      (= Q_ss - Q_su Quu^-1 Q_us when mu = 0);
     // the upper triangle is formed and mirrored (Q_ss symmetrised), as the kernel does.
+    // With a prescribed feedback row (sp) that identity does not hold and the general form is evaluated.
+    const double qod = 0.5 * (Quu[1] + Quu[2]);
     for (int a = 0; a < NS; ++a)
       for (int b = a; b < NS; ++b) {
         double v = 0.5 * (Qss[a + NS * b] + Qss[b + NS * a]) + (Qus[0 + NU * a] * K[0 + NU * b] + Qus[1 + NU * a] * K[1 + NU * b]);
-        if (mu != 0.0) v -= mu * (K[0 + NU * a] * K[0 + NU * b] + K[1 + NU * a] * K[1 + NU * b]);
+        if (sp) {
+          const double qk0 = Quu[0] * K[0 + NU * b] + qod * K[1 + NU * b], qk1 = qod * K[0 + NU * b] + Quu[3] * K[1 + NU * b];
+          v += (K[0 + NU * a] * qk0 + K[1 + NU * a] * qk1) + (K[0 + NU * a] * Qus[0 + NU * b] + K[1 + NU * a] * Qus[1 + NU * b]);
+        } else if (mu != 0.0) {
+          v -= mu * (K[0 + NU * a] * K[0 + NU * b] + K[1 + NU * a] * K[1 + NU * b]);
+        }
         Vss[a + NS * b] = v; Vss[b + NS * a] = v;
       }
   }
@@ -243,7 +283,17 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
               double* trace = nullptr) {
   const int N = T - 1;
   Work w(T);
-  std::fill(w.U.begin(), w.U.end(), 0.0);                    // zero initial guess, :266-269
+  std::fill(w.U.begin(), w.U.end(), 0.0);                    // zero initial guess, :266-269 ...
+  {                                                          // ... projected on the bounds (it moves only if the start speed violates them)
+    double s[NS] = {(double)x0[0], (double)x0[1], (double)x0[2], (double)x0[3], 0.0, 0.0}, sn[NS];
+    for (int i = 0; i < N; ++i) {
+      double a_lo, a_hi; bool sp_lo, sp_hi;
+      accel_box(p, s[3], &a_lo, &a_hi, &sp_lo, &sp_hi);
+      w.U[NU * i + 1] = clampd(0.0, a_lo, a_hi);
+      dyn(p, s, w.U.data() + NU * i, sn);
+      std::memcpy(s, sn, sizeof(s));
+    }
+  }
   double J = rollout(p, T, x0, xref, w.U.data(), w.S.data());
   double mu = 0.0;
   const double mu_min = 1e-6, mu_max = 1e10;
@@ -275,10 +325,13 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
       for (int i = 0; i < N; ++i) {
         const double* s = w.S.data() + NS * i;
         double* sn = w.Sn.data() + NS * i;
+        double a_lo, a_hi; bool sp_lo, sp_hi;
+        accel_box(p, sn[3], &a_lo, &a_hi, &sp_lo, &sp_hi);           // the box of a_i at the NEW speed of knot i
+        const double blo[2] = {lb[0], a_lo}, bhi[2] = {ub[0], a_hi};
         for (int a = 0; a < NU; ++a) {
           double du = alpha * w.kff[NU * i + a];
           for (int b = 0; b < NS; ++b) du += w.Kfb[NU * NS * i + a + NU * b] * (sn[b] - s[b]);
-          w.Un[NU * i + a] = clampd(w.U[NU * i + a] + du, lb[a], ub[a]);
+          w.Un[NU * i + a] = clampd(w.U[NU * i + a] + du, blo[a], bhi[a]);
         }
         dyn(p, sn, w.Un.data() + NU * i, sn + NS);
       }

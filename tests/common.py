@@ -163,3 +163,36 @@ def tracking_agents(n, course, seed, spread=0.5):
     st = np.stack([cx[i] + rng.normal(0, spread, n), cy[i] + rng.normal(0, spread, n),
                    cyaw[i] + rng.normal(0, 0.2, n), rng.uniform(-1.0, 4.0, n)], axis=1)
     return st.astype(np.float32)
+
+
+def speed_bound_problems(n, T, seed, fast=True):
+    """Problems whose optimum rides a speed bound: the reference trajectory asks for 60 km/h (MAX_SPEED is 55) or for
+    -25 km/h in reverse (MIN_SPEED is -20), from a start a little inside the bound."""
+    x0, xref = mpc_problem(n, T, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    xr = xref.reshape(n, T, 4).copy()
+    if fast:
+        x0[:, 3] = rng.uniform(14.8, 15.25, n).astype(np.float32)
+        xr[:, :, 3] = np.float32(60.0 / 3.6)
+    else:
+        x0[:, 3] = rng.uniform(-5.5, -5.1, n).astype(np.float32)
+        xr[:, :, 3] = np.float32(-25.0 / 3.6)
+    # a reference the vehicle can follow at that speed: straight ahead of the start pose
+    step = xr[:, :, 3] * 0.2
+    for i in range(T):
+        xr[:, i, 0] = x0[:, 0] + np.cos(x0[:, 2]) * step[:, :i + 1].sum(axis=1)
+        xr[:, i, 1] = x0[:, 1] + np.sin(x0[:, 2]) * step[:, :i + 1].sum(axis=1)
+        xr[:, i, 2] = x0[:, 2]
+    return x0, xr.reshape(n, 4 * T)
+
+
+def mpc_solve_threads(oracle_mod, x0, xref, T, **kw):
+    """The CPU twin on every core (the twin's entry point takes an agent range; ctypes releases the GIL)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(x0)
+    nt = max(1, min(os.cpu_count() or 1, 64, n // 16 or 1))
+    cuts = [k * n // nt for k in range(nt + 1)]
+    with ThreadPoolExecutor(nt) as ex:
+        parts = list(ex.map(lambda k: oracle_mod.mpc_solve(x0[cuts[k]:cuts[k + 1]], xref[cuts[k]:cuts[k + 1]], T, **kw), range(nt)))
+    return tuple(np.concatenate([p[j] for p in parts]) for j in range(3))

@@ -39,9 +39,12 @@ def test_lqr_golden(crx):
 def test_mpc_golden(crx):
     g = np.load(os.path.join(GOLD, "mpc_golden.npz"))
     sol, st, cost = crx.mpc_solve(_t(g["x0"]), _t(g["xref"]), int(g["T"]), return_status=True)
-    ok = ((st.cpu().numpy() & 1) == 1) & ((g["status"] & 1) == 1)
+    st, cost = st.cpu().numpy(), cost.cpu().numpy()
+    assert np.array_equal(st & 3, g["status"] & 3)                       # every agent, converged or not
+    ok = (g["status"] & 1) == 1
     assert ok.mean() > 0.95
     assert floored_rel_err(sol.cpu().numpy()[ok], g["sol"][ok], 1.0) <= 1e-6
+    assert np.max(np.abs(cost - g["cost"]) / np.maximum(np.abs(g["cost"]), 1.0)) <= 1e-6
 
 
 def test_track_golden(crx):

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from common import floored_rel_err, mpc_problem
+from common import floored_rel_err, mpc_problem, speed_bound_problems as _speed_bound_problems
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -117,3 +117,32 @@ def test_convergence_rate_and_golden(oracle_mod):
     ok = (st & 1) == 1
     assert ok.mean() > 0.95
     assert floored_rel_err(sol[ok], g["sol"][ok], 1.0) <= 1e-6
+
+
+@pytest.mark.parametrize("T,fast", [(6, True), (6, False), (21, True)])
+def test_speed_bounds_are_enforced_like_the_reference_nlp(oracle_mod, T, fast):
+    """v in [MIN_SPEED, MAX_SPEED] on every knot (:298-301) — active here; same optimum as SLSQP on the NLP with those bounds."""
+    P = oracle_mod.oracle_lib.MPC_DEFAULTS
+    n = 6 if T == 6 else 2
+    x0, xref = _speed_bound_problems(n, T, 70 + T, fast)
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref, T)
+    assert np.all(st & 1) and not np.any(st & 2)
+    v = sol[:, 3 * T:4 * T]
+    assert v.max() <= P["max_speed"] + 1e-6 and v.min() >= P["min_speed"] - 1e-6
+    bound = P["max_speed"] if fast else P["min_speed"]
+    assert (np.abs(v - bound) < 1e-6).sum(axis=1).min() >= 3               # the optimum reaches the bound and rides it
+    for k in range(n):
+        r = _slsqp(oracle_mod, x0[k].astype(np.float64), xref[k], T)
+        assert cost[k] <= r.fun + 1e-7 * max(1.0, abs(r.fun))
+        if T == 6:
+            assert abs(r.fun - cost[k]) <= 1e-7 * max(1.0, abs(cost[k]))
+            assert floored_rel_err(sol[k], r.x, 1.0) < 5e-5
+
+
+def test_start_speed_outside_the_bounds_is_flagged(oracle_mod):
+    x0, xref = _speed_bound_problems(4, 6, 90, True)
+    x0[:, 3] = np.float32(17.0)                       # above MAX_SPEED: the acceleration limits win, bit 1 reports it
+    sol, st, cost = oracle_mod.mpc_solve(x0, xref, 6)
+    assert np.all(st & 2)
+    a = sol[:, 4 * 6 + 5:]
+    assert np.allclose(a[:, 0], -1.0)

@@ -11,7 +11,7 @@ checked), but every compute call raises ``CrxError`` when no HIP device is prese
 from ._lib import CrxError, lib, lib_path, EXPORTED_SYMBOLS  # noqa: F401
 from .ekf import (  # noqa: F401
     ekf_default_QR, ekf_estimation, ekf_run, ekf_simulate_inputs, jacobF, jacobH, motion_model,
-    observation_model,
+    normal_draws, observation_model,
 )
 from .lqr import dlqr, dlqr_from_v, solve_DARE, solve_DARE_from_v  # noqa: F401
 from .mpc import mpc_n_vars, mpc_solve  # noqa: F401
@@ -26,7 +26,7 @@ from .track import (  # noqa: F401
 __all__ = [
     "CrxError", "lib", "lib_path", "EXPORTED_SYMBOLS",
     "motion_model", "jacobF", "jacobH", "observation_model", "ekf_estimation", "ekf_run",
-    "ekf_simulate_inputs", "ekf_default_QR",
+    "ekf_simulate_inputs", "ekf_default_QR", "normal_draws",
     "solve_DARE", "dlqr", "solve_DARE_from_v", "dlqr_from_v",
     "mpc_solve", "mpc_n_vars",
     "pf_run", "pf_default_params", "dwa_run", "dwa_control", "dwa_default_config",

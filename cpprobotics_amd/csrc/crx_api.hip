@@ -16,6 +16,7 @@
 #include "pf_kernels.hip.h"
 #include "dwa_kernels.hip.h"
 #include "frenet_kernels.hip.h"
+#include "crx_philox.h"
 
 namespace {
 
@@ -237,6 +238,30 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
   else
     hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<false>), grid, block, 0, (hipStream_t)stream, n, T,
                        u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// w[t][a][0..3] = the four N(0,1) draws of (seed, stream, global agent id agent0 + a, step t): see crx_philox.h
+namespace crx {
+__global__ void __launch_bounds__(256) normal_draws_kernel(int n, int T, unsigned long long agent0, unsigned long long seed,
+                                                           unsigned stream_id, float4* __restrict__ w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one (step, agent) pair per lane, agent fastest
+  if (i >= (size_t)n * T) return;
+  const unsigned step = (unsigned)(i / n);
+  const unsigned long long a = agent0 + (i % n);
+  float o[4];
+  philox_normal4(seed, stream_id, a, step, o);
+  w[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace crx
+
+int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed, unsigned stream_id, float* w, void* stream) {
+  if (n < 0 || T < 0 || agent0 < 0 || ((size_t)n * T && !w)) return fail(CRX_ERR_INVALID, "normal_draws: bad argument");
+  if (int rc = check_device()) return rc;
+  if ((size_t)n * T == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::normal_draws_kernel, dim3(blocks_for((size_t)n * T, 256)), dim3(256), 0, (hipStream_t)stream, n, T,
+                     (unsigned long long)agent0, seed, stream_id, reinterpret_cast<float4*>(w));
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -112,6 +112,20 @@ def ekf_run(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None, P_hist=None):
     return xEst, PEst
 
 
+def normal_draws(n, T, agent0=0, seed=0xC0FFEE, stream_id=0, device=None, out=None):
+    """[T,n,4] standard-normal draws keyed by (seed, stream_id, global agent id agent0 + a, step): the four draws each pass
+    of the reference's loop consumes (:174-181).  Counter-based (Philox4x32-10), so a shard of a swarm gets exactly the
+    draws the whole swarm would have had for its agents."""
+    import torch
+    if out is None:
+        out = torch.empty((T, n, 4), dtype=torch.float32, device=device or "cuda")
+    L.require_cuda(out)
+    L.expect("out", out, "f", T, n, 4)
+    L.check(L.lib().crx_normal_draws_dev(n, T, int(agent0), int(seed), int(stream_id), L.ptr(out), L.stream_ptr()),
+            "crx_normal_draws_dev")
+    return out
+
+
 QSIM = (1.0, (30.0 / 180 * math.pi) * (30.0 / 180 * math.pi))   # Qsim diag (:154-156)
 RSIM = (0.5 * 0.5, 0.5 * 0.5)                                    # Rsim diag (:159-161)
 

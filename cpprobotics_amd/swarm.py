@@ -53,3 +53,43 @@ def gather_time_major(local, n_total, group=None):
     buf = torch.empty((world * T, nl, Cc), dtype=local.dtype, device=local.device)   # rank-major blocks
     dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
     return buf.view(world, T, nl, Cc).permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()
+
+
+class ChunkedTrajectoryGather:
+    """The trajectory concat of north_star, chunked and overlapped: the fused T-step launch is cut into `chunks` launches of
+    T/chunks steps (the filter state carries over in place, results bit-identical to one launch) and the all-gather of chunk
+    k's history runs on the collective's own stream while chunk k+1 computes.
+
+    Wire/buffer layout (no transpose kernel; a consumer iterates shard by shard):
+        gathered[c][r][t][a][:] = estimate of agent (shard r's first agent + a) after step c*Tc + t
+    i.e. shape [chunks, world, Tc, n_local, C] — global step = c*Tc + t, global agent = r*n_local + a.  `time_major()` gives the
+    [T, n_total, C] view as a copy for consumers that want it.  Equal shards only (the bench's weak-scaling layout)."""
+
+    def __init__(self, T, n_local, C, chunks, device, dtype=torch.float32, group=None):
+        assert T % chunks == 0, "the chunk count must divide the number of steps"
+        self.T, self.nl, self.C, self.chunks, self.Tc, self.group = T, n_local, C, chunks, T // chunks, group
+        self.world = dist.get_world_size(group)
+        self.local = torch.empty((chunks, self.Tc, n_local, C), dtype=dtype, device=device)
+        self.gathered = torch.empty((chunks, self.world, self.Tc, n_local, C), dtype=dtype, device=device)
+        self.pending = []
+
+    def run(self, launch):
+        """launch(c, t0, t1, hist): enqueue steps [t0, t1) writing their history into hist ([Tc, n_local, C])."""
+        self.wait()                                   # the previous pass's gathers still read self.local
+        for c in range(self.chunks):
+            launch(c, c * self.Tc, (c + 1) * self.Tc, self.local[c])
+            self.pending.append(dist.all_gather_into_tensor(self.gathered[c].view(self.world * self.Tc, self.nl, self.C), self.local[c],
+                                                            group=self.group, async_op=True))
+        return self
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def bytes_received_per_rank(self):
+        return self.gathered.numel() * self.gathered.element_size()
+
+    def time_major(self):
+        self.wait()
+        return self.gathered.permute(0, 2, 1, 3, 4).reshape(self.T, self.world * self.nl, self.C).contiguous()

@@ -94,6 +94,12 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
  * u_true: n x 2.  xTrue, xDR: n x 4, updated in place.  Outputs z, ud: [T][n][2].
  * xTrue_hist / xDR_hist ([T][n][4]) may be NULL.  qsim[2], rsim[2] are the diagonal entries
  * Qsim(0,0),Qsim(1,1),Rsim(0,0),Rsim(1,1) (:154-161) as floats. */
+/* Standard-normal draws for synthetic inputs, keyed by (seed, stream_id, GLOBAL agent id, step) with Philox4x32-10 + Box-Muller
+ * (csrc/crx_philox.h): w[t][a][0..3] = the four draws pass t of the reference's loop consumes for agent agent0 + a
+ * (src/extended_kalman_filter.cpp:174-181; the reference's own generator is random_device-seeded, :162-164).  The bytes do not
+ * depend on n or agent0's alignment to a shard: a swarm sharded over G GPUs sees what one GPU would generate. */
+int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed, unsigned stream_id,
+                         float* w /* [T][n][4] */, void* stream);
 int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue, float* xDR,
                                 const float* w, float* z, float* ud, float* xTrue_hist,
                                 float* xDR_hist, const float qsim[2], const float rsim[2],

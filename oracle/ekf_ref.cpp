@@ -15,6 +15,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "eigen_order.h"
 #define CRX_TRIG_FMA 1
 #include "../cpprobotics_amd/csrc/crx_trig.h"  // only for trig_mode != 0 (hosts whose libm is not the FMA flavour)
@@ -139,6 +142,24 @@ void oracle_ekf_run(int n, int T, float* x, float* P, const float* z, const floa
   }
 }
 
+// The same, all agents, in ONE OpenMP region (static partition of the vehicle blocks) — the CPU baseline bench.py times.
+// Returns the number of threads the region ran with.
+int oracle_ekf_run_omp(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                       const float* Q, const float* R, double dt, int trig_mode, int sum_order, int nthreads) {
+  int used = 1;
+  constexpr int BLK = 64;
+  const int nblk = (n + BLK - 1) / BLK;
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int b = 0; b < nblk; ++b) {
+#ifdef _OPENMP
+    if (b == 0) used = omp_get_num_threads();
+#endif
+    const int a0 = b * BLK, a1 = (a0 + BLK < n) ? a0 + BLK : n;
+    oracle_ekf_run(n, T, x, P, z, u, x_hist, P_hist, Q, R, dt, trig_mode, sum_order, a0, a1);
+  }
+  return used;
+}
+
 // Input side of the reference's loop, /root/reference/src/extended_kalman_filter.cpp:174-181.
 // w: [T][n][4] standard-normal draws (float; the reference draws doubles from a
 // random_device-seeded mt19937, which cannot be reproduced, so the draws are an input here).
@@ -185,3 +206,14 @@ int oracle_libm_is_fma_flavour(void) {
 }
 
 }  // extern "C"
+
+// ---- the engine's counter-based input noise, evaluated on the host -----------------------------------------------------------
+// Not part of the reference (whose generator is random_device-seeded): the SAME header the device code compiles
+// (cpprobotics_amd/csrc/crx_philox.h, flowing product -> oracle like crx_trig.h), run on the CPU so that tests can demand
+// host == device bytes and shard-independence without a GPU.
+#include "../cpprobotics_amd/csrc/crx_philox.h"
+extern "C" void oracle_normal_draws(int n, int T, long long agent0, unsigned long long seed, unsigned stream_id, float* w) {
+  for (int t = 0; t < T; ++t)
+    for (int a = 0; a < n; ++a) crx::philox_normal4(seed, stream_id, (uint64_t)(agent0 + a), (uint32_t)t, w + ((size_t)t * n + a) * 4);
+}
+extern "C" void oracle_philox4x32_10(unsigned* ctr, unsigned k0, unsigned k1) { crx::philox4x32_10(ctr, k0, k1); }

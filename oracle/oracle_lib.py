@@ -17,7 +17,8 @@ _F = C.c_float
 
 def build(force=False):
     """g++ -O2 -ffp-contract=off (oracle/Makefile).  Idempotent."""
-    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "dwa_ref.cpp", "frenet_ref.cpp", "eigen_order.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("ekf_ref.cpp", "lqr_ref.cpp", "mpc_ref.cpp", "track_ref.cpp", "pf_ref.cpp", "dwa_ref.cpp", "frenet_ref.cpp", "eigen_order.h", "eigen_qr.h", "Makefile",
+                                           "../cpprobotics_amd/csrc/crx_philox.h", "../cpprobotics_amd/csrc/crx_trig.h")]
     if not force and os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs):
         return _SO
     subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -117,6 +118,19 @@ def ekf_simulate_inputs(u_true, xTrue, xDR, w, dt=0.1, qsim=None, rsim=None, tri
     lib().oracle_ekf_simulate_inputs(_I(n), _I(T), _p(u_true), _p(xTrue), _p(xDR), _p(w), _p(z), _p(ud), _p(xth), _p(xdh),
                                      _p(q), _p(r), _D(dt), _I(trig_mode() if trig is None else trig))
     return z, ud, xTrue, xDR, xth, xdh
+
+
+def normal_draws(n, T, agent0=0, seed=0xC0FFEE, stream_id=0):
+    """Host evaluation of the engine's Philox-keyed N(0,1) draws (cpprobotics_amd/csrc/crx_philox.h): [T,n,4]."""
+    w = np.empty((T, n, 4), dtype=np.float32)
+    lib().oracle_normal_draws(_I(n), _I(T), C.c_longlong(agent0), C.c_ulonglong(seed), C.c_uint(stream_id), _p(w))
+    return w
+
+
+def philox4x32_10(ctr, key):
+    c = np.array(ctr, dtype=np.uint32)
+    lib().oracle_philox4x32_10(_p(c), C.c_uint(key[0]), C.c_uint(key[1]))
+    return c
 
 
 # ---- LQR ---------------------------------------------------------------------------------------

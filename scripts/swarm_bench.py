@@ -8,8 +8,12 @@ Every rank owns a contiguous shard of the agents (no data-path collective: agent
   1. all vehicles of the shard run T fused EKF steps (crx_ekf_run_batch_dev), estimated trajectory [T][n][4] out;
   2. one agent in eight also plans: calc_ref_trajectory on the shared course from its estimated state, then
      mpc_solve over N = 20 control intervals (T = 21 knots);
-  3. the estimated trajectories are concatenated over the ranks with ONE RCCL all-gather (xGMI) — the exchange step
-     north_star names.  `--gather final` gathers the final estimates only (16 B/agent instead of 16*T).
+  3. the estimated trajectories are concatenated over the ranks — the exchange step north_star names — chunked: the T-step
+     launch is cut into --chunks launches and the all-gather of chunk k (RCCL's stream, xGMI) overlaps the compute of chunk
+     k+1 (cpprobotics_amd/swarm.py: ChunkedTrajectoryGather).  `--gather final` gathers the final estimates only.
+The EKF launches and the planning kernels run on two HIP streams: the planners of round r (which need only the final
+estimates) overlap the EKF launches of round r+1.  Every input is keyed by the GLOBAL agent id (Philox draws, numpy
+generators over the whole swarm), so a shard computes what the whole swarm would have computed for its agents.
 Prints one JSON line on rank 0: EKF updates/s, MPC solves/s, end-to-end rounds/s, bytes gathered."""
 import argparse
 import json
@@ -28,6 +32,7 @@ def main():
     ap.add_argument("--T", type=int, default=100, help="EKF steps per round")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
+    ap.add_argument("--chunks", type=int, default=4, help="launches per round of the chunked trajectory gather")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -49,12 +54,12 @@ def main():
     Q, R = ekf_QR()
     course, goal = mpc_course_f32()
     dc = crx.Course.from_numpy(course, device=dev)
-    g = torch.Generator(device=dev); g.manual_seed(99 + rank)       # agent parameters keyed by (rank-)global position
-    ci = torch.randint(0, len(course[0]) - 30, (n,), generator=g, device=dev)
+    # agent parameters keyed by the global agent id: drawn for the whole swarm, this rank keeps its slice
+    ci = torch.from_numpy(np.random.default_rng(99).integers(0, len(course[0]) - 30, n_total)[rank * n:(rank + 1) * n]).to(dev)
     cx, cy, cyaw = (torch.from_numpy(a).to(dev) for a in course[:3])
     x0 = torch.stack([cx[ci], cy[ci], cyaw[ci], torch.full((n,), 2.5, device=dev)], dim=1).contiguous()
     u_true = torch.stack([torch.full((n,), 0.0, device=dev), torch.zeros(n, device=dev)], dim=1).contiguous()  # (accel, yaw rate)
-    w = torch.randn((T, n, 4), generator=g, device=dev)
+    w = crx.normal_draws(n, T, agent0=rank * n, seed=99, device=dev)
     z, ud = crx.ekf_simulate_inputs(u_true, x0.clone(), x0.clone(), w)
     del w
     P0 = torch.eye(4, device=dev).reshape(1, 16).repeat(n, 1).contiguous()
@@ -62,19 +67,34 @@ def main():
     x_hist = torch.empty((T, n, 4), device=dev)
     tind = torch.zeros(n_mpc, dtype=torch.int32, device=dev)
 
+    plan_stream = torch.cuda.Stream(device=dev)
+    ekf_done = torch.cuda.Event()
+    cg = swarm.ChunkedTrajectoryGather(T, n, 4, args.chunks, dev) if (world > 1 and args.gather == "traj") else None
+    st = torch.empty((n_mpc, 4), device=dev)
+
     def one_round():
+        main = torch.cuda.current_stream()
         x.copy_(x0); P.copy_(P0)
-        crx.ekf_run(x, P, z, ud, Q, R, x_hist=x_hist)
-        st = x[::8].contiguous()                                      # every eighth agent plans from its estimate
-        crx.calc_nearest_index(st, dc, tind)
-        xref = crx.calc_ref_trajectory(st, dc, tind, Tm)
-        sol = crx.mpc_solve(st, xref, Tm)
+        if cg is not None:
+            cg.run(lambda c, t0_, t1_, hist: crx.ekf_run(x, P, z[t0_:t1_], ud[t0_:t1_], Q, R, x_hist=hist))
+        else:
+            crx.ekf_run(x, P, z, ud, Q, R, x_hist=x_hist)
+        main.wait_stream(plan_stream)                                 # the planners of the previous round still read st
+        st.copy_(x[::8])                                              # every eighth agent plans from its estimate
+        ekf_done.record(main)
+        with torch.cuda.stream(plan_stream):                          # planning overlaps the next round's EKF launches
+            plan_stream.wait_event(ekf_done)
+            crx.calc_nearest_index(st, dc, tind)
+            xref = crx.calc_ref_trajectory(st, dc, tind, Tm)
+            sol = crx.mpc_solve(st, xref, Tm)
         out = None
-        if world > 1 and args.gather != "none":
-            out = swarm.gather_time_major(x_hist, n_total) if args.gather == "traj" else swarm.gather_agents(x, n_total)
+        if world > 1 and args.gather == "final":
+            out = swarm.gather_agents(x, n_total)
         return sol, out
 
     def sync():
+        if cg is not None:
+            cg.wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

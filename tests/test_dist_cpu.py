@@ -25,12 +25,25 @@ def _worker(rank, world, port, n, T, q):
     from cpprobotics_amd import swarm
     Q, R = ekf_QR()
     u, x0, P0 = ekf_agents(n, 7)                 # global problem, keyed by global agent id
-    w = ekf_noise(T, n, 8)
     lo, hi = swarm.shard_range(n, rank, world)
-    z, ud, _, _, _, _ = oracle.ekf_simulate_inputs(u[lo:hi], x0[lo:hi], x0[lo:hi], np.ascontiguousarray(w[:, lo:hi]))
+    # the noise each shard draws for ITS agents: counter-based, keyed by (seed, global agent id, step) — crx_philox.h
+    w = oracle.normal_draws(hi - lo, T, agent0=lo, seed=8)
+    z, ud, _, _, _, _ = oracle.ekf_simulate_inputs(u[lo:hi], x0[lo:hi], x0[lo:hi], w)
     x, P, xh, _ = oracle.ekf_run(x0[lo:hi], P0[lo:hi], z, ud, Q, R)
     xg = swarm.gather_agents(torch.from_numpy(x), n)
     hg = swarm.gather_time_major(torch.from_numpy(xh), n)
+    if n % world == 0:
+        # the chunked, overlapped trajectory gather: 4 launches of T/4 steps, state carried over, one async all-gather each
+        cg = swarm.ChunkedTrajectoryGather(T, hi - lo, 4, 4, "cpu")
+        xc, Pc = x0[lo:hi].copy(), P0[lo:hi].copy()
+
+        def launch(c, t0, t1, hist):
+            nonlocal xc, Pc
+            xc, Pc, h, _ = oracle.ekf_run(xc, Pc, z[t0:t1], ud[t0:t1], Q, R)
+            hist.copy_(torch.from_numpy(h))
+        hc = cg.run(launch).time_major()
+        assert torch.equal(hc, hg) and cg.gathered.shape == (4, world, T // 4, hi - lo, 4)
+        assert torch.equal(cg.gathered[1, rank, 2], torch.from_numpy(xh[T // 4 + 2]))     # [chunk][rank][t][agent] index map
     # tracking swarm: each rank runs the closed LQR loop on its shard of the agents (shared course), results gathered
     from common import lqr_course, tracking_agents
     course, goal = lqr_course()
@@ -79,7 +92,7 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
         assert p.exitcode == 0
     Q, R = ekf_QR()
     u, x0, P0 = ekf_agents(n, 7)
-    w = ekf_noise(T, n, 8)
+    w = oracle_mod.normal_draws(n, T, agent0=0, seed=8)        # one "GPU" draws for everybody: the shards must have seen the same bytes
     z, ud, _, _, _, _ = oracle_mod.ekf_simulate_inputs(u, x0, x0, w)
     x, P, xh, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
     assert np.array_equal(xg, x) and np.array_equal(hg, xh)

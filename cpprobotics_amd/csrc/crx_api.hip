@@ -595,18 +595,18 @@ int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const cr
   return CRX_OK;
 }
 
-// work layout: xref [n][4T] floats | sol [n][4T+2(T-1)] floats | active [n] ints
+// The persistent kernel keeps everything in registers / private memory: no work buffer is needed any more (kept for ABI
+// compatibility with 0.1: returns 0, and crx_mpc_closed_loop_batch_dev ignores `work`).
 size_t crx_mpc_closed_loop_work_bytes(int n, int T) {
-  if (n <= 0 || T < 2) return 0;
-  const size_t nn = (size_t)n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
-  return sizeof(float) * nn * 4 * T + sizeof(float) * nn * nv + sizeof(int) * nn;
+  (void)n; (void)T;
+  return 0;
 }
 
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
                                   int* ticks_done, void* work, void* stream) {
   if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 ||
-      (n && (!state || !target_ind || !ticks_done || !work)))
+      (n && (!state || !target_ind || !ticks_done)))
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -614,21 +614,24 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   if (prm) p = *prm; else crx_mpc_default_params(&p);
   const crx::VehicleParams vp{p.dt, p.wb, p.max_steer, p.max_speed, p.min_speed, 1};
   const size_t nn = (size_t)n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
-  float* xref = static_cast<float*>(work);
-  float* sol = xref + nn * 4 * T;
-  int* active = reinterpret_cast<int*>(sol + nn * nv);
+  (void)nn; (void)nv; (void)work;              // `work` is no longer used (kept in the signature; may be NULL)
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(blocks_for(n, crx::kTrackBlock)), block(crx::kTrackBlock);
+  const dim3 grid(blocks_for(n, 64)), block(64);
   const crx::CourseView cv = view(course);
-  hipLaunchKernelGGL(crx::fill_int_kernel, grid, block, 0, s, n, active, 1);
-  hipLaunchKernelGGL(crx::fill_int_kernel, grid, block, 0, s, n, ticks_done, 0);
-  for (int t = 0; t < loop->max_ticks; ++t) {
-    hipLaunchKernelGGL(crx::calc_ref_trajectory_kernel, grid, block, 0, s, n, T, state, cv, dl, p.dt, nsearch, target_ind, xref,
-                       (const int*)active);
-    if (const hipError_t e = crx::mpc_launch(n, T, state, xref, p, sol, nullptr, nullptr, s, iter_block())) return hip_fail(e, "mpc launch");
-    hipLaunchKernelGGL(crx::mpc_tick_tail_kernel, grid, block, 0, s, n, T, t, state, sol, vp, loop->goal_x, loop->goal_y,
-                       loop->goal_dis, active, ticks_done, traj_hist);
-  }
+  crx::MpcP q;
+  q.dt = p.dt; q.wb = p.wb; q.max_steer = p.max_steer; q.max_accel = p.max_accel; q.max_speed = p.max_speed; q.min_speed = p.min_speed;
+  q.r_a = p.r_a; q.r_d = p.r_delta; q.rd_a = p.rd_a; q.rd_d = p.rd_delta; q.qx = p.q_x; q.qy = p.q_y; q.qyaw = p.q_yaw; q.qv = p.q_v;
+  q.tol = p.tol; q.max_iter = p.max_iter;
+  // ONE persistent kernel for the whole episode (round 1 enqueued three kernels per tick from the host)
+  if (T <= 8)
+    hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<8>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp, loop->goal_x,
+                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
+  else if (T <= 24)
+    hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<24>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp, loop->goal_x,
+                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
+  else
+    hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<CRX_MPC_MAX_T>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp,
+                       loop->goal_x, loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

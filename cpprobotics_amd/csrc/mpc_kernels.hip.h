@@ -143,15 +143,14 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   f0 = interior || (bf & 1); f1 = interior || (bf & 2);
 }
 
+// One lane's solve.  xi = (x, y, yaw, v) of x0; xr4 = the lane's reference trajectory, T columns (x, y, yaw, v) — global memory
+// in mpc_kernel, the lane's private array in the closed loop; so (may be null) receives the solution in the reference's layout;
+// a0 / d0 = the first acceleration and steering of the solution rounded to float, what mpc_simulation applies (:376).
+// Wave-synchronous: every lane of the wave must call it (finished / padding lanes with live = false).
 template <int MAXT>
-__global__ void __launch_bounds__(64)
-mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
-           float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
-  const size_t agent = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = agent < (size_t)n;
-  const size_t ag = live ? agent : 0;
+__device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, const float4 xi, const float4* __restrict__ xr4, const MpcP& p,
+                                               float* __restrict__ so, int& status_out, double& cost_out, float& a0_out, float& d0_out) {
   const int N = T - 1;
-  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + ag * (size_t)T;
 
   // per-lane problem storage (private memory)
   double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
@@ -213,7 +212,6 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 
   int cur = 0;
   {
-    const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
     S[0][0][0] = S[1][0][0] = (double)xi.x;
     S[0][0][1] = S[1][0][1] = (double)xi.y;
     S[0][0][2] = S[1][0][2] = (double)xi.z;
@@ -538,24 +536,44 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
     }
     if (iter == p.max_iter - 1) it = p.max_iter;
   }
+  status_out = 0; cost_out = 0.0; a0_out = 0.0f; d0_out = 0.0f;
   if (!live) return;
   if (!(status & 1) && !done) it = p.max_iter;
-
-  const size_t nv = 4 * (size_t)T + 2 * (size_t)N;
-  float* __restrict__ so = solg + agent * nv;
   for (int i = 0; i < T; ++i) {
     const double v = S[cur][i][3];
     if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
-    so[i] = (float)S[cur][i][0];
-    so[T + i] = (float)S[cur][i][1];
-    so[2 * T + i] = (float)S[cur][i][2];
-    so[3 * T + i] = (float)v;
+    if (so) {
+      so[i] = (float)S[cur][i][0];
+      so[T + i] = (float)S[cur][i][1];
+      so[2 * T + i] = (float)S[cur][i][2];
+      so[3 * T + i] = (float)v;
+    }
   }
-  for (int i = 0; i < N; ++i) {
-    so[4 * T + i] = (float)U[cur][i][0];
-    so[4 * T + N + i] = (float)U[cur][i][1];
-  }
-  if (statusg) statusg[agent] = status | (it << 8);
+  if (so)
+    for (int i = 0; i < N; ++i) {
+      so[4 * T + i] = (float)U[cur][i][0];
+      so[4 * T + N + i] = (float)U[cur][i][1];
+    }
+  status_out = status | (it << 8);
+  cost_out = J;
+  d0_out = (float)U[cur][0][0];
+  a0_out = (float)U[cur][0][1];
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+           float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  const size_t agent = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = agent < (size_t)n;
+  const size_t ag = live ? agent : 0;
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + ag * (size_t)T;
+  const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
+  const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  if (!live) return;
+  if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
 }
 

@@ -28,6 +28,7 @@
 #include "crx_fdlibm.h"
 #include "crx_trig.h"
 #include "dare_kernels.hip.h"
+#include "mpc_kernels.hip.h"
 
 namespace crx {
 
@@ -332,6 +333,57 @@ mpc_tick_tail_kernel(int n, int T, int tick, float* __restrict__ state, const fl
   if (traj_hist) reinterpret_cast<float4*>(traj_hist)[(size_t)tick * n + a] = s;
   const float dx = s.x - goal_x, dy = s.y - goal_y;
   if (sqrtf(dx * dx + dy * dy) <= goal_dis) active[a] = 0;
+}
+
+// MPC closed loop (mpc_simulation :371-385) for n agents as ONE persistent kernel: per tick calc_ref_trajectory (:130-170, the
+// window search included), mpc_solve (mpc_kernels.hip.h: mpc_solve_lane), update with the first control of the solution (:376),
+// the goal test (:380-384) — state, target_ind and the reference trajectory of a lane stay in registers / the lane's private
+// memory for the whole episode, nothing is enqueued from the host between ticks.  An agent that has reached the goal idles
+// (masked) until the last agent of its wave has; a wave leaves the loop when all its agents have.  The course arrays are read
+// straight from global memory: T gathers per tick against a solve of ~10^5 instructions.
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_closed_loop_kernel(int n, int T, int max_ticks, float* __restrict__ state, CourseView c, float dl, int nsearch, MpcP p, VehicleParams vp,
+                       float goal_x, float goal_y, float goal_dis, int* __restrict__ target_ind, float* __restrict__ traj_hist,
+                       int* __restrict__ ticks_done) {
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = a < (size_t)n;
+  const size_t ag = live ? a : 0;
+  float4 s = reinterpret_cast<const float4*>(state)[ag];
+  int tind = target_ind[ag];
+  int ticks = 0;
+  bool active = live;
+  float4 xr[MAXT];
+  const int last = c.n - 1;
+  for (int tick = 0; tick < max_ticks; ++tick) {
+    if (!__any(active)) break;
+    if (active) {                                                            // calc_ref_trajectory
+      int ind = calc_nearest_index_window_dev(s.x, s.y, c, tind, nsearch);
+      if (tind >= ind) ind = tind;
+      float travel = 0.0f;
+      for (int i = 0; i < T; ++i) {
+        travel = (float)((double)travel + (double)fabsf(s.w) * p.dt);
+        const int dind = (int)roundf(travel / dl);
+        const long long j_ll = (long long)ind + dind;
+        const int j = (j_ll < c.n) ? (int)j_ll : last;
+        xr[i] = make_float4(c.cx[j], c.cy[j], c.cyaw[j], c.sp[j]);
+      }
+      tind = ind;
+    }
+    int st; double J; float a0, d0;
+    mpc_solve_lane<MAXT>(active, T, s, xr, p, nullptr, st, J, a0, d0);
+    if (active) {
+      update_dev(s.x, s.y, s.z, s.w, a0, d0, vp);
+      ticks = tick + 1;
+      if (traj_hist) reinterpret_cast<float4*>(traj_hist)[(size_t)tick * n + a] = s;
+      const float dx = s.x - goal_x, dy = s.y - goal_y;
+      if (sqrtf(dx * dx + dy * dy) <= goal_dis) active = false;
+    }
+  }
+  if (!live) return;
+  reinterpret_cast<float4*>(state)[a] = s;
+  target_ind[a] = tind;
+  ticks_done[a] = ticks;
 }
 
 }  // namespace crx

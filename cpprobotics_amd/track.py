@@ -159,9 +159,8 @@ def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, n
     p = params if params is not None else default_params()
     ticks = torch.zeros((n,), dtype=torch.int32, device=state.device)
     hist = torch.zeros((max_ticks, n, 4), dtype=torch.float32, device=state.device) if want_hist else None
-    work = torch.empty((int(L.lib().crx_mpc_closed_loop_work_bytes(n, T)),), dtype=torch.uint8, device=state.device)
     lp = loop_params(goal, goal_dis, max_ticks)
     L.check(L.lib().crx_mpc_closed_loop_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), int(nsearch), C.byref(p),
-                                                  C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), L.ptr(work),
+                                                  C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), None,
                                                   L.stream_ptr()), "crx_mpc_closed_loop_batch_dev")
     return ticks, hist

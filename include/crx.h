@@ -240,10 +240,10 @@ int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_co
 int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const crx_course* course, float dl, double dt,
                                       int nsearch, int* target_ind, float* xref, void* stream);
 
-/* mpc_simulation's loop (:371-385), maths only: per tick calc_ref_trajectory -> mpc_solve -> update (first control of the
- * solution) -> goal test, for n agents; three kernels per tick enqueued on `stream` (no host synchronisation inside).
- * Agents that reached the goal stop being updated.  target_ind: in/out.  work: device scratch of
- * crx_mpc_closed_loop_work_bytes(n, T) bytes. */
+/* mpc_simulation's loop (src/model_predictive_control.cpp:371-385), maths only: per tick calc_ref_trajectory -> mpc_solve -> update
+ * (first control of the solution) -> goal test, for n agents, the WHOLE episode in one persistent kernel enqueued on `stream`
+ * (state, target_ind and the reference trajectory of an agent never leave the lane between ticks).  Agents that reached the
+ * goal stop being updated.  target_ind: in/out.  work: unused since 0.2 (may be NULL; crx_mpc_closed_loop_work_bytes returns 0). */
 size_t crx_mpc_closed_loop_work_bytes(int n, int T);
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,

@@ -184,7 +184,7 @@ def main():
             "cpu_baseline": {"value": float(tk[:ns].sum()) / t_cpu, "unit": "agent-ticks/s", "cores": min(cores, ns // 4), "kind": "port",
                              "sample": f"first {ns} agents", "single_thread_value": single},
             "parity": {"first_64_agents_bit_identical": same}}))
-    # ---- MPC closed loop (mpc_simulation): 3 kernels per tick ---------------------------------------------------------
+    # ---- MPC closed loop (mpc_simulation): one persistent kernel for the episode ---------------------------------------------------------
     mcourse, mgoal = mpc_course_f32()
     mdc = crx.Course.from_numpy(mcourse)
     n, T, max_ticks = 8192, 6, 50
@@ -193,7 +193,7 @@ def main():
     tind0 = torch.from_numpy(oracle.calc_nearest_index(mst, mcourse)[0].astype(np.int32)).cuda()
     mstd = torch.from_numpy(mst).cuda()
     t_mpc = gpu_time(lambda: crx.mpc_simulation(mstd.clone(), mdc, mgoal, T, max_ticks, target_ind=tind0.clone()), 1 if quick else 2)
-    print(json.dumps({"workload": f"MPC closed loop (mpc_simulation), {n} agents, T={T}, {max_ticks} ticks: calc_ref_trajectory + mpc_solve + update per tick",
+    print(json.dumps({"workload": f"MPC closed loop (mpc_simulation), {n} agents, T={T}, {max_ticks} ticks: calc_ref_trajectory + mpc_solve + update + goal test per tick, one persistent kernel",
                       "agent_ticks_per_s": n * max_ticks / t_mpc, "ms_per_tick": t_mpc / max_ticks * 1e3}))
 
     # ---- particle filter: one vehicle per wavefront, T fused ticks ---------------------------------

@@ -113,21 +113,28 @@ def test_calc_ref_trajectory_bit_exact(crx, oracle_mod):
     assert np.array_equal(crx.calc_nearest_index_window(_t(st), dc, _t(tind0)).cpu().numpy(), wo)
 
 
-def test_mpc_closed_loop_matches_oracle(crx, oracle_mod):
-    """mpc_simulation's loop: the HIP solver and the oracle's twin agree to ~1e-15 per solve, so the loops stay together
-    within the float tolerance of north_star (1e-6, floor 1.0) over the whole episode."""
+@pytest.mark.parametrize("T,n", [(6, 48), (6, 130), (21, 70)])
+def test_mpc_closed_loop_matches_oracle(crx, oracle_mod, T, n):
+    """mpc_simulation's loop as ONE persistent kernel: the HIP solver and the oracle's twin agree to ~1e-15 per solve, so the
+    loops stay together within the float tolerance of north_star (1e-6, floor 1.0) over the whole episode; agents that start
+    near the end of the course reach the goal and stop (same tick as the oracle's)."""
     course, goal = mpc_course_f32()
     dc = crx.Course.from_numpy(course)
-    n, T, max_ticks = 48, 6, 40
+    max_ticks = 40
     st = tracking_agents(n, tuple(c[:150] for c in course), 9, spread=0.5)
     st[:, 3] = np.random.default_rng(10).uniform(0.5, 4.0, n).astype(np.float32)
     st[0] = (course[0][0], course[1][0], course[2][0], course[4][0])          # the reference's start (:349)
+    nc = len(course[0])
+    for k in range(1, 9):                                                      # a few agents a short drive from the goal
+        j = nc - 3 - 2 * k
+        st[k] = (course[0][j], course[1][j], course[2][j], 2.5)
     tind0 = oracle_mod.calc_nearest_index(st, course)[0].astype(np.int32)
     so, tio, histo, tindo = oracle_mod.mpc_closed_loop(st, course, goal, T=T, max_ticks=max_ticks, target_ind=tind0, want_hist=True)
     sd, td = _t(st), _t(tind0)
     ticks, hist = crx.mpc_simulation(sd, dc, goal, T, max_ticks, target_ind=td, want_hist=True)
-    assert np.array_equal(ticks.cpu().numpy(), tio)
-    assert floored_rel_err(hist.cpu().numpy(), histo, 1.0) <= 1e-5
+    assert np.array_equal(ticks.cpu().numpy(), tio) and (tio[1:9] < max_ticks).any()
+    for a in range(n):                                                         # rows past an agent's last tick are not written
+        assert floored_rel_err(hist.cpu().numpy()[: tio[a], a], histo[: tio[a], a], 1.0) <= 1e-5
     assert floored_rel_err(sd.cpu().numpy(), so, 1.0) <= 1e-5
     assert np.array_equal(td.cpu().numpy(), tindo)
 

@@ -11,6 +11,7 @@
 #include "../../include/crx.h"
 #include "dare_kernels.hip.h"
 #include "ekf_kernels.hip.h"
+#include "ekf_wave2_kernels.hip.h"
 #include "mpc_kernels.hip.h"
 #include "track_kernels.hip.h"
 #include "pf_kernels.hip.h"
@@ -238,6 +239,20 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
   else
     hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<false>), grid, block, 0, (hipStream_t)stream, n, T,
                        u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// The two-lanes-per-vehicle A/B variant of the fused launch (ekf_wave2_kernels.hip.h).  Not the production path.
+int crx_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
+                               const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream) {
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run_pair: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  hipLaunchKernelGGL((crx::ekf_run_pair_kernel<4>), dim3(blocks_for(2 * (size_t)n, 64)), dim3(64), 0, (hipStream_t)stream, n, T, x, P, z, u,
+                     x_hist, k, left_domain);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -94,6 +94,13 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
  * u_true: n x 2.  xTrue, xDR: n x 4, updated in place.  Outputs z, ud: [T][n][2].
  * xTrue_hist / xDR_hist ([T][n][4]) may be NULL.  qsim[2], rsim[2] are the diagonal entries
  * Qsim(0,0),Qsim(1,1),Rsim(0,0),Rsim(1,1) (:154-161) as floats. */
+/* EXPERIMENT, not the production path: the fused launch with TWO LANES PER VEHICLE (rows (0,1) / (2,3) of the covariance on the
+ * even / odd lane of a pair, DPP moves across the pair) — the per-wavefront layout north_star sketches, kept so that the A/B
+ * in profiles/r02/ekf_wave_ab.txt can be re-run.  Same results as crx_ekf_run_batch_dev as IEEE values on that kernel's
+ * fast domain (0 < |yaw| < 120, 2^-60 <= |det S| <= 2^60); *left_domain (device int, may be NULL) is OR-ed with 1 if a
+ * vehicle left it, in which case the results are not to be used.  No P history. */
+int crx_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
+                               const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream);
 /* Standard-normal draws for synthetic inputs, keyed by (seed, stream_id, GLOBAL agent id, step) with Philox4x32-10 + Box-Muller
  * (csrc/crx_philox.h): w[t][a][0..3] = the four draws pass t of the reference's loop consumes for agent agent0 + a
  * (src/extended_kalman_filter.cpp:174-181; the reference's own generator is random_device-seeded, :162-164).  The bytes do not

@@ -330,3 +330,20 @@ def test_ekf_step_is_graph_capturable_and_bit_exact(crx, oracle_mod):
     g.replay()
     torch.cuda.synchronize()
     assert bit_equal(xd.cpu().numpy(), x) and bit_equal(Pd.cpu().numpy(), P)
+
+
+def test_two_lanes_per_vehicle_variant_equals_the_production_kernel(crx, oracle_mod):
+    """The A/B variant (ekf_wave2_kernels.hip.h: a vehicle on a pair of lanes, DPP moves across the pair) reproduces the oracle
+    as IEEE values on benign inputs — the numbers of profiles/r02/ekf_wave_ab.txt compare like with like."""
+    import torch
+    from cpprobotics_amd.ekf import ekf_run_pair
+    Q, R = ekf_QR()
+    for n, T in ((1, 9), (33, 64), (1000, 130)):
+        u, x0, P0 = ekf_agents(n, 5 + n)
+        z, ud, *_ = oracle_mod.ekf_simulate_inputs(u, x0, x0, ekf_noise(T, n, 6))
+        xo, Po, xho, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
+        xd, Pd = _t(x0), _t(P0)
+        xh = torch.empty((T, n, 4), device="cuda")
+        flag = ekf_run_pair(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh)
+        assert int(flag.cpu().numpy()[0]) == 0
+        assert np.array_equal(xh.cpu().numpy(), xho) and np.array_equal(xd.cpu().numpy(), xo) and np.array_equal(Pd.cpu().numpy(), Po)

@@ -18,6 +18,7 @@
 #include "dwa_kernels.hip.h"
 #include "frenet_kernels.hip.h"
 #include "crx_philox.h"
+#include "crx_qr.h"
 
 namespace {
 
@@ -833,23 +834,21 @@ void spline1d_build(const float* x, const float* y, int nx, float* a, float* b, 
   std::vector<float> h(nx - 1);
   for (int i = 1; i < nx; ++i) h[i - 1] = x[i] - x[i - 1];
   for (int i = 0; i < nx; ++i) a[i] = y[i];
-  // rows 0 and nx-1 are identity rows with zero right-hand sides (natural spline); the rest is tridiagonal
-  std::vector<double> lo(nx, 0.0), di(nx, 1.0), up(nx, 0.0), rhs(nx, 0.0);
-  for (int i = 0; i < nx - 2; ++i) {
-    lo[i + 1] = h[i];
-    di[i + 1] = (double)(2 * (h[i] + h[i + 1]));
-    up[i + 1] = h[i + 1];
-    rhs[i + 1] = (double)(float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
+  // calc_A :95-109 and calc_B :110-116 as the reference fills them (float entries), then A.colPivHouseholderQr().solve(B) :56
+  std::vector<float> A((size_t)nx * nx, 0.0f), B(nx, 0.0f), sol(nx, 0.0f);
+  auto at = [&](int i, int j) -> float& { return A[i + (size_t)nx * j]; };
+  at(0, 0) = 1;
+  for (int i = 0; i < nx - 1; ++i) {
+    if (i != nx - 2) at(i + 1, i + 1) = 2 * (h[i] + h[i + 1]);
+    at(i + 1, i) = h[i];
+    at(i, i + 1) = h[i];
   }
-  for (int i = 1; i < nx; ++i) {            // Thomas elimination (the matrix is diagonally dominant)
-    const double f = lo[i] / di[i - 1];
-    di[i] -= f * up[i - 1];
-    rhs[i] -= f * rhs[i - 1];
-  }
-  std::vector<double> sol(nx);
-  sol[nx - 1] = rhs[nx - 1] / di[nx - 1];
-  for (int i = nx - 2; i >= 0; --i) sol[i] = (rhs[i] - up[i] * sol[i + 1]) / di[i];
-  for (int i = 0; i < nx; ++i) c[i] = (float)sol[i];
+  at(0, 1) = 0.0;
+  at(nx - 1, nx - 2) = 0.0;
+  at(nx - 1, nx - 1) = 1.0;
+  for (int i = 0; i < nx - 2; ++i) B[i + 1] = (float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
+  crx::colpiv_qr_solve<crx::kFrMaxKnots>(nx, A.data(), B.data(), sol.data());
+  for (int i = 0; i < nx; ++i) c[i] = sol[i];
   for (int i = 0; i < nx - 1; ++i) {
     d[i] = (float)((c[i + 1] - c[i]) / (3.0 * h[i]));
     b[i] = (float)((a[i + 1] - a[i]) / h[i] - h[i] * (c[i + 1] + 2 * c[i]) / 3.0);

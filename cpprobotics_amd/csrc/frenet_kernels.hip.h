@@ -18,7 +18,7 @@
 // (float members, double macros, std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in
 // float).  Differences from the CPU oracle are confined to (a) pow(t,k) formed by exact-operand double products instead
 // of libm pow and (b) the double sin/cos (<= 1 ulp) — each can move a float result by one ulp only when the double lands
-// within 2^-29 of a rounding boundary.  The 3x3 / 2x2 coefficient solves are the oracle's cofactor expression, in double.
+// within 2^-29 of a rounding boundary.  The 3x3 / 2x2 coefficient solves are Eigen's ColPivHouseholderQR restated in float (crx_qr.h).
 // Reference quirks that decide the numbers are kept (the missing factor 5 in the quintic's first derivative,
 // quintic_polynomial.h:53; maxima starting at FLT_MIN); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
 // throw (s before the course) the path is dropped and status bit 2 is set.
@@ -28,6 +28,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "crx_fdlibm.h"
+#include "crx_qr.h"
 #include "mpc_kernels.hip.h"   // mpc_sincos (double)
 
 namespace crx {
@@ -48,31 +49,27 @@ struct FrQuartic { float a0, a1, a2, a3, a4; };
 __device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, float xe, float vxe, float axe, float T) {
   FrQuintic q;
   q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
+  // A and B as the comma initialisers of quintic_polynomial.h:41-47 fill them (double expressions rounded to float entries),
+  // then A.colPivHouseholderQr().solve(B) in float (:49; crx_qr.h)
   const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td, T4 = T2 * T2, T5 = T4 * Td;
-  const double a00 = (double)(float)T3, a01 = (double)(float)T4, a02 = (double)(float)T5;
-  const double a10 = (double)(float)(3.0 * T2), a11 = (double)(float)(4.0 * T3), a12 = (double)(float)(5.0 * T4);
-  const double a20 = (double)(6.0f * T), a21 = (double)(float)(12.0 * T2), a22 = (double)(float)(20.0 * T3);
-  const double b0 = (double)(float)((double)(xe - q.a0 - q.a1 * T) - (double)q.a2 * T2);
-  const double b1 = (double)(vxe - q.a1 - 2.0f * q.a2 * T);
-  const double b2 = (double)(axe - 2.0f * q.a2);
-  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
-  const double c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
-  const double c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
-  const double det = (a00 * c00 + a01 * c01) + a02 * c02;
-  q.a3 = (float)(((c00 * b0 + c10 * b1) + c20 * b2) / det);
-  q.a4 = (float)(((c01 * b0 + c11 * b1) + c21 * b2) / det);
-  q.a5 = (float)(((c02 * b0 + c12 * b1) + c22 * b2) / det);
+  float A[9] = {(float)T3, (float)(3.0 * T2), 6.0f * T,                    // column 0 (column-major)
+                (float)T4, (float)(4.0 * T3), (float)(12.0 * T2),          // column 1
+                (float)T5, (float)(5.0 * T4), (float)(20.0 * T3)};         // column 2
+  float B[3] = {(float)((double)(xe - q.a0 - q.a1 * T) - (double)q.a2 * T2), vxe - q.a1 - 2.0f * q.a2 * T, axe - 2.0f * q.a2};
+  float c[3];
+  colpiv_qr_solve<3>(3, A, B, c);
+  q.a3 = c[0]; q.a4 = c[1]; q.a5 = c[2];
   return q;
 }
 __device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, float vxe, float axe, float T) {
   FrQuartic q;
   q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
-  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td;
-  const double a00 = (double)(float)(3.0 * T2), a01 = (double)(float)(4.0 * T3), a10 = (double)(6.0f * T), a11 = (double)(float)(12.0 * T2);
-  const double b0 = (double)(vxe - q.a1 - 2.0f * q.a2 * T), b1 = (double)(axe - 2.0f * q.a2);
-  const double det = a00 * a11 - a01 * a10;
-  q.a3 = (float)((a11 * b0 - a01 * b1) / det);
-  q.a4 = (float)((a00 * b1 - a10 * b0) / det);
+  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td;                 // quartic_polynomial.h:38-45
+  float A[4] = {(float)(3.0 * T2), 6.0f * T, (float)(4.0 * T3), (float)(12.0 * T2)};
+  float B[2] = {vxe - q.a1 - 2.0f * q.a2 * T, axe - 2.0f * q.a2};
+  float c[2];
+  colpiv_qr_solve<2>(2, A, B, c);
+  q.a3 = c[0]; q.a4 = c[1];
   return q;
 }
 // the evaluation expressions of quintic_polynomial.h:44-62 / quartic_polynomial.h:44-60: float until the first pow, double

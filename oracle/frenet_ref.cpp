@@ -11,10 +11,11 @@
 // Things the reference does that a reader might take for typos are kept, because they decide the numbers:
 //   * QuinticPolynomial::calc_first_derivative ends in a5*t^4, not 5*a5*t^4 (quintic_polynomial.h:53);
 //   * max_speed / max_accel / max_curvature start at numeric_limits<float>::min() (the smallest positive normal).
-// One deliberate difference, stated in DESIGN.md §5e: the reference solves the 3x3 / 2x2 / nx x nx float systems with
-// Eigen's colPivHouseholderQr in float; Eigen is absent, so the systems (with the reference's float-rounded entries) are
-// solved in double and the solution rounded to float — the exact solution's rounding, of which Eigen's is an O(1e-6)
-// relative approximation.  Where the reference runs into undefined behaviour (a path with fewer than two points on the
+// The 3x3 / 2x2 / nx x nx float systems, which the reference hands to Eigen's colPivHouseholderQr in float
+// (quintic_polynomial.h:49, quartic_polynomial.h:45, cubic_spline.h:56), are solved by the float restatement of that
+// algorithm in oracle/eigen_qr.h (round 1 solved them exactly in double; the measured effect of the change is in DESIGN.md 5e).
+// This file is pinned against the reference's own lines: tests/test_oracle_vs_ref.py runs oracle/_ref/libref.so
+// (oracle/ref_shim/ref_frenet.cpp) on the same inputs and demands equal bits.  Where the reference runs into undefined behaviour (a path with fewer than two points on the
 // course: vector::back() of an empty vector, size()-1 wrapping) the path is dropped; where it would throw (s before the
 // course) the path is dropped and status bit 2 set; no surviving path ends the agent's episode with status bit 0.
 #include <cmath>
@@ -22,6 +23,7 @@
 #include <cstring>
 #include <limits>
 #include <vector>
+#include "eigen_qr.h"
 
 namespace {
 
@@ -32,23 +34,12 @@ struct FrenetCfg {   // the #defines :20-38, as the double expressions they expa
 };
 
 // ---- cubic_spline.h ----------------------------------------------------------------------------------------------
-// dense Gaussian elimination with partial pivoting, in double (stands in for colPivHouseholderQr().solve, see header)
-void solve_dense(int n, std::vector<double>& A, std::vector<double>& b) {
-  for (int k = 0; k < n; ++k) {
-    int piv = k;
-    for (int i = k + 1; i < n; ++i) if (std::fabs(A[i * n + k]) > std::fabs(A[piv * n + k])) piv = i;
-    if (piv != k) { for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[piv * n + j]); std::swap(b[k], b[piv]); }
-    for (int i = k + 1; i < n; ++i) {
-      const double f = A[i * n + k] / A[k * n + k];
-      for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
-      b[i] -= f * b[k];
-    }
-  }
-  for (int k = n - 1; k >= 0; --k) {
-    double s = b[k];
-    for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * b[j];
-    b[k] = s / A[k * n + k];
-  }
+// A.colPivHouseholderQr().solve(B) for a column-major float system (oracle/eigen_qr.h)
+void solve_qr(int n, const std::vector<float>& A, const std::vector<float>& b, std::vector<float>& x) {
+  oracle::ColPivQR<float> qr(n, n);
+  qr.compute(A.data());
+  x.resize(n);
+  qr.solve(b.data(), x.data());
 }
 
 struct Spline {   // cubic_spline.h:39-128
@@ -58,21 +49,20 @@ struct Spline {   // cubic_spline.h:39-128
   Spline(const std::vector<float>& x_, const std::vector<float>& y_) : x(x_), a(y_), nx((int)x_.size()) {
     std::vector<float> h(nx - 1);
     for (int i = 1; i < nx; ++i) h[i - 1] = x[i] - x[i - 1];
-    std::vector<double> A((size_t)nx * nx, 0.0), B(nx, 0.0);
-    A[0] = 1.0;                                                     // calc_A :95-109 (float entries)
+    std::vector<float> A((size_t)nx * nx, 0.0f), B(nx, 0.0f);      // column-major: A(i, j) = A[i + nx * j]
+    auto at = [&](int i, int j) -> float& { return A[i + (size_t)nx * j]; };
+    at(0, 0) = 1;                                                   // calc_A :95-109
     for (int i = 0; i < nx - 1; ++i) {
-      if (i != nx - 2) A[(i + 1) * nx + i + 1] = (double)(2 * (h[i] + h[i + 1]));
-      A[(i + 1) * nx + i] = h[i];
-      A[i * nx + i + 1] = h[i];
+      if (i != nx - 2) at(i + 1, i + 1) = 2 * (h[i] + h[i + 1]);
+      at(i + 1, i) = h[i];
+      at(i, i + 1) = h[i];
     }
-    A[1] = 0.0;
-    A[(nx - 1) * nx + nx - 2] = 0.0;
-    A[(nx - 1) * nx + nx - 1] = 1.0;
+    at(0, 1) = 0.0;
+    at(nx - 1, nx - 2) = 0.0;
+    at(nx - 1, nx - 1) = 1.0;
     for (int i = 0; i < nx - 2; ++i)                                 // calc_B :110-116 (double expression, float entry)
-      B[i + 1] = (double)(float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
-    solve_dense(nx, A, B);
-    c.resize(nx);
-    for (int i = 0; i < nx; ++i) c[i] = (float)B[i];
+      B[i + 1] = (float)(3.0 * (a[i + 2] - a[i + 1]) / h[i + 1] - 3.0 * (a[i + 1] - a[i]) / h[i]);
+    solve_qr(nx, A, B, c);
     for (int i = 0; i < nx - 1; ++i) {                               // :61-64
       d.push_back((float)((c[i + 1] - c[i]) / (3.0 * h[i])));
       b.push_back((float)((a[i + 1] - a[i]) / h[i] - h[i] * (c[i + 1] + 2 * c[i]) / 3.0));
@@ -135,23 +125,18 @@ struct Spline2D {   // :130-178
 };
 
 // ---- quintic_polynomial.h / quartic_polynomial.h --------------------------------------------------------------------
-// x = A^-1 B by cofactors, in double, from float-rounded entries; the crx kernel evaluates the same expression tree.
+// x = A.colPivHouseholderQr().solve(B), in float; A row by row as the comma initialisers of the reference fill it
 void solve3(const float A[3][3], const float B[3], float x[3]) {
-  const double a00 = A[0][0], a01 = A[0][1], a02 = A[0][2], a10 = A[1][0], a11 = A[1][1], a12 = A[1][2], a20 = A[2][0],
-               a21 = A[2][1], a22 = A[2][2], b0 = B[0], b1 = B[1], b2 = B[2];
-  const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
-  const double c10 = a02 * a21 - a01 * a22, c11 = a00 * a22 - a02 * a20, c12 = a01 * a20 - a00 * a21;
-  const double c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
-  const double det = (a00 * c00 + a01 * c01) + a02 * c02;
-  x[0] = (float)(((c00 * b0 + c10 * b1) + c20 * b2) / det);
-  x[1] = (float)(((c01 * b0 + c11 * b1) + c21 * b2) / det);
-  x[2] = (float)(((c02 * b0 + c12 * b1) + c22 * b2) / det);
+  std::vector<float> Am(9), Bm(B, B + 3), xv;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Am[i + 3 * j] = A[i][j];
+  solve_qr(3, Am, Bm, xv);
+  x[0] = xv[0]; x[1] = xv[1]; x[2] = xv[2];
 }
 void solve2(const float A[2][2], const float B[2], float x[2]) {
-  const double a00 = A[0][0], a01 = A[0][1], a10 = A[1][0], a11 = A[1][1], b0 = B[0], b1 = B[1];
-  const double det = a00 * a11 - a01 * a10;
-  x[0] = (float)((a11 * b0 - a01 * b1) / det);
-  x[1] = (float)((a00 * b1 - a10 * b0) / det);
+  std::vector<float> Am(4), Bm(B, B + 2), xv;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) Am[i + 2 * j] = A[i][j];
+  solve_qr(2, Am, Bm, xv);
+  x[0] = xv[0]; x[1] = xv[1];
 }
 
 struct Quintic {   // quintic_polynomial.h:39-69

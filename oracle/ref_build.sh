@@ -49,6 +49,12 @@ ext src/model_predictive_control.cpp 107 186 mpc_ref_traj.inc    # calc_nearest_
 ext src/model_predictive_control.cpp 188 346 mpc_nlp.inc         # FG_EVAL, mpc_solve
 ext src/model_predictive_control.cpp 349 360 mpc_sim_setup.inc   # State state(...), yaw wrap, goal_dis, target_ind, smooth_yaw
 ext src/model_predictive_control.cpp 372 385 mpc_sim_body.inc    # calc_ref_trajectory, mpc_solve, update, goal test
+# ---- src/dynamic_window_approach.cpp (no Eigen in it)
+ext src/dynamic_window_approach.cpp 16 41 dwa_types.inc          # PI, the array aliases, class Config
+ext src/dynamic_window_approach.cpp 43 155 dwa_fns.inc           # motion … dwa_control
+# ---- src/frenet_optimal_trajectory.cpp (+ the headers it includes, taken from $REF/include as they are)
+ext src/frenet_optimal_trajectory.cpp 20 38 frenet_defs.inc      # SIM_LOOP … KLON
+ext src/frenet_optimal_trajectory.cpp 40 176 frenet_fns.inc      # using namespace, sum_of_power … frenet_optimal_planning
 
 if echo '#include <Eigen/Eigen>' | g++ -x c++ -fsyntax-only - 2>/dev/null; then EIGEN_INC=""; KIND=1
 elif [ -f /usr/include/eigen3/Eigen/Eigen ]; then EIGEN_INC="-I/usr/include/eigen3"; KIND=1

@@ -240,3 +240,56 @@ def mpc_simulation(course, goal, T, max_ticks, solver):
     cb = _wrap_solver(T, solver)
     ticks = f(_I(max_ticks), _I(len(cx)), _p(cx), _p(cy), _p(cyaw), _p(ck), _p(sp), _F(goal[0]), _F(goal[1]), cb, _p(traj), _p(ctl), _p(cs))
     return ticks, traj[:ticks], ctl[:ticks], cs
+
+
+# ---- dynamic window (src/dynamic_window_approach.cpp) and Frenet planner (src/frenet_optimal_trajectory.cpp) -------------------
+def dwa_config():
+    out = np.zeros(12, np.float32)
+    f = lib().ref_dwa_config_floats
+    f.restype = _I
+    assert f(_p(out)) == 12
+    return out
+
+
+def dwa_run(state, u, goal, ob, max_ticks, cfg=None):
+    state, u, goal, ob = _f32(state).copy(), _f32(u).copy(), _f32(goal), _f32(ob)
+    cfg = dwa_config() if cfg is None else _f32(cfg)
+    n = len(state)
+    traj = np.zeros((max_ticks, n, 5), np.float32)
+    ticks = np.zeros(n, np.int32)
+    lib().ref_dwa_run(_I(n), _I(max_ticks), _p(state), _p(u), _p(goal), _p(ob), _I(len(ob)), _p(cfg), _p(traj), _p(ticks))
+    return state, u, ticks, traj
+
+
+def frenet_spline_build(wx, wy):
+    wx, wy = _f32(wx), _f32(wy)
+    coef = np.zeros((9, len(wx)), np.float32)
+    lib().ref_frenet_spline_build(_p(wx), _p(wy), _I(len(wx)), _p(coef))
+    return coef
+
+
+def quintic(args7):
+    a = _f32(args7)
+    out = np.zeros((len(a), 3), np.float32)
+    lib().ref_quintic(_I(len(a)), _p(a), _p(out))
+    return out
+
+
+def quartic(args6):
+    a = _f32(args6)
+    out = np.zeros((len(a), 2), np.float32)
+    lib().ref_quartic(_I(len(a)), _p(a), _p(out))
+    return out
+
+
+def frenet_run(state, wx, wy, goal, ob, max_ticks, want_paths=False, cap=4096):
+    state, wx, wy, goal, ob = _f32(state).copy(), _f32(wx), _f32(wy), _f32(goal), _f32(ob)
+    n = len(state)
+    hist = np.zeros((max_ticks, n, 8), np.float32)
+    ticks = np.zeros(n, np.int32); status = np.zeros(n, np.int32)
+    pcf = np.zeros((n, cap), np.float32) if want_paths else None
+    pok = np.zeros((n, cap), np.int32) if want_paths else None
+    npth = np.zeros(n, np.int32) if want_paths else None
+    lib().ref_frenet_run(_I(n), _I(max_ticks), _p(state), _p(wx), _p(wy), _I(len(wx)), _p(goal), _p(ob), _I(len(ob)), _p(hist), _p(ticks),
+                         _p(status), _p(pcf), _p(pok), _p(npth), _I(cap))
+    return dict(state=state, hist=hist, ticks=ticks, status=status, path_cf=pcf, path_ok=pok, n_paths=npth)

@@ -236,3 +236,59 @@ def test_mpc_simulation_loop_with_the_oracle_solver(host_trig):
     st0 = np.array([[cx[0], cy[0], cyaw[0], sp[0]]], np.float32)
     so, to, ho, _ = o.mpc_closed_loop(st0, course, goal, T, 60, want_hist=True)
     assert ticks == to[0] == 60 and _eq(ho[:60, 0], traj)
+
+
+# ---- the two sampling planners --------------------------------------------------------------------------------------
+def test_dwa_episodes(host_trig):
+    o = host_trig
+    O = o.oracle_lib
+    rng = np.random.default_rng(61)
+    n = 10
+    st = np.stack([rng.uniform(-1, 9, n), rng.uniform(-1, 9, n), rng.uniform(-3.2, 3.2, n), rng.uniform(-0.5, 1.0, n),
+                   rng.uniform(-0.69, 0.69, n)], axis=1).astype(np.float32)
+    st[0] = (0.0, 0.0, 3.141592653 / 8.0, 0.0, 0.0)                                   # the reference's start (:167)
+    u = st[:, 3:5].copy()
+    goal = np.stack([rng.uniform(8, 12, n), rng.uniform(8, 12, n)], axis=1).astype(np.float32)
+    goal[0] = (10.0, 10.0)
+    assert _eq(R.dwa_config(), O.DWA_CONFIG)                                          # class Config :25-41
+    so, uo, to, ho = o.dwa_run(st, u, goal, 80, want_hist=True)
+    sr, ur, tr, hr = R.dwa_run(st, u, goal, O.DWA_OBSTACLES, 80)
+    assert _eq(to, tr) and _eq(so, sr) and _eq(uo, ur)
+    for a in range(n):
+        assert _eq(ho[: to[a], a], hr[: tr[a], a])
+
+
+def test_polynomial_coefficients_and_spline_table(oracle_mod):
+    """colPivHouseholderQr().solve() call sites: quintic 3x3 (:49), quartic 2x2 (:45), Spline nx x nx (cubic_spline.h:56)."""
+    O = oracle_mod.oracle_lib
+    assert _eq(oracle_mod.frenet_spline_build(), R.frenet_spline_build(O.FRENET_WX, O.FRENET_WY))
+    rng = np.random.default_rng(62)
+    for nx in (2, 3, 7, 20):
+        wx = np.cumsum(rng.uniform(2.0, 12.0, nx)).astype(np.float32); wy = rng.uniform(-8, 8, nx).astype(np.float32)
+        assert _eq(oracle_mod.frenet_spline_build(wx, wy), R.frenet_spline_build(wx, wy))
+
+
+def test_frenet_candidates_and_episodes(oracle_mod):
+    o = oracle_mod
+    O = o.oracle_lib
+    coef = o.frenet_spline_build()
+    rx, ry = o.frenet_course_samples(coef)
+    goal = [rx[-1], ry[-1]]
+    rng = np.random.default_rng(63)
+    n = 10
+    st = np.stack([rng.uniform(0.0, 40.0, n), rng.uniform(1.0, 9.0, n), rng.uniform(-3.0, 3.0, n), rng.uniform(-0.8, 0.8, n),
+                   rng.uniform(-0.5, 0.5, n)], axis=1).astype(np.float32)
+    st[0] = O.FRENET_STATE0                                                            # the reference's start (:215-219)
+    p = o.frenet_plan(st, coef)
+    r1 = R.frenet_run(st, O.FRENET_WX, O.FRENET_WY, goal, O.FRENET_OBSTACLES, 1, want_paths=True, cap=p["path_cf"].shape[1])
+    assert _eq(p["n_paths"], r1["n_paths"]) and _eq(p["path_ok"], r1["path_ok"]) and np.array_equal(p["path_cf"], r1["path_cf"], equal_nan=True)
+    ro = o.frenet_run(st, coef, goal, 25, want_hist=True)
+    rr = R.frenet_run(st, O.FRENET_WX, O.FRENET_WY, goal, O.FRENET_OBSTACLES, 25)
+    assert _eq(ro["ticks"], rr["ticks"]) and _eq(ro["status"] & 1, rr["status"] & 1)
+    for a in range(n):
+        assert _eq(ro["hist"][: ro["ticks"][a], a], rr["hist"][: rr["ticks"][a], a])
+    # the reference's own scenario, start to goal: 98 planning calls, threads the obstacles, same trajectory
+    full_o = o.frenet_run(st[:1], coef, goal, 500, want_hist=True)
+    full_r = R.frenet_run(st[:1], O.FRENET_WX, O.FRENET_WY, goal, O.FRENET_OBSTACLES, 500)
+    assert full_r["ticks"][0] == full_o["ticks"][0] == 98 and full_r["status"][0] == 0
+    assert _eq(full_o["hist"][:98, 0], full_r["hist"][:98, 0])

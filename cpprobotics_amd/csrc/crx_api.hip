@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -942,6 +943,72 @@ int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, i
     ++k;
   }
   return k;
+}
+
+// The course the reference's LQR / MPC mains build from their way-points: Spline2D(wx, wy) sampled every `ds`
+// (src/lqr_speed_steer_control.cpp:252-265 with ds = 0.1, src/model_predictive_control.cpp:473-486 with ds = 1.0): position
+// (calc_postion), heading (calc_yaw = atan2 of the first derivatives) and curvature (calc_curvature) per sample.  Host, once
+// per course.  Returns the number of samples; fills up to cap of each non-null array.
+int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double ds, float* cx, float* cy, float* cyaw, float* ck, int cap) {
+  if (!wx || !wy || nx < 2 || nx > crx::kFrMaxKnots || !(ds > 0.0) || cap < 0) return fail(CRX_ERR_INVALID, "course_from_waypoints: bad argument");
+  std::vector<float> coef(9 * (size_t)nx);
+  if (int rc = crx_frenet_spline_build(wx, wy, nx, coef.data())) return rc;
+  const float* s = coef.data();
+  const float *ax = s + nx, *bx = s + 2 * nx, *cxx = s + 3 * nx, *dx_ = s + 4 * nx, *ay = s + 5 * nx, *by = s + 6 * nx, *cyy = s + 7 * nx, *dy_ = s + 8 * nx;
+  int k = 0;
+  for (float i = 0; i < s[nx - 1]; i += ds) {                      // float i += double literal, as the mains write it
+    if (k < cap) {
+      const int seg = host_bisect(s, i, 0, nx), segd = host_bisect(s, i, 0, nx - 1);   // calc / calc_dd use bisect(t,0,nx), calc_d bisect(t,0,nx-1)
+      const float e = i - s[seg], ed = i - s[segd];
+      if (cx) cx[k] = ax[seg] + bx[seg] * e + cxx[seg] * e * e + dx_[seg] * e * e * e;
+      if (cy) cy[k] = ay[seg] + by[seg] * e + cyy[seg] * e * e + dy_[seg] * e * e * e;
+      const float d1x = bx[segd] + 2 * cxx[segd] * ed + 3 * dx_[segd] * ed * ed;
+      const float d1y = by[segd] + 2 * cyy[segd] * ed + 3 * dy_[segd] * ed * ed;
+      if (cyaw) cyaw[k] = std::atan2(d1y, d1x);
+      if (ck) {
+        const float ddx = 2 * cxx[seg] + 6 * dx_[seg] * e, ddy = 2 * cyy[seg] + 6 * dy_[seg] * e;
+        ck[k] = (ddy * d1x - ddx * d1y) / (d1x * d1x + d1y * d1y);
+      }
+    }
+    ++k;
+  }
+  return k;
+}
+
+// calc_speed_profile of the two tracking files.  variant 5 (src/lqr_speed_steer_control.cpp:40-62): direction flips where the
+// heading jumps by pi/4..pi/2, zero at the switch points, then the last 39 entries ramp down as target/(50-k) with a floor of
+// 1/3.6 — the reference's k = 0 pass writes one element PAST the end of the vector (:55-56); that write is not made here.
+// variant 0 (src/model_predictive_control.cpp:83-105): sign from the direction of travel against the heading; the reference's
+// `speed_profile[-1] = 0.0` (:102) writes BEFORE the vector, so the last entry keeps its value, as here.
+int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp) {
+  if ((variant != 0 && variant != 5) || n < 1 || !ryaw || !sp || (variant == 0 && (!rx || !ry))) return fail(CRX_ERR_INVALID, "calc_speed_profile: bad argument");
+  for (int i = 0; i < n; ++i) sp[i] = target_speed;
+  float direction = 1.0;
+  if (variant == 5) {
+    for (int i = 0; i + 1 < n; ++i) {
+      const float dyaw = std::abs(ryaw[i + 1] - ryaw[i]);
+      const float switch_point = (M_PI / 4.0 < dyaw) && (dyaw < M_PI / 2.0);
+      if (switch_point) direction = direction * -1;
+      if (direction != 1.0) sp[i] = target_speed * -1; else sp[i] = target_speed;
+      if (switch_point) sp[i] = 0.0;
+    }
+    for (int k = 1; k < 40 && k <= n; ++k) {
+      sp[n - k] = target_speed / (50 - k);
+      if (sp[n - k] <= 1.0 / 3.6) sp[n - k] = 1.0 / 3.6;
+    }
+  } else {
+    for (int i = 0; i + 1 < n; ++i) {
+      const float dx = rx[i + 1] - rx[i], dy = ry[i + 1] - ry[i];
+      const float move_direction = std::atan2(dy, dx);
+      if (dx != 0.0 && dy != 0.0) {
+        const double a = (double)(move_direction - ryaw[i]);
+        const float dangle = std::abs((float)(std::fmod(std::fmod(a + M_PI, 2 * M_PI) - 2 * M_PI, 2 * M_PI) + M_PI));   // YAW_P2P, motion_model.h:18
+        if (dangle >= M_PI / 4.0) direction = -1.0; else direction = 1.0;
+      }
+      if (direction != 1.0) sp[i] = -1 * target_speed; else sp[i] = target_speed;
+    }
+  }
+  return CRX_OK;
 }
 
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,

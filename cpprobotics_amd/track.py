@@ -36,6 +36,22 @@ class Course:
         return C.byref(self.c)
 
 
+def course_from_waypoints(wx, wy, ds, target_speed=10.0 / 3.6, variant=5):
+    """The course arrays (cx, cy, cyaw, ck, speed_profile) the reference's mains build: Spline2D(wx, wy) sampled every ds
+    (lqr files ds = 0.1, MPC ds = 1.0) and calc_speed_profile (variant 5 = lqr_speed_steer_control.cpp, 0 = MPC).  numpy, host."""
+    import numpy as np
+    wx = np.ascontiguousarray(wx, dtype=np.float32); wy = np.ascontiguousarray(wy, dtype=np.float32)
+    l = L.lib()
+    k = l.crx_course_from_waypoints(wx.ctypes.data, wy.ctypes.data, len(wx), float(ds), None, None, None, None, 0)
+    if k < 0:
+        L.check(k, "crx_course_from_waypoints")
+    cx, cy, cyaw, ck, sp = (np.zeros(k, np.float32) for _ in range(5))
+    l.crx_course_from_waypoints(wx.ctypes.data, wy.ctypes.data, len(wx), float(ds), cx.ctypes.data, cy.ctypes.data, cyaw.ctypes.data, ck.ctypes.data, k)
+    L.check(l.crx_calc_speed_profile(int(variant), cx.ctypes.data, cy.ctypes.data, cyaw.ctypes.data, k, float(target_speed), sp.ctypes.data),
+            "crx_calc_speed_profile")
+    return cx, cy, cyaw, ck, sp
+
+
 def _lqr_params(dt, Lw, eps, maxiter):
     p = L.LqrParams()
     p.dt, p.L, p.eps, p.maxiter = float(dt), float(Lw), float(eps), int(maxiter)

@@ -323,6 +323,13 @@ int crx_frenet_num_paths(const crx_frenet_config* cfg);
 int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef);
 /* host: the course sampled as main :205-213 does (float i += 0.1); returns the sample count, fills up to cap of them */
 int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap);
+/* host: the course the reference's tracking mains build from their way-points — Spline2D(wx, wy) (include/cubic_spline.h:130-178,
+ * the nx x nx system by colPivHouseholderQr in float) sampled every ds: src/lqr_speed_steer_control.cpp:252-265 (ds = 0.1),
+ * src/model_predictive_control.cpp:473-486 (ds = 1.0).  Returns the sample count; fills up to cap of each non-NULL array. */
+int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double ds, float* cx, float* cy, float* cyaw, float* ck, int cap);
+/* host: calc_speed_profile, variant 5 = src/lqr_speed_steer_control.cpp:40-62, variant 0 = src/model_predictive_control.cpp:83-105;
+ * the two out-of-bounds writes of the reference (:55-56 k = 0, :102) are not made. */
+int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp);
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,

@@ -35,6 +35,7 @@ ext src/lqr_speed_steer_control.cpp 65 164 lqr5_fns.inc          # calc_nearest_
 ext src/lqr_speed_steer_control.cpp 167 171 lqr5_loop_setup.inc  # T, goal_dis, stop_speed, State state(...)
 ext src/lqr_speed_steer_control.cpp 185 186 lqr5_loop_e.inc      # e, e_th
 ext src/lqr_speed_steer_control.cpp 195 205 lqr5_loop_body.inc   # control, update, goal test
+ext src/lqr_speed_steer_control.cpp 252 265 lqr5_main_course.inc # Spline2D csp_obj(wx, wy) … the sampling loop (ds = 0.1)
 # ---- src/lqr_steer_control.cpp (4-state)
 ext src/lqr_steer_control.cpp 20 23 lqr4_defs.inc
 ext src/lqr_steer_control.cpp 55 146 lqr4_fns.inc               # calc_nearest_index, solve_DARE, dlqr, lqr_steering_control, update
@@ -49,6 +50,7 @@ ext src/model_predictive_control.cpp 107 186 mpc_ref_traj.inc    # calc_nearest_
 ext src/model_predictive_control.cpp 188 346 mpc_nlp.inc         # FG_EVAL, mpc_solve
 ext src/model_predictive_control.cpp 349 360 mpc_sim_setup.inc   # State state(...), yaw wrap, goal_dis, target_ind, smooth_yaw
 ext src/model_predictive_control.cpp 372 385 mpc_sim_body.inc    # calc_ref_trajectory, mpc_solve, update, goal test
+ext src/model_predictive_control.cpp 473 486 mpc_main_course.inc # Spline2D csp_obj(wx, wy) … the sampling loop (ds = 1.0)
 # ---- src/dynamic_window_approach.cpp (no Eigen in it)
 ext src/dynamic_window_approach.cpp 16 41 dwa_types.inc          # PI, the array aliases, class Config
 ext src/dynamic_window_approach.cpp 43 155 dwa_fns.inc           # motion … dwa_control

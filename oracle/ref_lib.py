@@ -293,3 +293,14 @@ def frenet_run(state, wx, wy, goal, ob, max_ticks, want_paths=False, cap=4096):
     lib().ref_frenet_run(_I(n), _I(max_ticks), _p(state), _p(wx), _p(wy), _I(len(wx)), _p(goal), _p(ob), _I(len(ob)), _p(hist), _p(ticks),
                          _p(status), _p(pcf), _p(pok), _p(npth), _I(cap))
     return dict(state=state, hist=hist, ticks=ticks, status=status, path_cf=pcf, path_ok=pok, n_paths=npth)
+
+
+def main_course(wx, wy, which="lqr"):
+    """The sampling loops of the reference's mains: lqr_speed_steer_control.cpp:252-265 (ds 0.1) / model_predictive_control.cpp:473-486 (ds 1.0)."""
+    wx, wy = _f32(wx), _f32(wy)
+    cap = 100000
+    out = [np.zeros(cap, np.float32) for _ in range(4)]
+    f = lib().ref_lqr5_main_course if which == "lqr" else lib().ref_mpc6_main_course
+    f.restype = _I
+    k = f(_p(wx), _p(wy), _I(len(wx)), *[_p(a) for a in out], _I(cap))
+    return tuple(a[:k] for a in out)

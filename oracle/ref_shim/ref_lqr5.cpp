@@ -84,4 +84,13 @@ void ref_lqr5_closed_loop(int n, int max_ticks, float* state0, int nc, const flo
   }
 }
 
+// main() :252-265: the course sampled from the way-points.  Returns the sample count; arrays of capacity cap.
+int ref_lqr5_main_course(const float* wx_, const float* wy_, int nx, float* cx, float* cy, float* cyaw, float* ck, int cap) {
+  Vec_f wx(wx_, wx_ + nx), wy(wy_, wy_ + nx);
+#include "lqr5_main_course.inc"
+  const int k = (int)r_x.size();
+  for (int i = 0; i < k && i < cap; ++i) { cx[i] = r_x[i]; cy[i] = r_y[i]; cyaw[i] = ryaw[i]; ck[i] = rcurvature[i]; }
+  return k;
+}
+
 }  // extern "C"

@@ -131,5 +131,14 @@ int SYM(simulation)(int max_ticks, int nc, const float* cx_, const float* cy_, c
   return ticks;
 }
 
+// main() :473-486 (ds = 1.0)
+int SYM(main_course)(const float* wx_, const float* wy_, int nx, float* cx, float* cy, float* cyaw, float* ck, int cap) {
+  Vec_f wx(wx_, wx_ + nx), wy(wy_, wy_ + nx);
+#include "mpc_main_course.inc"
+  const int k = (int)r_x.size();
+  for (int i = 0; i < k && i < cap; ++i) { cx[i] = r_x[i]; cy[i] = r_y[i]; cyaw[i] = ryaw[i]; ck[i] = rcurvature[i]; }
+  return k;
+}
+
 }  // extern "C"
 }  // namespace

@@ -292,3 +292,17 @@ def test_frenet_candidates_and_episodes(oracle_mod):
     full_r = R.frenet_run(st[:1], O.FRENET_WX, O.FRENET_WY, goal, O.FRENET_OBSTACLES, 500)
     assert full_r["ticks"][0] == full_o["ticks"][0] == 98 and full_r["status"][0] == 0
     assert _eq(full_o["hist"][:98, 0], full_r["hist"][:98, 0])
+
+
+def test_course_generation_of_the_mains():
+    """The product's host course builder (crx_course_from_waypoints: Spline2D by float QR, calc_postion / calc_yaw /
+    calc_curvature sampled every ds) against the sampling loops of the reference's own mains."""
+    import cpprobotics_amd as crx
+    lqr_w = ([0.0, 6.0, 12.5, 10.0, 17.5, 20.0, 25.0], [0.0, -3.0, -5.0, 6.5, 3.0, 0.0, 0.0])            # lqr_speed_steer_control.cpp:249-250
+    mpc_w = ([0.0, 60.0, 125.0, 50.0, 75.0, 35.0, -10.0], [0.0, 0.0, 50.0, 65.0, 30.0, 50.0, -20.0])     # model_predictive_control.cpp:469-471
+    for (wx, wy), ds, which in ((lqr_w, 0.1, "lqr"), (mpc_w, 1.0, "mpc")):
+        cx, cy, cyaw, ck, sp = crx.course_from_waypoints(wx, wy, ds, variant=5 if which == "lqr" else 0)
+        rx, ry, ryaw, rk = R.main_course(wx, wy, which)
+        assert len(cx) == len(rx) > 100
+        assert _eq(cx, rx) and _eq(cy, ry) and _eq(cyaw, ryaw) and _eq(ck, rk)
+        assert np.isfinite(sp).all() and abs(abs(sp[0]) - 10.0 / 3.6) < 1e-6

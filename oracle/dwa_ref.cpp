@@ -3,8 +3,9 @@
 //
 // CPU restatement of the reference's dynamic-window planner, /root/reference/src/dynamic_window_approach.cpp:
 //   Config :25-41, motion :43-50, calc_dynamic_window :52-60, calc_trajectory :63-74, calc_obstacle_cost :77-101,
-//   calc_to_goal_cost :103-113, calc_final_input :115-145, dwa_control :148-155, main loop :192-194 + goal test :225,
-// statement by statement with the host libm (cosf, sinf, acosf, sqrtf, pow, sqrt).  PARITY-UNPINNED (no reference tests).
+//   calc_to_goal_cost :103-113, calc_final_input :115-145, dwa_control :148-155, main loop :192-194 + goal test :221,
+// statement by statement with the host libm (cosf, sinf, acosf, sqrtf, pow, sqrt).  
+// PINNED against the reference's own lines (oracle/ref_build.sh compiles them unmodified — this file needs no Eigen — and tests/test_oracle_vs_ref.py demands equal bits).
 #include <array>
 #include <cfloat>
 #include <cmath>
@@ -121,7 +122,7 @@ void oracle_dwa_control(int n, const float* state, float* u, const float* goal, 
   }
 }
 
-// main loop :192-194 + goal test :225, max_ticks iterations at most: dwa_control -> motion -> goal test.
+// main loop :192-194 + goal test :221, max_ticks iterations at most: dwa_control -> motion -> goal test.
 void oracle_dwa_run(int n, int max_ticks, float* state, float* u, const float* goal, const float* ob, int nob, const float* cfg,
                     float* traj_hist, int* ticks_done, int a0, int a1) {
   Config c; std::memcpy(&c, cfg, sizeof(c));

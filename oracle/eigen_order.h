@@ -5,7 +5,8 @@
 // operation, how Eigen 3.3.x evaluates the small fixed-size float products the reference
 // writes (un-vendored dependency: `find_package(Eigen3 REQUIRED)`, /root/reference/CMakeLists.txt:13;
 // Debian-11 libeigen3-dev => Eigen 3.3.9 per .devcontainer/Dockerfile).  Eigen itself is absent
-// from this image, so this restatement is PARITY-UNPINNED: it follows the published
+// from this image, so this restatement is UNPINNED against Eigen's binary (the one thing the reference-line build of
+// oracle/ref_build.sh cannot check on a host without Eigen): it follows the published
 // Eigen 3.3.9 sources (Core/ProductEvaluators.h, Core/AssignEvaluator.h, Core/Redux.h,
 // arch/SSE/PacketMath.h), not an execution of them.
 //

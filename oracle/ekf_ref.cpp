@@ -5,10 +5,11 @@
 //   /root/reference/src/extended_kalman_filter.cpp:22-78 (motion_model, jacobF,
 //   observation_model, jacobH, ekf_estimation) and the input side of its main loop :171-183,
 // written as the dense matrix expressions the reference writes, evaluated in the order
-// Eigen 3.3.9 evaluates them (oracle/eigen_order.h).  PARITY-UNPINNED: the reference holds no
-// tests or golden vectors and Eigen is not in this image, so this file is validated only
-// against an independent numpy-float32 twin (oracle/np_twin.py), a float64 evaluation and the
-// filter's own invariants (tests/test_oracle_ekf.py).
+// Eigen 3.3.9 evaluates them (oracle/eigen_order.h).  PINNED against the reference's own lines (oracle/ref_build.sh compiles them unmodified — against the host's Eigen, or against the
+// Eigen stand-in oracle/ref_shim/Eigen/Eigen where there is none — and tests/test_oracle_vs_ref.py demands equal bits); unpinned only
+// with respect to Eigen's own binary, absent from every host of this project.
+// Also validated against an independent numpy-float32 twin (oracle/np_twin.py), a float64 evaluation and the filter's own
+// invariants (tests/test_oracle_ekf.py).
 //
 // Build: oracle/Makefile (g++ -O2 -ffp-contract=off, no -march: SSE2, no FMA — the reference's
 // own arithmetic, CMakeLists.txt:4-6).

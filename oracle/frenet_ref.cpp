@@ -1,6 +1,8 @@
 // frenet_ref.cpp — CPU restatement of the reference's Frenet optimal-trajectory planner.  TEST INFRASTRUCTURE ONLY: only
-// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.  PARITY UNPINNED (the reference has no
-// tests or golden vectors for this path and needs Eigen + OpenCV to build, neither of which is in this image).
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.  
+// PINNED against the reference's own lines (oracle/ref_build.sh compiles them unmodified — against the host's Eigen, or against the
+// Eigen stand-in oracle/ref_shim/Eigen/Eigen where there is none — and tests/test_oracle_vs_ref.py demands equal bits); unpinned only
+// with respect to Eigen's own binary, absent from every host of this project.
 //
 // Follows /root/reference/src/frenet_optimal_trajectory.cpp:
 //   calc_frenet_paths :51-100, calc_global_paths :102-136, check_collision :138-148, check_paths :150-158,

@@ -6,8 +6,11 @@
 //                   :102-106 (dlqr), :116-129 (A, B, Q, R as lqr_steering_control builds them)
 //   4x4 / 1 input : /root/reference/src/lqr_steer_control.cpp:75-90, :92-96, :104-115
 // written as the dense expressions the reference writes, in Eigen 3.3.9's evaluation order
-// (oracle/eigen_order.h).  PARITY-UNPINNED (no reference tests, no Eigen in this image);
-// cross-checked against a numpy-float32 twin, a float64 evaluation and
+// (oracle/eigen_order.h).  
+// PINNED against the reference's own lines (oracle/ref_build.sh compiles them unmodified — against the host's Eigen, or against the
+// Eigen stand-in oracle/ref_shim/Eigen/Eigen where there is none — and tests/test_oracle_vs_ref.py demands equal bits); unpinned only
+// with respect to Eigen's own binary, absent from every host of this project.
+// Also cross-checked against a numpy-float32 twin, a float64 evaluation and
 // scipy.linalg.solve_discrete_are (tests/test_oracle_lqr.py).
 #include <cmath>
 #include <cstring>

@@ -14,8 +14,11 @@
 //   (2) oracle_mpc_solve: a plainly written (dense 6x6, no structure exploited) CPU twin of the
 //       engine's algorithm — control-limited DDP with exact second-order terms on the state
 //       augmented by the previous control — against which the HIP kernel must agree to 1e-6.
-// PARITY-UNPINNED with respect to the reference (no golden vectors exist); pinned instead by
-// optimality: KKT residual and agreement with scipy.optimize on the same NLP (tests/test_oracle_mpc.py).
+// The PROBLEM (objective, constraint functions, bounds, initial point, output layout) is pinned against the reference's own
+// lines: FG_EVAL and mpc_solve compiled unmodified with AD<double> = double and ipopt::solve replaced by a recorder
+// (oracle/ref_shim/ref_mpc.cpp, tests/test_oracle_vs_ref.py).  The SOLVER is ours; it is pinned by optimality: KKT residual and
+// agreement with scipy.optimize on the same NLP, speed bounds included (tests/test_oracle_mpc.py).  The reference's own answer
+// (an IPOPT iterate under a CPU-time budget) is not reproducible by anything.
 #include <cmath>
 #include <cstring>
 #include <vector>

@@ -10,7 +10,9 @@
 //   mpc_simulation          src/model_predictive_control.cpp:348-385 (math only; mpc_solve = oracle/mpc_ref.cpp)
 // with the host libm for std::atan2/std::tan/std::cos/std::sin/std::fmod/std::sqrt/std::round — exactly what
 // the reference links.  The Riccati solve is oracle_dare() of lqr_ref.cpp (dense, Eigen order).
-// PARITY-UNPINNED like the rest of the oracle (no reference tests exist; Eigen/OpenCV absent from this image).
+// PINNED against the reference's own lines (oracle/ref_build.sh compiles them unmodified — against the host's Eigen, or against the
+// Eigen stand-in oracle/ref_shim/Eigen/Eigen where there is none — and tests/test_oracle_vs_ref.py demands equal bits); unpinned only
+// with respect to Eigen's own binary, absent from every host of this project.
 // Memory safety: where the reference indexes the course without a bounds check (:110 of the MPC file, `ind += 1`
 // in the 4-state loop) the index is clipped to the course, as the engine does.
 #include <cfloat>

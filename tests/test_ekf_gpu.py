@@ -347,3 +347,25 @@ def test_two_lanes_per_vehicle_variant_equals_the_production_kernel(crx, oracle_
         flag = ekf_run_pair(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh)
         assert int(flag.cpu().numpy()[0]) == 0
         assert np.array_equal(xh.cpu().numpy(), xho) and np.array_equal(xd.cpu().numpy(), xo) and np.array_equal(Pd.cpu().numpy(), Po)
+
+
+def test_chunked_launches_equal_one_launch(crx):
+    """The chunked trajectory gather cuts the T-step launch into launches of T/chunks steps with the filter state carried over in
+    place (cpprobotics_amd/swarm.py: ChunkedTrajectoryGather): every byte of the history and of the final state must be the same."""
+    import torch
+    Q, R = ekf_QR()
+    n, T = 777, 240
+    u, x0, P0 = ekf_agents(n, 31)
+    w = crx.normal_draws(n, T, agent0=5000, seed=11)
+    xt, xd = _t(x0), _t(x0)
+    z, ud = crx.ekf_simulate_inputs(_t(u), xt, xd, w)
+    x1, P1 = _t(x0), _t(P0)
+    h1 = torch.empty((T, n, 4), device="cuda")
+    crx.ekf_run(x1, P1, z, ud, Q, R, x_hist=h1)
+    for chunks in (2, 10, 60):
+        x2, P2 = _t(x0), _t(P0)
+        h2 = torch.empty((T, n, 4), device="cuda")
+        Tc = T // chunks
+        for c in range(chunks):
+            crx.ekf_run(x2, P2, z[c * Tc:(c + 1) * Tc], ud[c * Tc:(c + 1) * Tc], Q, R, x_hist=h2[c * Tc:(c + 1) * Tc])
+        assert torch.equal(h1.view(torch.int32), h2.view(torch.int32)) and torch.equal(x1, x2) and torch.equal(P1, P2)

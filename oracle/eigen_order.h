@@ -77,6 +77,14 @@ inline ProductOrder product_order(int r, int c, int k, bool lhs_rm, bool rhs_rm)
   const bool dst_rm = (r == 1 && c != 1);
   const int inner = dst_rm ? c : r;
   if ((can_vec_lhs || can_vec_rhs) && eval_rm == dst_rm && inner % 4 == 0) return PO_ASC;
+  // Coefficient path.  ORACLE_CPATH_ORDER (a build flag of the test infrastructure only) forces one order for EVERY sum of this
+  // path — 1: ascending, 2: the unrolled tree — so that tests can show that on the reference's own call sites the choice
+  // made here does not matter (every such sum has at most two non-zero terms): tests/test_oracle_vs_ref.py.
+#if defined(ORACLE_CPATH_ORDER) && ORACLE_CPATH_ORDER == 1
+  return PO_ASC;
+#elif defined(ORACLE_CPATH_ORDER) && ORACLE_CPATH_ORDER == 2
+  return PO_TREE;
+#endif
   if (lhs_rm && !rhs_rm && k >= 4) return PO_VEC;
   return PO_TREE;
 }

@@ -61,15 +61,26 @@ ext src/frenet_optimal_trajectory.cpp 40 176 frenet_fns.inc      # using namespa
 if echo '#include <Eigen/Eigen>' | g++ -x c++ -fsyntax-only - 2>/dev/null; then EIGEN_INC=""; KIND=1
 elif [ -f /usr/include/eigen3/Eigen/Eigen ]; then EIGEN_INC="-I/usr/include/eigen3"; KIND=1
 else EIGEN_INC="-I$HERE/ref_shim"; KIND=0; fi
-CXXFLAGS="-std=gnu++11 -O1 -ffp-contract=off -fPIC -w -I$GEN -I$REF/include $EIGEN_INC -DREF_EIGEN_KIND=$KIND"
-OBJS=()
-for f in "$HERE"/ref_shim/ref_*.cpp; do
-  o="$OUT/$(basename "${f%.cpp}").o"
-  g++ $CXXFLAGS -c "$f" -o "$o"
-  OBJS+=("$o")
-done
-# the MPC unit once more for the BASELINE horizon (the reference's macro T is 6)
-g++ $CXXFLAGS -DREF_MPC_T=21 -c "$HERE/ref_shim/ref_mpc.cpp" -o "$OUT/ref_mpc_T21.o"
-# the reference headers define non-inline functions (cubic_spline.h, motion_model.h): every unit carries an identical copy
-g++ -shared -Wl,--allow-multiple-definition -o "$OUT/libref.so" "${OBJS[@]}" "$OUT/ref_mpc_T21.o" -lm
+build_flavour() {      # $1 = library name, $2 = extra flags
+  local CXXFLAGS="-std=gnu++11 -O1 -ffp-contract=off -fPIC -w -I$GEN -I$REF/include $EIGEN_INC -DREF_EIGEN_KIND=$KIND $2"
+  local OBJS=() tag="$1"
+  for f in "$HERE"/ref_shim/ref_*.cpp; do
+    o="$OUT/$(basename "${f%.cpp}").$tag.o"
+    g++ $CXXFLAGS -c "$f" -o "$o"
+    OBJS+=("$o")
+  done
+  # the MPC unit once more for the BASELINE horizon (the reference's macro T is 6)
+  g++ $CXXFLAGS -DREF_MPC_T=21 -c "$HERE/ref_shim/ref_mpc.cpp" -o "$OUT/ref_mpc_T21.$tag.o"
+  # the reference headers define non-inline functions (cubic_spline.h, motion_model.h): every unit carries an identical copy
+  g++ -shared -Wl,--allow-multiple-definition -o "$OUT/$tag.so" "${OBJS[@]}" "$OUT/ref_mpc_T21.$tag.o" -lm
+}
+build_flavour libref ""
+if [ $KIND = 0 ]; then
+  # two more builds of the stand-in flavour in which EVERY coefficient-path sum is forced to one order (eigen_order.h): the tests
+  # demand the same bits from all three on the reference's own call sites
+  build_flavour libref_cpath_asc "-DORACLE_CPATH_ORDER=1" &
+  build_flavour libref_cpath_tree "-DORACLE_CPATH_ORDER=2" &
+  wait
+fi
+rm -f "$OUT"/*.o
 echo "ref_build: $OUT/libref.so (Eigen: $([ $KIND = 1 ] && echo host || echo stand-in))"

@@ -39,6 +39,28 @@ def lib():
     return _lib
 
 
+class flavour:
+    """`with flavour("cpath_asc"): ...` — run the functions of this module against libref_cpath_asc.so / libref_cpath_tree.so, the
+    stand-in builds in which every coefficient-path sum of a product is forced to one order (oracle/eigen_order.h)."""
+
+    def __init__(self, name):
+        self.path = os.path.join(_HERE, "_ref", f"libref_{name}.so")
+
+    def available(self):
+        return os.path.exists(self.path)
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        _lib = C.CDLL(self.path)
+        _lib.ref_eigen_kind.restype = _I
+        return self
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.saved
+
+
 def eigen_kind():
     return "host Eigen" if lib().ref_eigen_kind() == 1 else "stand-in (oracle/ref_shim/Eigen/Eigen)"
 

@@ -306,3 +306,48 @@ def test_course_generation_of_the_mains():
         assert len(cx) == len(rx) > 100
         assert _eq(cx, rx) and _eq(cy, ry) and _eq(cyaw, ryaw) and _eq(ck, rk)
         assert np.isfinite(sp).all() and abs(abs(sp[0]) - 10.0 / 3.6) < 1e-6
+
+
+# ---- how much of this depends on the stand-in's restatement of Eigen's accumulation order? -------------------------------------------
+@pytest.mark.skipif(not (R.flavour("cpath_asc").available() and R.flavour("cpath_tree").available()), reason="stand-in flavours not built (host Eigen in use)")
+def test_which_reference_call_sites_depend_on_the_coefficient_path_order(oracle_mod):
+    """The reference's lines compiled against the stand-in three times: with the order rule of oracle/eigen_order.h, and with every
+    coefficient-path sum forced to ascending / to the unrolled tree.  ekf_estimation, solve_DARE and dlqr on the reference's own
+    matrices give the same bits in all three — every coefficient-path sum there has at most two non-zero terms — so the one
+    decision of the stand-in that cannot be checked without Eigen's binary has no influence on them.  The ONE expression of the
+    hot path that is sensitive to it is `-K * x` of lqr_steering_control (dense gain times dense error state,
+    lqr_speed_steer_control.cpp:141, lqr_steer_control.cpp:127): 2x5 column-major K -> unrolled tree (the 5-state loop equals the
+    forced-tree build), 1x4 row-major K -> vectorised redux (differs from both forced orders by one float ulp of the steering
+    command).  Dense random DARE inputs, beyond the reference's call sites, are sensitive too."""
+    Q, Rm = ekf_QR()
+    n, T = 64, 300
+    u, x0, P0 = ekf_agents(n, 3)
+    z, ud, *_ = oracle_mod.ekf_simulate_inputs(u, x0, x0, ekf_noise(T, n, 4), trig=0)
+    v = lqr_speeds(300, 11)
+    course, goal = lqr_course()
+    st = tracking_agents(6, tuple(c[:80] for c in course), 31, spread=0.3)
+    rng = np.random.default_rng(17)
+    Ad = (np.eye(5)[None] * 0.9 + rng.normal(0, 0.15, (50, 5, 5))).astype(np.float32).reshape(50, -1)
+    Bd = rng.normal(0, 0.5, (50, 10)).astype(np.float32)
+    Qd = np.tile(np.eye(5, dtype=np.float32).reshape(1, 25), (50, 1)); Rd = np.tile(np.eye(2, dtype=np.float32).reshape(1, 4), (50, 1))
+
+    def everything():
+        out = dict(ekf=R.ekf_run(x0, P0, z, ud, Q, Rm, want_phist=True)[2:4])
+        for dim in (5, 4):
+            A, B, Qm, Rr = oracle_mod.lqr_build(v, dim)
+            out[f"dare{dim}"] = R.dare(A, B, Qm, Rr)
+            out[f"loop{dim}"] = R.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=400)
+        out["dense"] = R.dare(Ad, Bd, Qd, Rd)
+        return out
+    base = everything()
+    same = lambda a, b: all(_eq(p, q) for p, q in zip(a, b))
+    for name in ("cpath_asc", "cpath_tree"):
+        with R.flavour(name):
+            other = everything()
+        for key in ("ekf", "dare5", "dare4"):
+            assert same(base[key], other[key]), (name, key)
+        assert not same(base["dense"], other["dense"]), "dense inputs should be sensitive to the order"
+        if name == "cpath_tree":
+            assert same(base["loop5"], other["loop5"])
+        # the 4-state loop: same tick counts, states within a few float ulps (one ulp of the steering command per tick)
+        assert _eq(base["loop4"][1], other["loop4"][1]) and np.abs(base["loop4"][0] - other["loop4"][0]).max() < 1e-5

@@ -1,0 +1,18 @@
+"""MPC kernel time for the library in CRX_LIB_PATH (A/B of build variants): BASELINE configs[3] and T = 6."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
+import cpprobotics_amd as crx
+from common import mpc_problem
+for n, T in ((8192, 21), (8192, 6), (65536, 21)):
+    x0, xref = mpc_problem(n, T, 4)
+    x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+    for _ in range(3):
+        sol, st, cost = crx.mpc_solve(x0, xref, T, return_status=True)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(15)]
+    for a, b in evs:
+        a.record(); crx.mpc_solve(x0, xref, T); b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in evs)
+    it = (st.cpu().numpy() >> 8)
+    print(os.environ.get("CRX_LIB_PATH", "default").split("/")[-1], f"n={n} T={T}: median {ms[7]:.4f} ms min {ms[0]:.4f}; sweeps mean {it.mean():.2f} max {it.max()}; cost sum {cost.sum().item():.9f}")

@@ -5,7 +5,7 @@ import cpprobotics_amd as crx
 from common import *
 Q, R = ekf_QR()
 lib = crx.lib()
-for n, T, hist in [(65536, 1000, True), (65536, 1000, False), (131072, 500, True), (262144, 250, True)]:
+for n, T, hist in [(65536, 1000, True), (65536, 1000, False), (131072, 500, True), (262144, 250, True), (1048576, 100, True)]:
     u, x0, P0 = ekf_agents(n, 1)
     z = torch.randn((T, n, 2), device='cuda') * 0.3; ud = torch.randn((T, n, 2), device='cuda') * 0.1 + 1
     xh = torch.empty((T, n, 4), device='cuda') if hist else None

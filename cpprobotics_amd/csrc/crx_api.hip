@@ -955,6 +955,7 @@ int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double d
   if (int rc = crx_frenet_spline_build(wx, wy, nx, coef.data())) return rc;
   const float* s = coef.data();
   const float *ax = s + nx, *bx = s + 2 * nx, *cxx = s + 3 * nx, *dx_ = s + 4 * nx, *ay = s + 5 * nx, *by = s + 6 * nx, *cyy = s + 7 * nx, *dy_ = s + 8 * nx;
+  if (!((float)((double)s[nx - 1] + ds) > s[nx - 1])) return fail(CRX_ERR_INVALID, "course_from_waypoints: ds too small for this course (the float walk would not advance)");
   int k = 0;
   for (float i = 0; i < s[nx - 1]; i += ds) {                      // float i += double literal, as the mains write it
     if (k < cap) {

@@ -350,30 +350,37 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
       double Quu10 = G[1][2] * bd + dt * Wxp[3][0] + Wpp01;
       double Quu11 = l_uu1 + G[1][3] * dt + dt * Wxp[3][1] + Wpp11;
-      if (exact) {   // V_s . d2F; the steering curvature e00 only where it leaves this stage's control Hessian positive
-                     // definite (a saturated steering input otherwise proposes a jump to a box corner)
+      // the box of the step: steering limits; the acceleration box of this knot's (nominal) speed = acceleration limits and
+      // the speed bounds of knot i+1
+      AccelBox ab = accel_box(p, inv_dt, v);
+      double lo0 = lb0 - ud, hi0 = ub0 - ud, lo1 = ab.lo - ua, hi1 = ab.hi - ua;
+      // active set of a Newton step (projected Newton): a control resting on a bound the gradient pushes it against stays
+      // there (its box collapses to {0}) and the Hessian is judged on the controls that are left — see oracle/mpc_ref.cpp
+      const bool hold0 = exact && ((lo0 >= 0.0 && Qu0 > 0.0) || (hi0 <= 0.0 && Qu0 < 0.0));
+      const bool hold1 = exact && ((lo1 >= 0.0 && Qu1 > 0.0) || (hi1 <= 0.0 && Qu1 < 0.0));
+      if (exact) {   // V_s . d2F; the steering curvature e00 only where it leaves the control Hessian of the controls not held
+                     // positive definite (a saturated steering input otherwise proposes a jump to a box corner)
         const double e00 = lx[2] * v * dt_wb * 2.0 * tn * sec2;
         const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = 0.5 * (Quu01 + Quu10);
         Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
         const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
         Qxx[2][3] += cross; Qxx[3][2] += cross;
         Qux[0][3] += lx[2] * sec2 * dt_wb;
-        if (g0 > 1e-12 && g0 * g3 - go * go > 1e-12 * g0) Quu00 += e00;
+        if (g0 > 1e-12 && (hold1 || g0 * g3 - go * go > 1e-12 * g0)) Quu00 += e00;
       }
       const double hod = 0.5 * (Quu01 + Quu10);
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
-      // the box of the step: steering limits; the acceleration box of this knot's (nominal) speed = acceleration limits and
-      // the speed bounds of knot i+1; and, for a Newton step, a trust box around the current controls — with the exact
-      // (possibly indefinite) Hessian an unrestricted stage proposes a jump to the far corner of the box, which the line
-      // search rejects at every step length, and the solver falls back to linearly converging Gauss-Newton steps: that is
-      // the whole tail of the iteration-count distribution.  Gauss-Newton steps are not restricted.
-      AccelBox ab = accel_box(p, inv_dt, v);
-      double lo0 = lb0 - ud, hi0 = ub0 - ud, lo1 = ab.lo - ua, hi1 = ab.hi - ua;
+      // for a Newton step, a trust box around the current controls — with the exact (possibly indefinite) Hessian an
+      // unrestricted stage proposes a jump to the far corner of the box, which the line search rejects at every step
+      // length, and the solver falls back to linearly converging Gauss-Newton steps: that is the whole tail of the
+      // iteration-count distribution.  Gauss-Newton steps are not restricted.
       if (exact) {
         lo0 = fmax(lo0, -kMpcTrustSteer); hi0 = fmin(hi0, kMpcTrustSteer);
         if (lo1 < -kMpcTrustAccel) { lo1 = -kMpcTrustAccel; ab.sp_lo = false; }
         if (hi1 > kMpcTrustAccel) { hi1 = kMpcTrustAccel; ab.sp_hi = false; }
       }
+      if (hold0) { lo0 = 0.0; hi0 = 0.0; }
+      if (hold1) { lo1 = 0.0; hi1 = 0.0; }
       double k0, k1; bool f0, f1;
       boxqp2(h00, hod, h11, Qu0, Qu1, lo0, hi0, lo1, hi1, k0, k1, f0, f1);
       // the acceleration rests on a SPEED bound: it is then a function of the state, a = (v_bound - v)/DT — a feedback row

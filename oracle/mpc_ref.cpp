@@ -194,10 +194,21 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
       for (int b = 0; b < NU; ++b) { double t = luu[a + NU * b]; for (int k = 0; k < NS; ++k) t += Fu[k + NS * a] * VFu[k + NS * b]; Quu[a + NU * b] = t; }
     for (int a = 0; a < NU; ++a)
       for (int b = 0; b < NS; ++b) { double t = lus[a + NU * b]; for (int k = 0; k < NS; ++k) t += Fu[k + NS * a] * VF[k + NS * b]; Qus[a + NU * b] = t; }
+    double a_lo, a_hi; bool sp_lo, sp_hi;
+    accel_box(p, v, &a_lo, &a_hi, &sp_lo, &sp_hi);           // speed bounds of knot i+1 as a box on a_i at the nominal v_i
+    double lo[2] = {lb[0] - u[0], a_lo - u[1]}, hi[2] = {ub[0] - u[0], a_hi - u[1]};
+    // Active set of a Newton step (projected Newton): a control that rests on a bound the gradient pushes it against
+    // stays there — its box collapses to {0} — and the Hessian is judged on the controls that are left.  Without it an
+    // indefinite 2x2 Hessian sends a saturated control to the far corner of the trust box, the line search rejects the
+    // step at every length and the solver crawls on Gauss-Newton steps (one agent in ~25,000 never converged).
+    const bool hold0 = exact && ((lo[0] >= 0.0 && Qu[0] > 0.0) || (hi[0] <= 0.0 && Qu[0] < 0.0));
+    const bool hold1 = exact && ((lo[1] >= 0.0 && Qu[1] > 0.0) || (hi[1] <= 0.0 && Qu[1] < 0.0));
     // second-order dynamics terms  Vs' . d2F
-    // The curvature the steering input picks up from the dynamics (e00) is left out of a stage whose control Hessian it
-    // would make indefinite — typically a steering input saturated along the horizon: the Newton step of such a stage is
-    // a jump to a box corner that the line search then rejects at every step length.  The state-side terms always go in.
+    // The curvature the steering input picks up from the dynamics (e00) is left out of a stage whose control Hessian —
+    // over the controls not held — it would make indefinite: typically a steering input saturated along the horizon, whose
+    // Newton step is a jump to a box corner that the line search rejects.  Leaving it out of a stage that does not need
+    // it costs the quadratic convergence (the slowest agent of the BASELINE batch converged linearly at e00/Quu = 0.25
+    // per sweep because its HELD acceleration made the 2x2 test fail).  The state-side terms always go in.
     if (exact) {
       const double e00 = Vs[2] * v / p.wb * dt * 2.0 * tn * sec2;
       const double h0 = Quu[0] + e00 + mu, h3 = Quu[3] + mu, hod = 0.5 * (Quu[1] + Quu[2]);
@@ -205,23 +216,22 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
       const double cross = Vs[0] * (-sn * dt) + Vs[1] * (c * dt);
       Qss[2 + NS * 3] += cross; Qss[3 + NS * 2] += cross;
       Qus[0 + NU * 3] += Vs[2] * sec2 / p.wb * dt;
-      if (h0 > 1e-12 && h0 * h3 - hod * hod > 1e-12 * h0) Quu[0] += e00;
+      if (h0 > 1e-12 && (hold1 || h0 * h3 - hod * hod > 1e-12 * h0)) Quu[0] += e00;
     }
     // regularised control Hessian must be positive definite
     const double H[4] = {Quu[0] + mu, Quu[1], Quu[2], Quu[3] + mu};
-    double a_lo, a_hi; bool sp_lo, sp_hi;
-    accel_box(p, v, &a_lo, &a_hi, &sp_lo, &sp_hi);           // speed bounds of knot i+1 as a box on a_i at the nominal v_i
-    double lo[2] = {lb[0] - u[0], a_lo - u[1]}, hi[2] = {ub[0] - u[0], a_hi - u[1]};
     // A Newton step is searched inside a trust box around the current controls (|d delta| <= 0.4 rad, |d a| <= 0.5 m/s^2): with
     // the exact (possibly indefinite) Hessian an unconstrained stage proposes a jump to the far box corner, which the line
     // search then rejects at every step length, and the solver falls back to linearly converging Gauss-Newton steps — the
     // whole tail of the iteration-count distribution (on the BASELINE batch: 50-iteration cap hit by 3 agents, 22+ by 8;
-    // with the trust box every agent converges in <= 21).  Gauss-Newton steps (positive definite) are not restricted.
+    // with the trust box every agent converges in <= 21, with the active set above in <= 16).  Gauss-Newton steps (positive definite) are not restricted.
     if (exact) {
       lo[0] = lo[0] < -kTrustSteer ? -kTrustSteer : lo[0]; hi[0] = hi[0] > kTrustSteer ? kTrustSteer : hi[0];
       if (lo[1] < -kTrustAccel) { lo[1] = -kTrustAccel; sp_lo = false; }     // that end of the box is no longer the speed bound's
       if (hi[1] > kTrustAccel) { hi[1] = kTrustAccel; sp_hi = false; }
     }
+    if (hold0) { lo[0] = 0.0; hi[0] = 0.0; }
+    if (hold1) { lo[1] = 0.0; hi[1] = 0.0; }
     double k[2]; int fr[2];
     boxqp2(H, Qu, lo, hi, k, fr);
     (void)deficit;

@@ -59,6 +59,17 @@ inline unsigned iter_block() {
   return 64;
 }
 
+// CRX_MPC_LIVE=<agents per wave>, CRX_MPC_WG=<waves per workgroup>: launch-geometry experiments (scripts/gpu_mpc_ab.py).
+inline int mpc_forced_live() {
+  static const int forced = [] { const char* e = std::getenv("CRX_MPC_LIVE"); return e ? std::atoi(e) : 64; }();
+  return forced;
+}
+
+inline int mpc_forced_wg() {
+  static const int forced = [] { const char* e = std::getenv("CRX_MPC_WG"); return e ? std::atoi(e) : 1; }();
+  return forced;
+}
+
 crx::EkfConsts make_consts(const float* Q, const float* R, const crx_ekf_params* prm) {
   crx::EkfConsts k;
   std::memcpy(k.Q, Q, sizeof(k.Q));
@@ -444,7 +455,7 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, iter_block());
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, mpc_forced_live(), mpc_forced_wg());
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
 

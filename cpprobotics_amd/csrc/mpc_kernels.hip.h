@@ -42,6 +42,25 @@
 
 namespace crx {
 
+// Selects.  The compiler's idiom for `c ? a : b` on doubles is v_cmp -> VCC and two VOP2 v_cndmask_b32_e32 reading VCC
+// implicitly; that encoding issues at ~19 cycles per instruction on gfx950 (profiles/r01/ubench_issue_patterns.txt, rows
+// U/V/W: the VOP3 encoding with the mask in an SGPR pair, or in VCC, issues at 5.5) and the solver's candidate scoring and
+// quadrant logic are chains of them.  sel64 emits the VOP3 form.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ int sel32(lanemask_t m, int a, int b) {   // lane's bit of m set ? a : b
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ double sel64(lanemask_t m, double a, double b) {
+  return __hiloint2double(sel32(m, __double2hiint(a), __double2hiint(b)), sel32(m, __double2loint(a), __double2loint(b)));
+}
+__device__ __forceinline__ double sel64(bool c, double a, double b) { return sel64(lanes_where(c), a, b); }
+__device__ __forceinline__ double flip_sign_if(double x, int bit) {   // bit = 0 or 1: x or -x, one shift and one xor
+  return __hiloint2double(__double2hiint(x) ^ (bit << 31), __double2loint(x));
+}
+
 // sin, cos (and tan = sin/cos) in fp64 for the solver.  OCML's sincos()/tan() carry a full Payne-Hanek reduction and
 // cost ~150 instructions each; the solver calls them once per stage per rollout.  For |x| < 2^17 a three-term
 // Cody-Waite reduction (fma) and the fdlibm kernel polynomials give <= 1 ulp in ~45 instructions; larger arguments
@@ -66,10 +85,11 @@ __device__ __forceinline__ void mpc_sincos(double x, double* sp, double* cp) {
                                               -2.75573143513906633035e-07), 2.48015872894767294178e-05),
                                -1.38888888888741095749e-03), 4.16666666666666019037e-02);
   const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-  const double s0 = (q & 1) ? cr : sr;
-  const double c0 = (q & 1) ? sr : cr;
-  *sp = (q & 2) ? -s0 : s0;
-  *cp = ((q + 1) & 2) ? -c0 : c0;
+  const lanemask_t odd = lanes_where((q & 1) != 0);
+  const double s0 = sel64(odd, cr, sr);
+  const double c0 = sel64(odd, sr, cr);
+  *sp = flip_sign_if(s0, (q >> 1) & 1);
+  *cp = flip_sign_if(c0, ((q + 1) >> 1) & 1);
 }
 __device__ __forceinline__ double mpc_tan(double x) {
   double sn, cs;
@@ -83,7 +103,8 @@ struct MpcP {
   int max_iter;
 };
 
-__device__ __forceinline__ double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// lo <= hi at every call site; equal to v < lo ? lo : (v > hi ? hi : v) up to the sign of a zero (v_max_f64 + v_min_f64)
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // Trust box of a Newton step (see the backward sweep) — the same constants as the twin, oracle/mpc_ref.cpp.
 constexpr double kMpcTrustSteer = 0.4, kMpcTrustAccel = 0.5;
@@ -121,8 +142,8 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   int bf = 0;                                  // bit 0: control 0 free, bit 1: control 1 free
   auto consider = [&](double a, double b, int flags, bool valid) {
     const double obj = 0.5 * (h00 * a * a + 2.0 * hod * a * b + h11 * b * b) + g0 * a + g1 * b;
-    const bool take = valid && obj < best;
-    best = take ? obj : best; b0 = take ? a : b0; b1 = take ? b : b1; bf = take ? flags : bf;
+    const lanemask_t take = lanes_where(valid && obj < best);
+    best = sel64(take, obj, best); b0 = sel64(take, a, b0); b1 = sel64(take, b, b1); bf = sel32(take, flags, bf);
   };
   const bool c11 = h11 > tiny, c00 = h00 > tiny;
   const double ih11 = 1.0 / (c11 ? h11 : 1.0), ih00 = 1.0 / (c00 ? h00 : 1.0);   // one reciprocal per edge pair
@@ -139,7 +160,8 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   for (int q0 = 0; q0 < 2; ++q0)
 #pragma unroll
     for (int q1 = 0; q1 < 2; ++q1) consider(q0 ? hi0 : lo0, q1 ? hi1 : lo1, 0, true);
-  k0 = interior ? ia : b0; k1 = interior ? ib : b1;
+  const lanemask_t in = lanes_where(interior);
+  k0 = sel64(in, ia, b0); k1 = sel64(in, ib, b1);
   f0 = interior || (bf & 1); f1 = interior || (bf & 2);
 }
 
@@ -236,6 +258,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
   int status = 0, it = 0;
   bool done = !live;
 
+#ifdef CRX_MPC_TICKS
+  long long tk_b = 0, tk_f = 0, tk_nb = 0, tk_nf = 0; const long long tk_0 = clock64();
+#endif
   for (int iter = 0; iter < p.max_iter; ++iter) {
     if (__all(done)) break;
     if (done) continue;
@@ -268,6 +293,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
     StageIn nx = load_stage(cur, N - 1);
     double uc0 = U[cur][N - 1][0], uc1 = U[cur][N - 1][1];
     double up0 = U[cur][N >= 2 ? N - 2 : 0][0], up1 = U[cur][N >= 2 ? N - 2 : 0][1];
+#if CRX_MPC_TICKS >= 2
+    const long long tk_b0 = clock64();
+#endif
     for (int i = N - 1; i >= 0; --i) {
       const StageIn in = nx;
       const double ud = uc0, ua = uc1;
@@ -475,6 +503,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       lp0 = Vs[4]; lp1 = Vs[5];
       Wpp00 = Vss[4][4]; Wpp01 = Vss[4][5]; Wpp11 = Vss[5][5];
     }
+#if CRX_MPC_TICKS >= 2
+    tk_b += clock64() - tk_b0; tk_nb++;
+    const long long tk_f0 = clock64();
+#endif
     if (gnorm < p.tol && mu == 0.0) { status |= 1; done = true; continue; }
     // ------------------------------------------------------------------ forward rollout + line search
     const double aJ = fabs(J);
@@ -527,9 +559,15 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
         const double e0 = (double)rN.x - xs[0], e1 = (double)rN.y - xs[1], e2 = (double)rN.z - xs[2], e3 = (double)rN.w - xs[3];
         Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
       }
+#if CRX_MPC_TICKS >= 2
+      tk_nf++;
+#endif
       if (Jn < J || (trust && Jn <= J + noise)) { J = Jn; accepted = true; break; }
       alpha *= 0.5;
     }
+#if CRX_MPC_TICKS >= 2
+    tk_f += clock64() - tk_f0;
+#endif
     if (accepted) {
       cur = nxt;
       if (gn_left > 0) gn_left--;
@@ -564,16 +602,34 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
     }
   status_out = status | (it << 8);
   cost_out = J;
+#ifdef CRX_MPC_TICKS
+  { const int ln = threadIdx.x & 63; const long long tt = clock64() - tk_0;   // diagnostic build: lanes 0-4 report the wave's
+    for (int o = 32; o >= 1; o >>= 1) {                                          // longest lane instead of their cost
+      tk_b = max(tk_b, __shfl_xor(tk_b, o)); tk_f = max(tk_f, __shfl_xor(tk_f, o));
+      tk_nb = max(tk_nb, __shfl_xor(tk_nb, o)); tk_nf = max(tk_nf, __shfl_xor(tk_nf, o));
+    }
+    if (ln == 0) cost_out = (double)tt; if (ln == 1) cost_out = (double)tk_b; if (ln == 2) cost_out = (double)tk_f;
+    if (ln == 3) cost_out = (double)tk_nb; if (ln == 4) cost_out = (double)tk_nf; }
+#endif
   d0_out = (float)U[cur][0][0];
   a0_out = (float)U[cur][0][1];
 }
 
+// `live_lanes` agents in the low lanes of every wave, `blockDim.x / 64` waves per workgroup.  Production: full waves (64) in
+// single-wave workgroups.  The launch lasts as long as its slowest wave, and a wave pays in every sweep for the agent of
+// its lanes that needs the most line-search rollouts, so while the batch leaves SIMDs idle (BASELINE configs[3]: 128 full
+// waves on 1,024 SIMDs) emptier waves look attractive — measured (profiles/r02/mpc_tail.txt), they are slower: 32 / 16 /
+// 8 agents per wave take 1.18 / 1.41 / 1.95 ms against 1.08, and so do two or four waves per workgroup (1.18 / 1.42 ms at
+// full waves): every wave streams its lanes' 5.4 KB of private memory through L2 each sweep whether the lanes are used or
+// not, and waves that share a CU share its path to it.
 template <int MAXT>
-__global__ void __launch_bounds__(64)
-mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+__global__ void __launch_bounds__(256)   // 1-4 waves per workgroup, one wave per SIMD: the register budget of a lone wave
+mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
            float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
-  const size_t agent = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = agent < (size_t)n;
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const size_t agent = wave * (size_t)live_lanes + lane;
+  const bool live = lane < live_lanes && agent < (size_t)n;
   const size_t ag = live ? agent : 0;
   const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + ag * (size_t)T;
   const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
@@ -586,19 +642,22 @@ mpc_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict_
 }
 
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                             int* status, double* cost, hipStream_t stream, unsigned lanes = 64) {
+                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1) {
   MpcP p;
   p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
   p.max_speed = q.max_speed; p.min_speed = q.min_speed;
   p.r_a = q.r_a; p.r_d = q.r_delta; p.rd_a = q.rd_a; p.rd_d = q.rd_delta;
   p.qx = q.q_x; p.qy = q.q_y; p.qyaw = q.q_yaw; p.qv = q.q_v; p.tol = q.tol; p.max_iter = q.max_iter;
-  const dim3 grid((unsigned)((n + lanes - 1) / lanes)), block(lanes);
+  if (live < 1 || live > 64) live = 64;
+  if (wg_waves < 1 || wg_waves > 4) wg_waves = 1;
+  const size_t waves = ((size_t)n + live - 1) / live;
+  const dim3 grid((unsigned)((waves + wg_waves - 1) / wg_waves)), block(64 * wg_waves);
   if (T <= 8)
-    hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
   else if (T <= 24)
-    hipLaunchKernelGGL((mpc_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_kernel<24>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
   else
-    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import cpprobotics_amd as crx
 from common import mpc_problem
-for n, T in ((8192, 21), (8192, 6), (65536, 21)):
+for n, T in ((8192, 21), (8192, 6), (16384, 21), (65536, 21)):
     x0, xref = mpc_problem(n, T, 4)
     x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
     for _ in range(3):
@@ -15,4 +15,4 @@ for n, T in ((8192, 21), (8192, 6), (65536, 21)):
     torch.cuda.synchronize()
     ms = sorted(a.elapsed_time(b) for a, b in evs)
     it = (st.cpu().numpy() >> 8)
-    print(os.environ.get("CRX_LIB_PATH", "default").split("/")[-1], f"n={n} T={T}: median {ms[7]:.4f} ms min {ms[0]:.4f}; sweeps mean {it.mean():.2f} max {it.max()}; cost sum {cost.sum().item():.9f}")
+    print("live=" + os.environ.get("CRX_MPC_LIVE", "auto"), f"n={n} T={T}: median {ms[7]:.4f} ms min {ms[0]:.4f}; sweeps mean {it.mean():.2f} max {it.max()}; cost sum {cost.sum().item():.9f}")

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "crx_frenet_course_samples": (_I, [_P, _I, _P, _P, _I]),
     "crx_course_from_waypoints": (_I, [_P, _P, _I, _D, _P, _P, _P, _P, _I]),
     "crx_calc_speed_profile": (_I, [_I, _P, _P, _P, _I, _F, _P]),
+    "crx_smooth_yaw": (_I, [_P, _I]),
     "crx_frenet_run_batch_dev": (_I, [_I, _I, _P, _P, _I, _P, _P, _I, C.POINTER(FrenetConfig), _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "crx_pf_default_params": (None, [C.POINTER(PfParams)]),
     "crx_pf_run_batch_dev": (_I, [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(PfParams), _P, _P, _P]),

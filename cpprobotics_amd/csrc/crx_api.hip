@@ -1023,6 +1023,27 @@ int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const 
   return CRX_OK;
 }
 
+int crx_smooth_yaw(float* cyaw, int n) {   // src/model_predictive_control.cpp:172-185
+  if (n < 0 || (n && !cyaw)) return fail(CRX_ERR_INVALID, "smooth_yaw: bad argument");
+  for (int i = 0; i + 1 < n; ++i) {
+    float dyaw = cyaw[i + 1] - cyaw[i];
+    if (!std::isfinite(dyaw)) return fail(CRX_ERR_INVALID, "smooth_yaw: non-finite heading");
+    while (dyaw > M_PI / 2.0) {
+      const float before = cyaw[i + 1];
+      cyaw[i + 1] -= M_PI * 2.0;
+      if (cyaw[i + 1] == before) return fail(CRX_ERR_INVALID, "smooth_yaw: heading too large to unwind in float");
+      dyaw = cyaw[i + 1] - cyaw[i];
+    }
+    while (dyaw < -M_PI / 2.0) {
+      const float before = cyaw[i + 1];
+      cyaw[i + 1] += M_PI * 2.0;
+      if (cyaw[i + 1] == before) return fail(CRX_ERR_INVALID, "smooth_yaw: heading too large to unwind in float");
+      dyaw = cyaw[i + 1] - cyaw[i];
+    }
+  }
+  return CRX_OK;
+}
+
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,

@@ -52,6 +52,15 @@ def course_from_waypoints(wx, wy, ds, target_speed=10.0 / 3.6, variant=5):
     return cx, cy, cyaw, ck, sp
 
 
+def smooth_yaw(cyaw):
+    """smooth_yaw of the reference's MPC file (:172-185): the course headings made continuous, as mpc_simulation does before
+    its loop (:360).  numpy, host; returns a new array."""
+    import numpy as np
+    c = np.array(cyaw, dtype=np.float32, copy=True, order="C")
+    L.check(L.lib().crx_smooth_yaw(c.ctypes.data, len(c)), "crx_smooth_yaw")
+    return c
+
+
 def _lqr_params(dt, Lw, eps, maxiter):
     p = L.LqrParams()
     p.dt, p.L, p.eps, p.maxiter = float(dt), float(Lw), float(eps), int(maxiter)
@@ -163,8 +172,11 @@ def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10
 
 def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, nsearch=10, goal_dis=0.5, params=None,
                    want_hist=False):
-    """mpc_simulation's loop (maths only): state and target_ind are updated in place.
-    -> (ticks_done int32 [n], traj_hist or None)."""
+    """mpc_simulation's loop (:371-385, maths only) for n vehicles at once: state and target_ind are updated in place.
+    -> (ticks_done int32 [n], traj_hist or None).
+    The set-up of the reference (:349-360) is the caller's, from the pieces of this module: the course arrays from
+    course_from_waypoints(wx, wy, 1.0, variant=0), the start state (cx[0], cy[0], cyaw[0], sp[0]) taken BEFORE the headings are
+    passed through smooth_yaw (:360), target_ind = 0."""
     import torch
     from .mpc import default_params
     L.require_cuda(state, target_ind)

@@ -318,8 +318,8 @@ void crx_frenet_default_config(crx_frenet_config* c);
 /* number of candidate paths the configuration generates, or a negative crx error if it exceeds the kernel's grids
  * (<= 64 lateral offsets, horizons x target speeds <= 64, <= 64 time steps, horizons x speeds x time steps <= 2048) */
 int crx_frenet_num_paths(const crx_frenet_config* cfg);
-/* host: Spline2D(wx, wy) -> coef[9][nx].  The nx-by-nx float system the reference hands to colPivHouseholderQr is solved
- * in double (tridiagonal elimination) and rounded to float. */
+/* host: Spline2D(wx, wy) -> coef[9][nx] (include/cubic_spline.h:53-65, :95-116, :172-186).  The nx-by-nx float system is
+ * solved as the reference solves it, A.colPivHouseholderQr().solve(B) in float (csrc/crx_qr.h), bit for bit. */
 int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef);
 /* host: the course sampled as main :205-213 does (float i += 0.1); returns the sample count, fills up to cap of them */
 int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap);
@@ -330,6 +330,11 @@ int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double d
 /* host: calc_speed_profile, variant 5 = src/lqr_speed_steer_control.cpp:40-62, variant 0 = src/model_predictive_control.cpp:83-105;
  * the two out-of-bounds writes of the reference (:55-56 k = 0, :102) are not made. */
 int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp);
+/* host, in place: smooth_yaw, src/model_predictive_control.cpp:172-185 — what mpc_simulation (:360) does to the course headings
+ * before its loop: a step of more than pi/2 between consecutive samples is unwound by 2 pi (float -= double, as the reference).
+ * n < 2 is a no-op (the reference's unsigned size()-1 would wrap).  A heading the float walk cannot unwind (non-finite, or so
+ * large that -2 pi does not change it; the reference would not return) is refused with CRX_ERR_INVALID. */
+int crx_smooth_yaw(float* cyaw, int n);
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,

@@ -308,6 +308,26 @@ def test_course_generation_of_the_mains():
         assert np.isfinite(sp).all() and abs(abs(sp[0]) - 10.0 / 3.6) < 1e-6
 
 
+def test_smooth_yaw_of_the_mpc_main():
+    """crx_smooth_yaw (host) against the reference's own smooth_yaw (:172-185): the MPC main's course headings (atan2 output, which
+    jumps by 2 pi where the course turns through +-pi), synthetic windings of several turns, and the refusals."""
+    import cpprobotics_amd as crx
+    mpc_w = ([0.0, 60.0, 125.0, 50.0, 75.0, 35.0, -10.0], [0.0, 0.0, 50.0, 65.0, 30.0, 50.0, -20.0])
+    *_, ryaw, _ = R.main_course(*mpc_w, "mpc")
+    assert np.abs(np.diff(ryaw)).max() > 3.0                       # the raw headings do jump
+    out = crx.smooth_yaw(ryaw)
+    assert _eq(out, R.smooth_yaw(ryaw)) and np.abs(np.diff(out)).max() < np.pi / 2 + 1e-6 and not _eq(out, ryaw)
+    rng = np.random.default_rng(5)
+    for k in range(20):
+        wind = np.cumsum(rng.normal(0.0, 0.8, 300))                # up to several turns either way
+        raw = (np.arctan2(np.sin(wind), np.cos(wind)) + (k % 3 - 1) * 2 * np.pi * (rng.random(300) < 0.05)).astype(np.float32)
+        assert _eq(crx.smooth_yaw(raw), R.smooth_yaw(raw))
+    assert len(crx.smooth_yaw(np.zeros(0, np.float32))) == 0 and _eq(crx.smooth_yaw(np.float32([1.0])), np.float32([1.0]))
+    for bad in (np.float32([0.0, np.inf]), np.float32([0.0, np.nan, 0.0]), np.float32([0.0, 1e30])):
+        with pytest.raises(crx.CrxError):
+            crx.smooth_yaw(bad)
+
+
 # ---- how much of this depends on the stand-in's restatement of Eigen's accumulation order? -------------------------------------------
 @pytest.mark.skipif(not (R.flavour("cpath_asc").available() and R.flavour("cpath_tree").available()), reason="stand-in flavours not built (host Eigen in use)")
 def test_which_reference_call_sites_depend_on_the_coefficient_path_order(oracle_mod):

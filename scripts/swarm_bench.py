@@ -57,7 +57,7 @@ def main():
     # agent parameters keyed by the global agent id: drawn for the whole swarm, this rank keeps its slice
     ci = torch.from_numpy(np.random.default_rng(99).integers(0, len(course[0]) - 30, n_total)[rank * n:(rank + 1) * n]).to(dev)
     cx, cy, cyaw = (torch.from_numpy(a).to(dev) for a in course[:3])
-    x0 = torch.stack([cx[ci], cy[ci], cyaw[ci], torch.full((n,), 2.5, device=dev)], dim=1).contiguous()
+    x0 = torch.stack([cx[ci], cy[ci], cyaw[ci], torch.full((n,), 2.5, device=dev)], dim=1).contiguous()   # 2.5 m/s = v_cmd
     u_true = torch.stack([torch.full((n,), 0.0, device=dev), torch.zeros(n, device=dev)], dim=1).contiguous()  # (accel, yaw rate)
     w = crx.normal_draws(n, T, agent0=rank * n, seed=99, device=dev)
     z, ud = crx.ekf_simulate_inputs(u_true, x0.clone(), x0.clone(), w)
@@ -71,6 +71,7 @@ def main():
     ekf_done = torch.cuda.Event()
     cg = swarm.ChunkedTrajectoryGather(T, n, 4, args.chunks, dev) if (world > 1 and args.gather == "traj") else None
     st = torch.empty((n_mpc, 4), device=dev)
+    v_cmd = 2.5
 
     def one_round():
         main = torch.cuda.current_stream()
@@ -80,7 +81,10 @@ def main():
         else:
             crx.ekf_run(x, P, z, ud, Q, R, x_hist=x_hist)
         main.wait_stream(plan_stream)                                 # the planners of the previous round still read st
-        st.copy_(x[::8])                                              # every eighth agent plans from its estimate
+        st[:, :3].copy_(x[::8, :3])                                   # every eighth agent plans from its estimated pose ...
+        st[:, 3] = v_cmd                                              # ... at the commanded speed: the filter's 4th state integrates
+                                                                      # the noisy velocity input every step (F(3,3) = 1 and B(3,0) = 1,
+                                                                      # src/extended_kalman_filter.cpp:27,34) — a random walk, not a speed
         ekf_done.record(main)
         with torch.cuda.stream(plan_stream):                          # planning overlaps the next round's EKF launches
             plan_stream.wait_event(ekf_done)

@@ -93,11 +93,20 @@ def test_mpc_full_size(crx, oracle_mod):
     n, T = 8192, 21
     x0, xref = mpc_problem(n, T, 4)
     sd, std = _compare(crx, oracle_mod, n, T, 4, 0.999)
-    assert (std >> 8).max() <= 24                                          # no straggler left on this batch (was: 3 agents at the cap of 50)
+    assert (std >> 8).max() <= 18                                          # no straggler left on this batch (was: 3 agents at the cap of 50)
     cd = crx.mpc_solve(_t(x0), _t(xref), T, return_status=True)[2].cpu().numpy()
     idx = np.arange(0, n, 64)
     j0 = np.array([oracle_mod.mpc_cost(x0[k], xref[k], T, np.zeros((T - 1, 2)))[0] for k in idx])
     assert np.all(cd[idx] <= j0 + 1e-9)                                     # never worse than the zero-control start
+
+
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_mpc_more_seeds(crx, oracle_mod, seed):
+    """Other draws of the BASELINE distribution (scripts/gpu_mpc_fuzz.py runs 98,304 problems this way): the active-set and
+    Hessian decisions of a Newton sweep hang on signs of small numbers, and the kernel contracts multiply-adds where the twin does
+    not — the two must still walk the same path."""
+    sd, std = _compare(crx, oracle_mod, 2048, 21, seed, 0.999)
+    assert (std >> 8).max() <= 30
 
 
 def test_mpc_edge_cases(crx):

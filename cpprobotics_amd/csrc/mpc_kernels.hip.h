@@ -91,10 +91,34 @@ __device__ __forceinline__ void mpc_sincos(double x, double* sp, double* cp) {
   *sp = flip_sign_if(s0, (q >> 1) & 1);
   *cp = flip_sign_if(c0, ((q + 1) >> 1) & 1);
 }
+// n / d for a divisor of ordinary magnitude (cos of a steering angle; the 1x1 / 2x2 pivots of a stage QP): hardware
+// reciprocal estimate, two Newton steps, one residual correction of the quotient — <= 1 ulp in 8 instructions, where the
+// IEEE division sequence (scaling for subnormals and overflow, which cannot occur here) takes ~35.
+__device__ __forceinline__ double fast_div(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
+}
 __device__ __forceinline__ double mpc_tan(double x) {
   double sn, cs;
   mpc_sincos(x, &sn, &cs);
-  return sn / cs;
+  return fast_div(sn, cs);
+}
+// tan of a steering angle known to lie in [-pi/4, pi/4] (MAX_STEER = 45 deg, :288-291): the reduction of mpc_sincos is the
+// identity there (quadrant 0, r = x: rint(0.5) = 0), so this is mpc_tan without it — the same bits.
+__device__ __forceinline__ double mpc_tan_small(double x) {
+  const double z = x * x;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                              2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                               8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double sr = fma(x * z, ps, x);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                              -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                               -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  return fast_div(sr, cr);
 }
 
 struct MpcP {
@@ -133,7 +157,7 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   const double tiny = 1e-12;
   const double det = h00 * h11 - hod * hod;
   const bool pd = h00 > tiny && det > tiny * h00;
-  const double idet = 1.0 / (pd ? det : 1.0);
+  const double idet = fast_div(1.0, pd ? det : 1.0);
   const double ia = -(h11 * g0 - hod * g1) * idet, ib = -(-hod * g0 + h00 * g1) * idet;
   const bool interior = pd && ia >= lo0 && ia <= hi0 && ib >= lo1 && ib <= hi1;
   k0 = ia; k1 = ib; f0 = true; f1 = true;
@@ -146,7 +170,7 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
     best = sel64(take, obj, best); b0 = sel64(take, a, b0); b1 = sel64(take, b, b1); bf = sel32(take, flags, bf);
   };
   const bool c11 = h11 > tiny, c00 = h00 > tiny;
-  const double ih11 = 1.0 / (c11 ? h11 : 1.0), ih00 = 1.0 / (c00 ? h00 : 1.0);   // one reciprocal per edge pair
+  const double ih11 = fast_div(1.0, c11 ? h11 : 1.0), ih00 = fast_div(1.0, c00 ? h00 : 1.0);   // one reciprocal per edge pair
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double c0 = b ? hi0 : lo0;
@@ -185,6 +209,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
   const double inv_dt = 1.0 / dt;
   const double lb0 = -p.max_steer, ub0 = p.max_steer;
+  const bool small_steer = p.max_steer <= 0.78539816339744830962;   // uniform: every steering angle of a rollout is clamped to it
 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
   // rolls controls U[c] from x0 and returns fg[0]
@@ -205,7 +230,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
   auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
-    const double tn_ = mpc_tan(d);
+    const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
     tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
     sn[0] = s[0] + s[3] * cs_ * dt;
     sn[1] = s[1] + s[3] * sn_ * dt;
@@ -425,7 +450,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       {
         const bool both = f0 && f1;
         const double den = both ? (h00 * h11 - hod * hod) : (f0 ? h00 : (f1 ? h11 : 1.0));
-        const double inv = 1.0 / den;
+        const double inv = fast_div(1.0, den);
         const double i00 = both ? h11 * inv : (f0 ? inv : 0.0);
         const double i11 = both ? h00 * inv : (f1 ? inv : 0.0);
         const double i01 = both ? -hod * inv : 0.0;
@@ -436,7 +461,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
         }
         if (__any(sp)) {          // rare (never on the reference's scenario: 10 km/h against bounds of -20 / +55 km/h)
           if (sp) {
-            const double ih = f0 ? 1.0 / h00 : 0.0;
+            const double ih = f0 ? fast_div(1.0, h00) : 0.0;
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
               K[1][b] = (b == 3) ? -inv_dt : 0.0;

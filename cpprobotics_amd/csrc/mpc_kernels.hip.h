@@ -365,23 +365,26 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       const double Qp0 = l_p0, Qp1 = l_p1;
       const double Qu0 = l_u0 + bd * lx[2] + lp0;
       const double Qu1 = l_u1 + dt * lx[3] + lp1;
-      // M = Wxx*A ; Qxx = l_xx + A'*M
+      // M = Wxx*A ; Qxx = l_xx + A'*M.  Wxx is symmetric by construction (mirrored upper triangle), so Qxx is symmetric up to
+      // rounding: only its upper triangle is formed (a <= b) and used — 7 rows of products instead of 20, and no averaging of
+      // the two halves (the CPU twin forms both and averages them; the difference is a rounding of the last bit).
       double M[4][4];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) {
+      for (int a = 0; a < 3; ++a) {
         M[a][0] = Wxx[a][0];
         M[a][1] = Wxx[a][1];
         M[a][2] = Wxx[a][0] * a02 + Wxx[a][1] * a12 + Wxx[a][2];
         M[a][3] = Wxx[a][0] * a03 + Wxx[a][1] * a13 + Wxx[a][2] * a23 + Wxx[a][3];
       }
-      double Qxx[4][4];
+      M[3][3] = Wxx[3][0] * a03 + Wxx[3][1] * a13 + Wxx[3][2] * a23 + Wxx[3][3];
+      double Qxx[4][4];     // entries a <= b only
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        Qxx[0][b] = M[0][b];
-        Qxx[1][b] = M[1][b];
-        Qxx[2][b] = a02 * M[0][b] + a12 * M[1][b] + M[2][b];
-        Qxx[3][b] = a03 * M[0][b] + a13 * M[1][b] + a23 * M[2][b] + M[3][b];
-      }
+      for (int b = 0; b < 4; ++b) Qxx[0][b] = M[0][b];
+#pragma unroll
+      for (int b = 1; b < 4; ++b) Qxx[1][b] = M[1][b];
+#pragma unroll
+      for (int b = 2; b < 4; ++b) Qxx[2][b] = a02 * M[0][b] + a12 * M[1][b] + M[2][b];
+      Qxx[3][3] = a03 * M[0][3] + a13 * M[1][3] + a23 * M[2][3] + M[3][3];
 #pragma unroll
       for (int a = 0; a < 4; ++a) Qxx[a][a] += q2[a];
       // G = B'*Wxx + Wpx ; Qux = G*A ; Quu = l_uu + G*B + B'*Wxp + Wpp
@@ -417,7 +420,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
         const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = 0.5 * (Quu01 + Quu10);
         Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
         const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
-        Qxx[2][3] += cross; Qxx[3][2] += cross;
+        Qxx[2][3] += cross;
         Qux[0][3] += lx[2] * sec2 * dt_wb;
         if (g0 > 1e-12 && (hold1 || g0 * g3 - go * go > 1e-12 * g0)) Quu00 += e00;
       }
@@ -455,10 +458,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
         const double i11 = both ? h00 * inv : (f1 ? inv : 0.0);
         const double i01 = both ? -hod * inv : 0.0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
+        for (int b = 0; b < 4; ++b) {
           K[0][b] = -(i00 * Qus[0][b] + i01 * Qus[1][b]);
           K[1][b] = -(i01 * Qus[0][b] + i11 * Qus[1][b]);
         }
+        K[0][4] = -(i00 * l_up0); K[1][4] = -(i01 * l_up0);      // Q_us columns 4, 5 = diag(l_up0, l_up1): the zero products are
+        K[0][5] = -(i01 * l_up1); K[1][5] = -(i11 * l_up1);      // written out (x*0 and x+0 are not foldable in IEEE arithmetic)
         if (__any(sp)) {          // rare (never on the reference's scenario: 10 km/h against bounds of -20 / +55 km/h)
           if (sp) {
             const double ih = f0 ? fast_div(1.0, h00) : 0.0;
@@ -483,23 +488,23 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         const double qs = (b < 4) ? Qx[b < 4 ? b : 0] : (b == 4 ? Qp0 : Qp1);
-        Vs[b] = qs + (K[0][b] * t0 + K[1][b] * t1) + (Qus[0][b] * k0 + Qus[1][b] * k1);
+        const double uk = (b < 4) ? Qus[0][b] * k0 + Qus[1][b] * k1 : (b == 4 ? l_up0 * k0 : l_up1 * k1);
+        Vs[b] = qs + (K[0][b] * t0 + K[1][b] * t1) + uk;
       }
       double Vss[6][6];
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int b = a; b < 6; ++b) {
-          double qss;
-          if (a < 4 && b < 4) qss = 0.5 * (Qxx[a < 4 ? a : 0][b < 4 ? b : 0] + Qxx[b < 4 ? b : 0][a < 4 ? a : 0]);
-          else if (a == 4 && b == 4) qss = l_pp0;
-          else if (a == 5 && b == 5) qss = l_pp1;
-          else qss = 0.0;
+          const double uK = (a < 4) ? Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b] : (a == 4 ? l_up0 * K[0][b] : l_up1 * K[1][b]);
           // V_ss = Q_ss + K'Quu K + K'Q_us + Q_us'K.  The gains solve (Quu + mu I)_FF K_F = -Q_us,F on the free controls
           // (rows of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
           //   V_ss = Q_ss + Q_us'K - mu K'K
           // (the familiar Q_ss - Q_su Quu^-1 Q_us when mu = 0).  Only the upper triangle is formed and mirrored.
-          Vss[a][b] = qss + (Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b]);
+          if (a < 4 && b < 4) Vss[a][b] = Qxx[a < 4 ? a : 0][b < 4 ? b : 0] + uK;
+          else if (a == 4 && b == 4) Vss[a][b] = l_pp0 + uK;
+          else if (a == 5 && b == 5) Vss[a][b] = l_pp1 + uK;
+          else Vss[a][b] = uK;
         }
       if (mu != 0.0) {      // rare: the regularised iterations
 #pragma unroll

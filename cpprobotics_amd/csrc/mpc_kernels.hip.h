@@ -171,6 +171,24 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   };
   const bool c11 = h11 > tiny, c00 = h00 > tiny;
   const double ih11 = fast_div(1.0, c11 ? h11 : 1.0), ih00 = fast_div(1.0, c00 ? h00 : 1.0);   // one reciprocal per edge pair
+  if (__all(c00 && c11)) {
+    // Both diagonal curvatures positive in every lane (always so in a Gauss-Newton sweep): the problem along each of the four
+    // edges is a convex parabola, whose minimiser over the edge is the stationary point clamped to it — four candidates
+    // cover the whole boundary, corners included, and the one kept is the same point the full enumeration below keeps.
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double c0 = b ? hi0 : lo0;
+      const double t1 = clampd(-(g1 + hod * c0) * ih11, lo1, hi1);
+      consider(c0, t1, (t1 > lo1 && t1 < hi1) ? 2 : 0, true);
+      const double c1 = b ? hi1 : lo1;
+      const double t0 = clampd(-(g0 + hod * c1) * ih00, lo0, hi0);
+      consider(t0, c1, (t0 > lo0 && t0 < hi0) ? 1 : 0, true);
+    }
+    const lanemask_t in = lanes_where(interior);
+    k0 = sel64(in, ia, b0); k1 = sel64(in, ib, b1);
+    f0 = interior || (bf & 1); f1 = interior || (bf & 2);
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const double c0 = b ? hi0 : lo0;

@@ -496,7 +496,7 @@ crx::VehicleParams vparams(const crx_vehicle_params* p, int mpc) {
   return crx::VehicleParams{d.dt, d.wheelbase, d.max_steer, d.max_speed, d.min_speed, d.clamp_speed};
 }
 inline bool use_lds(const crx_course* c) { return c->n <= crx::kCourseLdsMax; }
-inline size_t lds_bytes(const crx_course* c) { return use_lds(c) ? sizeof(float2) * (size_t)c->n : 0; }
+inline size_t lds_bytes(const crx_course* c) { return use_lds(c) ? sizeof(float4) * (((size_t)c->n + 1) / 2) : 0; }   // two points per word
 
 // host-side staging of a course for the host-pointer entry points
 struct DevCourse {

@@ -21,7 +21,8 @@
 // Layout: agent state [n][4] = (x, y, yaw, v) — the reference's `struct State` (include/motion_model.h:31-42);
 // the course is five shared read-only arrays of ncourse floats (cx, cy, cyaw, ck, sp).  One agent per lane.
 // The nearest-point search is a linear scan of the whole course per agent per tick, as in the reference; the
-// (cx, cy) pairs are staged once per workgroup in LDS and read as wave-wide broadcasts.
+// course points are staged once per workgroup in LDS, two per 16-byte word as (cx[2j], cx[2j+1], cy[2j], cy[2j+1]), read
+// as wave-wide broadcasts and scored two at a time with packed fp32 arithmetic (same IEEE operations, same order).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -60,13 +61,25 @@ __device__ __forceinline__ float calc_nearest_index_dev(float sx, float sy, cons
                                                         const float2* __restrict__ pts, int& ind) {
   float mind = FLT_MAX;
   int best = ind;
-  for (int i = 0; i < c.n; ++i) {
-    float px, py;
-    if (LDS) { const float2 p = pts[i]; px = p.x; py = p.y; }
-    else { px = c.cx[i]; py = c.cy[i]; }
-    const float idx = px - sx, idy = py - sy;
-    const float d_e = idx * idx + idy * idy;
-    if (d_e < mind) { mind = d_e; best = i; }
+  if (LDS) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float4* __restrict__ pairs = reinterpret_cast<const float4*>(pts);
+    const v2f s2x = {sx, sx}, s2y = {sy, sy};
+    const int np = (c.n + 1) >> 1;                 // an odd course is padded with a NaN point, which never compares smaller
+    for (int j = 0; j < np; ++j) {
+      const float4 q = pairs[j];
+      const v2f px = {q.x, q.y}, py = {q.z, q.w};
+      const v2f idx = px - s2x, idy = py - s2y;
+      const v2f d_e = idx * idx + idy * idy;       // v_pk_mul, v_pk_mul, v_pk_add: idx*idx + idy*idy of each point, unfused
+      if (d_e.x < mind) { mind = d_e.x; best = 2 * j; }
+      if (d_e.y < mind) { mind = d_e.y; best = 2 * j + 1; }
+    }
+  } else {
+    for (int i = 0; i < c.n; ++i) {
+      const float idx = c.cx[i] - sx, idy = c.cy[i] - sy;
+      const float d_e = idx * idx + idy * idy;
+      if (d_e < mind) { mind = d_e; best = i; }
+    }
   }
   ind = best;
   const int j = best < 0 ? 0 : (best >= c.n ? c.n - 1 : best);   // memory safety only (stale caller index + NaN position)
@@ -158,7 +171,13 @@ __device__ __forceinline__ void update_dev(float& sx, float& sy, float& syaw, fl
 }
 
 __device__ __forceinline__ void stage_course(const CourseView& c, float2* pts) {
-  for (int i = threadIdx.x; i < c.n; i += blockDim.x) pts[i] = make_float2(c.cx[i], c.cy[i]);
+  float4* pairs = reinterpret_cast<float4*>(pts);
+  const int np = (c.n + 1) >> 1;
+  for (int j = threadIdx.x; j < np; j += blockDim.x) {
+    const int i0 = 2 * j, i1 = 2 * j + 1;
+    const bool has1 = i1 < c.n;
+    pairs[j] = make_float4(c.cx[i0], has1 ? c.cx[i1] : __builtin_nanf(""), c.cy[i0], has1 ? c.cy[i1] : __builtin_nanf(""));
+  }
   __syncthreads();
 }
 
@@ -168,7 +187,7 @@ __global__ void __launch_bounds__(kTrackBlock)
 lqr_steering_control_kernel(int n, const float* __restrict__ state, CourseView c, int* __restrict__ ind_io,
                             float* __restrict__ pe_io, float* __restrict__ pth_io, double dt, double L, float eps,
                             int maxiter, float* __restrict__ control) {
-  extern __shared__ float2 pts[];
+  extern __shared__ __attribute__((aligned(16))) float2 pts[];
   if (LDS) stage_course(c, pts);
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = a < (size_t)n;
@@ -206,7 +225,7 @@ lqr_closed_loop_kernel(int n, int max_ticks, float* __restrict__ state, CourseVi
                        float* __restrict__ pth_io, int* __restrict__ ind_io, double dt, double L, float eps, int maxiter,
                        VehicleParams vp, float goal_x, float goal_y, float goal_dis, double kp, float stop_speed,
                        float* __restrict__ traj_hist, int* __restrict__ ticks_done) {
-  extern __shared__ float2 pts[];
+  extern __shared__ __attribute__((aligned(16))) float2 pts[];
   if (LDS) stage_course(c, pts);
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = a < (size_t)n;
@@ -299,7 +318,7 @@ calc_nearest_index_window_kernel(int n, const float* __restrict__ state, CourseV
 template <bool LDS>
 __global__ void __launch_bounds__(kTrackBlock)
 calc_nearest_index_kernel(int n, const float* __restrict__ state, CourseView c, int* __restrict__ ind_io, float* __restrict__ e_out) {
-  extern __shared__ float2 pts[];
+  extern __shared__ __attribute__((aligned(16))) float2 pts[];
   if (LDS) stage_course(c, pts);
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= (size_t)n) return;

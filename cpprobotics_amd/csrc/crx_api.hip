@@ -96,7 +96,7 @@ struct DevBuf {
 
 extern "C" {
 
-int crx_version(void) { return 200; }  // 0.2.0
+int crx_version(void) { return 201; }  // 0.2.1 (0.2.0 + crx_smooth_yaw)
 
 // The engine keeps no global state: crx_init only checks that a device is there and forces the HIP runtime + code object to
 // load now rather than in the first timed call; crx_shutdown drains the device.  Both are optional.

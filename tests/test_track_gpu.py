@@ -30,6 +30,29 @@ def test_calc_nearest_index_bit_exact(crx, oracle_mod, lqr_setup, n):
     assert np.array_equal(ind.cpu().numpy(), io) and bit_equal(e.cpu().numpy(), eo)
 
 
+@pytest.mark.parametrize("nc", [1, 2, 3, 64, 425, 8192, 8193, 20001])
+def test_calc_nearest_index_course_lengths(crx, oracle_mod, nc):
+    """Odd, even, tiny and very long courses: the scan reads two points per LDS word (an odd course is padded with a point that
+    never compares smaller); courses beyond 8,192 points are scanned from global memory.  Ties (repeated points) keep the first."""
+    rng = np.random.default_rng(nc)
+    t = np.linspace(0.0, 6.0, nc)
+    cx = (20.0 * np.cos(t) + rng.normal(0, 0.05, nc)).astype(np.float32)
+    cy = (15.0 * np.sin(1.3 * t) + rng.normal(0, 0.05, nc)).astype(np.float32)
+    if nc >= 64:
+        cx[nc // 2] = cx[nc // 2 - 7]; cy[nc // 2] = cy[nc // 2 - 7]          # an exact duplicate: the earlier index must win
+    cyaw = rng.uniform(-3, 3, nc).astype(np.float32)
+    course = (cx, cy, cyaw, np.zeros(nc, np.float32), np.full(nc, 2.0, np.float32))
+    n = 333
+    st = np.stack([rng.uniform(-25, 25, n), rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(0, 3, n)], axis=1).astype(np.float32)
+    if nc >= 64:
+        st[:5, 0] = cx[nc // 2]; st[:5, 1] = cy[nc // 2]                       # agents sitting exactly on the duplicated point
+    io, eo = oracle_mod.calc_nearest_index(st, course)
+    ind, e = crx.calc_nearest_index(_t(st), crx.Course.from_numpy(course))
+    assert np.array_equal(ind.cpu().numpy(), io) and bit_equal(e.cpu().numpy(), eo)
+    if nc >= 64:
+        assert (io[:5] == nc // 2 - 7).all()
+
+
 @pytest.mark.parametrize("dim", [5, 4])
 @pytest.mark.parametrize("n", [1, 100, 1025])
 def test_lqr_steering_control_bit_exact(crx, oracle_mod, lqr_setup, dim, n):

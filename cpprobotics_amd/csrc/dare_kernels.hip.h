@@ -21,6 +21,7 @@
 // contraction; one IEEE division per 2x2 inverse.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace crx {
 
@@ -233,54 +234,7 @@ dare_dense_kernel(int n, const float* __restrict__ Ag, const float* __restrict__
 }
 
 // ---------- structured: A, B from v; Q = I; R = I ----------------------------------------------
-// 5x5 (:116-129): A00=1 A01=dt A12=v A22=1 A23=dt A44=1 ; B30=v/L B41=dt.
-__device__ __forceinline__ void dare5_v_iter(float dt, float v, float bv, float bd, const float* X,
-                                             float* Xn) {
-  float AtX[25], c4[25];
-  float c2[10];
-  // A'X : row0 = X0., row1 = dt*X0., row2 = v*X1. + X2., row3 = dt*X2., row4 = X4.
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {
-    AtX[0 + 5 * j] = X[0 + 5 * j];
-    AtX[1 + 5 * j] = dt * X[0 + 5 * j];
-    AtX[2 + 5 * j] = v * X[1 + 5 * j] + X[2 + 5 * j];
-    AtX[3 + 5 * j] = dt * X[2 + 5 * j];
-    AtX[4 + 5 * j] = X[4 + 5 * j];
-  }
-  // G = (B'X)B ; B'X row0 = bv*X3., row1 = bd*X4.
-  const float G00 = (bv * X[3 + 5 * 3]) * bv, G10 = (bd * X[4 + 5 * 3]) * bv;
-  const float G01 = (bv * X[3 + 5 * 4]) * bd, G11 = (bd * X[4 + 5 * 4]) * bd;
-  float Sg[4] = {1.0f + G00, 0.0f + G10, 0.0f + G01, 1.0f + G11}, Si[4];
-  inverse2(Sg, Si);
-  // c1 = (A'X)B : col0 = AtX.3*bv, col1 = AtX.4*bd ; c2 = c1*Si
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const float c10 = AtX[i + 5 * 3] * bv, c11 = AtX[i + 5 * 4] * bd;
-    c2[i] = c10 * Si[0] + c11 * Si[1];
-    c2[i + 5] = c10 * Si[2] + c11 * Si[3];
-  }
-  // c3 = c2*B' : only columns 3 (c2.0*bv) and 4 (c2.1*bd) ; c4 = c3*X
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const float c33 = c2[i] * bv, c34 = c2[i + 5] * bd;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) c4[i + 5 * j] = c33 * X[3 + 5 * j] + c34 * X[4 + 5 * j];
-  }
-  // Xn = ((A'X)A - c4*A) + I ; (M*A) col0 = M.0, col1 = M.0*dt, col2 = M.1*v + M.2, col3 = M.2*dt, col4 = M.4
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const float p10 = AtX[i], p11 = AtX[i] * dt, p12 = AtX[i + 5] * v + AtX[i + 10],
-                p13 = AtX[i + 10] * dt, p14 = AtX[i + 20];
-    const float p20 = c4[i], p21 = c4[i] * dt, p22 = c4[i + 5] * v + c4[i + 10],
-                p23 = c4[i + 10] * dt, p24 = c4[i + 20];
-    Xn[i + 0] = (p10 - p20) + (i == 0 ? 1.0f : 0.0f);
-    Xn[i + 5] = (p11 - p21) + (i == 1 ? 1.0f : 0.0f);
-    Xn[i + 10] = (p12 - p22) + (i == 2 ? 1.0f : 0.0f);
-    Xn[i + 15] = (p13 - p23) + (i == 3 ? 1.0f : 0.0f);
-    Xn[i + 20] = (p14 - p24) + (i == 4 ? 1.0f : 0.0f);
-  }
-}
-
+// 5x5 (:116-129): A00=1 A01=dt A12=v A22=1 A23=dt A44=1 ; B30=v/L B41=dt.  The iteration itself is dare5_v_iter_pk below.
 __device__ __forceinline__ void dlqr5_v_gain(float dt, float v, float bv, float bd, const float* X,
                                              float* K) {
   float BtX[10];
@@ -302,36 +256,7 @@ __device__ __forceinline__ void dlqr5_v_gain(float dt, float v, float bv, float 
   }
 }
 
-// 4x4 (:104-115): A00=1 A01=dt A12=v A22=1 A23=dt ; B3=v/L ; R=1.
-__device__ __forceinline__ void dare4_v_iter(float dt, float v, float bv, const float* X, float* Xn) {
-  float AtX[16], c4[16];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    AtX[0 + 4 * j] = X[0 + 4 * j];
-    AtX[1 + 4 * j] = dt * X[0 + 4 * j];
-    AtX[2 + 4 * j] = X[2 + 4 * j] + v * X[1 + 4 * j];
-    AtX[3 + 4 * j] = dt * X[2 + 4 * j];
-  }
-  const float g = (bv * X[3 + 4 * 3]) * bv;
-  const float s = 1.0f + g;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float c2 = (AtX[i + 12] * bv) / s;
-    const float c33 = c2 * bv;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c4[i + 4 * j] = c33 * X[3 + 4 * j];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float p10 = AtX[i], p11 = AtX[i] * dt, p12 = AtX[i + 4] * v + AtX[i + 8], p13 = AtX[i + 8] * dt;
-    const float p20 = c4[i], p21 = c4[i] * dt, p22 = c4[i + 4] * v + c4[i + 8], p23 = c4[i + 8] * dt;
-    Xn[i + 0] = (p10 - p20) + (i == 0 ? 1.0f : 0.0f);
-    Xn[i + 4] = (p11 - p21) + (i == 1 ? 1.0f : 0.0f);
-    Xn[i + 8] = (p12 - p22) + (i == 2 ? 1.0f : 0.0f);
-    Xn[i + 12] = (p13 - p23) + (i == 3 ? 1.0f : 0.0f);
-  }
-}
-
+// 4x4 (:104-115): A00=1 A01=dt A12=v A22=1 A23=dt ; B3=v/L ; R=1.  The iteration itself is dare4_v_iter_pk below.
 __device__ __forceinline__ void dlqr4_v_gain(float dt, float v, float bv, const float* X, float* K) {
   const float b0 = bv * X[3 + 0], b1 = bv * X[3 + 4], b2 = bv * X[3 + 8], b3 = bv * X[3 + 12];
   const float g = b3 * bv;
@@ -340,6 +265,136 @@ __device__ __forceinline__ void dlqr4_v_gain(float dt, float v, float bv, const 
   K[1] = inv * (b0 * dt);
   K[2] = inv * (b2 + b1 * v);
   K[3] = inv * (b2 * dt);
+}
+
+// ---------- structured iterations on packed rows -----------------------------------------------------------------------
+// A'X, (A'X)B, its product with the 2x2 inverse, with B', with X and with A — written for the literal 0/1 structure of A and B
+// (at most two non-zero terms per sum, so every coefficient equals the dense Eigen-order evaluation bit for bit:
+// tests/test_lqr_gpu.py::test_dare_dense_matches_structured_and_oracle) and laid out so that two neighbouring columns of a
+// row share one packed fp32 instruction: X is held as rows of column pairs (0,1), (2,3) (+ column 4).  v_pk_mul_f32 /
+// v_pk_add_f32 are two independent IEEE operations — the bits are those of the scalar form; the instruction count is not
+// (the compiler's own pairing of a scalar formulation spent a fifth of the loop on register moves: -7 % / -9 % VALU).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f bc2(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ float max_abs2(float m, v2f d) { return fmaxf(fmaxf(m, fabsf(d.x)), fabsf(d.y)); }
+
+struct Row5 { v2f a, b; float c; };   // columns (0,1), (2,3), 4 of one row
+struct Row4 { v2f a, b; };            // columns (0,1), (2,3)
+
+__device__ __forceinline__ void dare5_v_iter_pk(float dt, float v, float bv, float bd, const Row5* X, Row5* Xn) {
+  Row5 R[5];                                                   // A'X, row by row
+  R[0] = X[0];
+  R[1].a = bc2(dt) * X[0].a; R[1].b = bc2(dt) * X[0].b; R[1].c = dt * X[0].c;
+  R[2].a = bc2(v) * X[1].a + X[2].a; R[2].b = bc2(v) * X[1].b + X[2].b; R[2].c = v * X[1].c + X[2].c;
+  R[3].a = bc2(dt) * X[2].a; R[3].b = bc2(dt) * X[2].b; R[3].c = dt * X[2].c;
+  R[4] = X[4];
+  const float G00 = (bv * X[3].b.y) * bv, G10 = (bd * X[4].b.y) * bv;
+  const float G01 = (bv * X[3].c) * bd, G11 = (bd * X[4].c) * bd;
+  float Sg[4] = {1.0f + G00, 0.0f + G10, 0.0f + G01, 1.0f + G11}, Si[4];
+  inverse2(Sg, Si);
+  const v2f si02 = {Si[0], Si[2]}, si13 = {Si[1], Si[3]}, bvd = {bv, bd};
+  const v2f vdt = {v, dt}, one_dt = {1.0f, dt};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float c10 = R[i].b.y * bv, c11 = R[i].c * bd;        // ((A'X)B) row i
+    const v2f c2 = bc2(c10) * si02 + bc2(c11) * si13;           // * Si
+    const v2f c3 = c2 * bvd;                                   // the two non-zero columns (3, 4) of (..)*B'
+    Row5 C;                                                    // row i of (..)*X
+    C.a = bc2(c3.x) * X[3].a + bc2(c3.y) * X[4].a;
+    C.b = bc2(c3.x) * X[3].b + bc2(c3.y) * X[4].b;
+    C.c = c3.x * X[3].c + c3.y * X[4].c;
+    // (M*A) columns: 0 = M.0, 1 = M.0*dt, 2 = M.1*v + M.2, 3 = M.2*dt, 4 = M.4.   x*1.0f = x and x + (-0.0f) = x bit for bit
+    const v2f p1a = bc2(R[i].a.x) * one_dt, p2a = bc2(C.a.x) * one_dt;
+    const v2f p1b = (v2f){R[i].a.y, R[i].b.x} * vdt + (v2f){R[i].b.x, -0.0f};
+    const v2f p2b = (v2f){C.a.y, C.b.x} * vdt + (v2f){C.b.x, -0.0f};
+    Xn[i].a = (p1a - p2a) + (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+    Xn[i].b = (p1b - p2b) + (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+    Xn[i].c = (R[i].c - C.c) + (i == 4 ? 1.0f : 0.0f);
+  }
+}
+
+__device__ __forceinline__ void dare4_v_iter_pk(float dt, float v, float bv, const Row4* X, Row4* Xn) {
+  Row4 R[4];
+  R[0] = X[0];
+  R[1].a = bc2(dt) * X[0].a; R[1].b = bc2(dt) * X[0].b;
+  R[2].a = X[2].a + bc2(v) * X[1].a; R[2].b = X[2].b + bc2(v) * X[1].b;
+  R[3].a = bc2(dt) * X[2].a; R[3].b = bc2(dt) * X[2].b;
+  const float g = (bv * X[3].b.y) * bv;
+  const float s = 1.0f + g;
+  const v2f vdt = {v, dt}, one_dt = {1.0f, dt};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float c2 = (R[i].b.y * bv) / s;
+    const float c33 = c2 * bv;
+    Row4 C;
+    C.a = bc2(c33) * X[3].a; C.b = bc2(c33) * X[3].b;
+    const v2f p1a = bc2(R[i].a.x) * one_dt, p2a = bc2(C.a.x) * one_dt;
+    const v2f p1b = (v2f){R[i].a.y, R[i].b.x} * vdt + (v2f){R[i].b.x, -0.0f};
+    const v2f p2b = (v2f){C.a.y, C.b.x} * vdt + (v2f){C.b.x, -0.0f};
+    Xn[i].a = (p1a - p2a) + (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+    Xn[i].b = (p1b - p2b) + (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+  }
+}
+
+// max |Y - X| with the scan semantics of max_abs_diff: element (0,0) first, NaN there sticks.
+__device__ __forceinline__ float max_abs_diff_rows(const Row5* Y, const Row5* X) {
+  const v2f d0 = Y[0].a - X[0].a;
+  const float m0 = fabsf(d0.x);
+  float m = fmaxf(m0, fabsf(d0.y));
+  m = max_abs2(m, Y[0].b - X[0].b); m = fmaxf(m, fabsf(Y[0].c - X[0].c));
+#pragma unroll
+  for (int i = 1; i < 5; ++i) { m = max_abs2(m, Y[i].a - X[i].a); m = max_abs2(m, Y[i].b - X[i].b); m = fmaxf(m, fabsf(Y[i].c - X[i].c)); }
+  return (m0 != m0) ? m0 : m;
+}
+__device__ __forceinline__ float max_abs_diff_rows(const Row4* Y, const Row4* X) {
+  const v2f d0 = Y[0].a - X[0].a;
+  const float m0 = fabsf(d0.x);
+  float m = fmaxf(m0, fabsf(d0.y));
+  m = max_abs2(m, Y[0].b - X[0].b);
+#pragma unroll
+  for (int i = 1; i < 4; ++i) { m = max_abs2(m, Y[i].a - X[i].a); m = max_abs2(m, Y[i].b - X[i].b); }
+  return (m0 != m0) ? m0 : m;
+}
+
+// The reference's loop (see riccati_fixed_point) for A, B built from v, Q = I, R = I, on packed rows.  Xcm receives the
+// result column-major like every other X of this file; returns the number of evaluations.
+template <int DIM>
+__device__ __forceinline__ int riccati_from_v(float dt, float v, float bv, float bd, float eps, int maxiter, bool live, float* Xcm) {
+  using Row = typename std::conditional<DIM == 5, Row5, Row4>::type;
+  Row X[DIM], Y[DIM];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    X[i].a = (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+    X[i].b = (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+    if constexpr (DIM == 5) X[i].c = (i == 4) ? 1.0f : 0.0f;
+  }
+  auto iter = [&](const Row* Xi, Row* Xo) {
+    if constexpr (DIM == 5) dare5_v_iter_pk(dt, v, bv, bd, Xi, Xo);
+    else dare4_v_iter_pk(dt, v, bv, Xi, Xo);
+  };
+  bool done = !live || maxiter <= 0;
+  bool in_y = false;
+  int it = maxiter < 0 ? 0 : maxiter;
+  for (int i = 0; i < maxiter; i += 2) {
+    if (!done) {
+      iter(X, Y);
+      in_y = true;
+      if (max_abs_diff_rows(Y, X) < eps) { done = true; it = i + 1; }
+    }
+    if (!done && i + 1 < maxiter) {
+      iter(Y, X);
+      in_y = false;
+      if (max_abs_diff_rows(X, Y) < eps) { done = true; it = i + 2; }
+    }
+    if (__all(done)) break;
+  }
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) {
+    const Row& r = in_y ? Y[i] : X[i];
+    Xcm[i + DIM * 0] = r.a.x; Xcm[i + DIM * 1] = r.a.y; Xcm[i + DIM * 2] = r.b.x; Xcm[i + DIM * 3] = r.b.y;
+    if constexpr (DIM == 5) Xcm[i + DIM * 4] = r.c;
+  }
+  return it;
 }
 
 template <int DIM>
@@ -353,12 +408,7 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
   const float v = live ? vg[a] : 1.0f;
   const float bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
   float X[NN];
-#pragma unroll
-  for (int i = 0; i < NN; ++i) X[i] = (i % (DIM + 1) == 0) ? 1.0f : 0.0f;
-  const int it = riccati_fixed_point<NN>(X, eps, maxiter, live, [&](const float* Xi, float* Xo) {
-    if (DIM == 5) dare5_v_iter(dt, v, bv, dt, Xi, Xo);
-    else dare4_v_iter(dt, v, bv, Xi, Xo);
-  });
+  const int it = riccati_from_v<DIM>(dt, v, bv, dt, eps, maxiter, live, X);
   if (!live) return;
   if (Xg) {
 #pragma unroll

@@ -96,12 +96,7 @@ __device__ __forceinline__ void dlqr_from_v_dev(float v, float dtf, double L, fl
   constexpr int NN = DIM * DIM;
   const float bv = (float)((double)v / L);   // B(3,0) = state.v / L
   float X[NN];
-#pragma unroll
-  for (int i = 0; i < NN; ++i) X[i] = (i % (DIM + 1) == 0) ? 1.0f : 0.0f;
-  riccati_fixed_point<NN>(X, eps, maxiter, live, [&](const float* Xi, float* Xo) {
-    if (DIM == 5) dare5_v_iter(dtf, v, bv, dtf, Xi, Xo);
-    else dare4_v_iter(dtf, v, bv, Xi, Xo);
-  });
+  riccati_from_v<DIM>(dtf, v, bv, dtf, eps, maxiter, live, X);
   if (DIM == 5) dlqr5_v_gain(dtf, v, bv, dtf, X, K);
   else dlqr4_v_gain(dtf, v, bv, X, K);
 }

@@ -43,9 +43,9 @@
 namespace crx {
 
 // Selects.  The compiler's idiom for `c ? a : b` on doubles is v_cmp -> VCC and two VOP2 v_cndmask_b32_e32 reading VCC
-// implicitly; that encoding issues at ~19 cycles per instruction on gfx950 (profiles/r01/ubench_issue_patterns.txt, rows
-// U/V/W: the VOP3 encoding with the mask in an SGPR pair, or in VCC, issues at 5.5) and the solver's candidate scoring and
-// quadrant logic are chains of them.  sel64 emits the VOP3 form.
+// implicitly; back-to-back runs of that encoding issue at ~19 cycles per instruction on gfx950, the VOP3 encoding with the
+// mask in an SGPR pair at 5.5 (profiles/r01/ubench_issue_patterns.txt, rows U/V/W), and the solver's candidate scoring and
+// quadrant logic select several values on one condition.  sel64 emits the VOP3 form (measured: -3 % on the BASELINE solve).
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ lanemask_t lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 __device__ __forceinline__ int sel32(lanemask_t m, int a, int b) {   // lane's bit of m set ? a : b

@@ -1,5 +1,7 @@
 """GPU parity: HIP MPC solver (through the C ABI) against its CPU twin — 1e-6 floored relative
 (fp64 arithmetic on both sides; libm vs device trig and summation order differ, so not bit-exact)."""
+import math
+
 import numpy as np
 import pytest
 
@@ -107,6 +109,32 @@ def test_mpc_more_seeds(crx, oracle_mod, seed):
     not — the two must still walk the same path."""
     sd, std = _compare(crx, oracle_mod, 2048, 21, seed, 0.999)
     assert (std >> 8).max() <= 30
+
+
+@pytest.mark.parametrize("over", [dict(max_steer=math.radians(60.0)), dict(max_steer=math.radians(20.0), max_accel=0.6),
+                                  dict(q_x=2.0, q_y=0.5, q_yaw=0.1, q_v=1.5, r_a=0.05, r_delta=0.02, rd_a=0.1, rd_delta=0.3),
+                                  dict(dt=0.1, wb=1.5, max_speed=4.0, min_speed=-1.0)])
+def test_mpc_other_parameters(crx, oracle_mod, over):
+    """Non-default problem parameters: a steering limit beyond 45 degrees (the kernel's reduction-free tan no longer applies),
+    tighter limits, other weights, another time step / wheelbase / speed bounds."""
+    import ctypes as C
+    n, T = 600, 21
+    x0, xref = mpc_problem(n, T, 77)
+    so, sto, co = mpc_solve_threads(oracle_mod, x0, xref, T, params=over)
+    p = crx.mpc.default_params()
+    for k, v in over.items():
+        setattr(p, k, v)
+    sd, std, cd = crx.mpc_solve(_t(x0), _t(xref), T, params=p, return_status=True)
+    sd, std, cd = sd.cpu().numpy(), std.cpu().numpy(), cd.cpu().numpy()
+    conv = (sto & 1) == 1
+    assert conv.mean() > 0.95 and np.array_equal(std & 1, sto & 1)
+    assert (np.abs((std >> 8) - (sto >> 8)) <= 1).all()
+    assert floored_rel_err(sd[conv], so[conv], 1.0) <= TOL
+    N = T - 1
+    ms = over.get("max_steer", math.radians(45.0)); ma = over.get("max_accel", 1.0)
+    assert np.all(np.abs(sd[:, 4 * T:4 * T + N]) <= np.float32(ms) + 1e-6) and np.all(np.abs(sd[:, 4 * T + N:]) <= ma + 1e-6)
+    if "max_steer" in over and over["max_steer"] > 0.8:
+        assert np.abs(sd[:, 4 * T:4 * T + N]).max() > 0.8          # the wider limit is actually used
 
 
 def test_mpc_edge_cases(crx):

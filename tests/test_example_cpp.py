@@ -1,4 +1,5 @@
-"""examples/*.cpp: the reference's EKF demo and its two sampling planners for a whole fleet, in C++ against the C ABI."""
+"""examples/*.cpp: the reference's EKF demo, its two sampling planners and its two tracking demos for a whole fleet, in C++
+against the C ABI."""
 import os
 import subprocess
 
@@ -23,6 +24,11 @@ def exe(tmp_path_factory, crx):
 @pytest.fixture(scope="module")
 def planner_exe(tmp_path_factory, crx):
     return _build(tmp_path_factory, "planner_fleet")
+
+
+@pytest.fixture(scope="module")
+def tracking_exe(tmp_path_factory, crx):
+    return _build(tmp_path_factory, "tracking_fleet")
 
 
 def test_example_builds_and_fails_loudly_without_gpu(exe):
@@ -53,3 +59,24 @@ def test_planner_example_runs(planner_exe):
     r = subprocess.run([planner_exe, "512"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Frenet:" in r.stdout and "DWA:" in r.stdout
+
+
+def test_tracking_example_builds_and_fails_loudly_without_gpu(tracking_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([tracking_exe, "64"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tracking_example_runs(tracking_exe):
+    """The two tracking mains for a fleet: agent 0 is the reference's own vehicle — it reaches the LQR goal, and advances along the
+    MPC course."""
+    import re
+    r = subprocess.run([tracking_exe, "512"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"LQR: .* reached the goal after (\d+) ticks; (\d+) of 512 reached it", r.stdout)
+    assert m and 100 < int(m.group(1)) < 1000 and int(m.group(2)) > 450, r.stdout
+    m = re.search(r"MPC: .* agent 0 is at course index (\d+)", r.stdout)
+    assert m and int(m.group(1)) > 30, r.stdout

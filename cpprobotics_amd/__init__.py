@@ -19,7 +19,7 @@ from .dwa import dwa_control, dwa_default_config, dwa_run  # noqa: F401
 from .frenet import FrenetCourse, frenet_default_config, frenet_num_paths, frenet_optimal_planning, frenet_run  # noqa: F401
 from .pf import pf_default_params, pf_run  # noqa: F401
 from .track import (  # noqa: F401
-    Course, course_from_waypoints, calc_nearest_index, calc_nearest_index_window, calc_ref_trajectory, closed_loop_prediction,
+    Course, course_from_waypoints, calc_speed_profile, calc_nearest_index, calc_nearest_index_window, calc_ref_trajectory, closed_loop_prediction,
     lqr_steering_control, mpc_simulation, smooth_yaw, update, vehicle_params,
 )
 
@@ -31,6 +31,6 @@ __all__ = [
     "mpc_solve", "mpc_n_vars",
     "pf_run", "pf_default_params", "dwa_run", "dwa_control", "dwa_default_config",
     "FrenetCourse", "frenet_default_config", "frenet_num_paths", "frenet_optimal_planning", "frenet_run",
-    "Course", "course_from_waypoints", "calc_nearest_index", "lqr_steering_control", "update", "closed_loop_prediction",
+    "Course", "course_from_waypoints", "calc_speed_profile", "calc_nearest_index", "lqr_steering_control", "update", "closed_loop_prediction",
     "calc_nearest_index_window", "calc_ref_trajectory", "mpc_simulation", "smooth_yaw", "vehicle_params",
 ]

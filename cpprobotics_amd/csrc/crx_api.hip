@@ -993,10 +993,11 @@ int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double d
 // variant 0 (src/model_predictive_control.cpp:83-105): sign from the direction of travel against the heading; the reference's
 // `speed_profile[-1] = 0.0` (:102) writes BEFORE the vector, so the last entry keeps its value, as here.
 int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp) {
-  if ((variant != 0 && variant != 5) || n < 1 || !ryaw || !sp || (variant == 0 && (!rx || !ry))) return fail(CRX_ERR_INVALID, "calc_speed_profile: bad argument");
+  if ((variant != 0 && variant != 4 && variant != 5) || n < 1 || !ryaw || !sp || (variant == 0 && (!rx || !ry)))
+    return fail(CRX_ERR_INVALID, "calc_speed_profile: bad argument (variant 5, 4 or 0)");
   for (int i = 0; i < n; ++i) sp[i] = target_speed;
   float direction = 1.0;
-  if (variant == 5) {
+  if (variant == 5 || variant == 4) {
     for (int i = 0; i + 1 < n; ++i) {
       const float dyaw = std::abs(ryaw[i + 1] - ryaw[i]);
       const float switch_point = (M_PI / 4.0 < dyaw) && (dyaw < M_PI / 2.0);
@@ -1004,9 +1005,13 @@ int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const 
       if (direction != 1.0) sp[i] = target_speed * -1; else sp[i] = target_speed;
       if (switch_point) sp[i] = 0.0;
     }
-    for (int k = 1; k < 40 && k <= n; ++k) {
-      sp[n - k] = target_speed / (50 - k);
-      if (sp[n - k] <= 1.0 / 3.6) sp[n - k] = 1.0 / 3.6;
+    if (variant == 5) {
+      for (int k = 1; k < 40 && k <= n; ++k) {          // :55-60 (its k = 0 writes past the end and is not made)
+        sp[n - k] = target_speed / (50 - k);
+        if (sp[n - k] <= 1.0 / 3.6) sp[n - k] = 1.0 / 3.6;
+      }
+    } else {
+      sp[n - 1] = 0.0;                                  // src/lqr_steer_control.cpp:50
     }
   } else {
     for (int i = 0; i + 1 < n; ++i) {

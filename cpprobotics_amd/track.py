@@ -38,7 +38,8 @@ class Course:
 
 def course_from_waypoints(wx, wy, ds, target_speed=10.0 / 3.6, variant=5):
     """The course arrays (cx, cy, cyaw, ck, speed_profile) the reference's mains build: Spline2D(wx, wy) sampled every ds
-    (lqr files ds = 0.1, MPC ds = 1.0) and calc_speed_profile (variant 5 = lqr_speed_steer_control.cpp, 0 = MPC).  numpy, host."""
+    (lqr files ds = 0.1, MPC ds = 1.0) and calc_speed_profile (variant 5 = lqr_speed_steer_control.cpp, 4 = lqr_steer_control.cpp,
+    0 = MPC).  numpy, host."""
     import numpy as np
     wx = np.ascontiguousarray(wx, dtype=np.float32); wy = np.ascontiguousarray(wy, dtype=np.float32)
     l = L.lib()
@@ -50,6 +51,17 @@ def course_from_waypoints(wx, wy, ds, target_speed=10.0 / 3.6, variant=5):
     L.check(l.crx_calc_speed_profile(int(variant), cx.ctypes.data, cy.ctypes.data, cyaw.ctypes.data, k, float(target_speed), sp.ctypes.data),
             "crx_calc_speed_profile")
     return cx, cy, cyaw, ck, sp
+
+
+def calc_speed_profile(variant, cx, cy, cyaw, target_speed=10.0 / 3.6):
+    """calc_speed_profile of the reference's tracking files: variant 5 = lqr_speed_steer_control.cpp:40-62, 4 = lqr_steer_control.cpp:35-52,
+    0 = model_predictive_control.cpp:83-105.  numpy, host."""
+    import numpy as np
+    cx, cy, cyaw = (np.ascontiguousarray(a, dtype=np.float32) for a in (cx, cy, cyaw))
+    sp = np.zeros(len(cyaw), np.float32)
+    L.check(L.lib().crx_calc_speed_profile(int(variant), cx.ctypes.data, cy.ctypes.data, cyaw.ctypes.data, len(cyaw), float(target_speed),
+                                           sp.ctypes.data), "crx_calc_speed_profile")
+    return sp
 
 
 def smooth_yaw(cyaw):

@@ -327,8 +327,9 @@ int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, i
  * the nx x nx system by colPivHouseholderQr in float) sampled every ds: src/lqr_speed_steer_control.cpp:252-265 (ds = 0.1),
  * src/model_predictive_control.cpp:473-486 (ds = 1.0).  Returns the sample count; fills up to cap of each non-NULL array. */
 int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double ds, float* cx, float* cy, float* cyaw, float* ck, int cap);
-/* host: calc_speed_profile, variant 5 = src/lqr_speed_steer_control.cpp:40-62, variant 0 = src/model_predictive_control.cpp:83-105;
- * the two out-of-bounds writes of the reference (:55-56 k = 0, :102) are not made. */
+/* host: calc_speed_profile, variant 5 = src/lqr_speed_steer_control.cpp:40-62, variant 4 = src/lqr_steer_control.cpp:35-52,
+ * variant 0 = src/model_predictive_control.cpp:83-105; the two out-of-bounds writes of the reference (5-state file :55-56 with
+ * k = 0, MPC file :102 `speed_profile[-1]`) are not made. */
 int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp);
 /* host, in place: smooth_yaw, src/model_predictive_control.cpp:172-185 — what mpc_simulation (:360) does to the course headings
  * before its loop: a step of more than pi/2 between consecutive samples is unwound by 2 pi (float -= double, as the reference).

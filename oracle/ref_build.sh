@@ -36,12 +36,14 @@ ext src/lqr_speed_steer_control.cpp 167 171 lqr5_loop_setup.inc  # T, goal_dis, 
 ext src/lqr_speed_steer_control.cpp 185 186 lqr5_loop_e.inc      # e, e_th
 ext src/lqr_speed_steer_control.cpp 195 205 lqr5_loop_body.inc   # control, update, goal test
 ext src/lqr_speed_steer_control.cpp 252 265 lqr5_main_course.inc # Spline2D csp_obj(wx, wy) … the sampling loop (ds = 0.1)
+ext src/lqr_speed_steer_control.cpp 40 63 lqr5_speed_profile.inc # calc_speed_profile (with the end-of-course slow-down)
 # ---- src/lqr_steer_control.cpp (4-state)
 ext src/lqr_steer_control.cpp 20 23 lqr4_defs.inc
 ext src/lqr_steer_control.cpp 55 146 lqr4_fns.inc               # calc_nearest_index, solve_DARE, dlqr, lqr_steering_control, update
 ext src/lqr_steer_control.cpp 149 153 lqr4_loop_setup.inc
 ext src/lqr_steer_control.cpp 167 169 lqr4_loop_e.inc            # e, e_th, ind
 ext src/lqr_steer_control.cpp 187 198 lqr4_loop_body.inc
+ext src/lqr_steer_control.cpp 35 52 lqr4_speed_profile.inc      # calc_speed_profile
 # ---- src/model_predictive_control.cpp
 ext src/model_predictive_control.cpp 26 48 mpc_defs.inc          # DT … WB (without NX/T, which the wrapper sets)
 ext src/model_predictive_control.cpp 50 60 mpc_globals.inc       # using …, M_XREF, x_start … a_start
@@ -51,6 +53,7 @@ ext src/model_predictive_control.cpp 188 346 mpc_nlp.inc         # FG_EVAL, mpc_
 ext src/model_predictive_control.cpp 349 360 mpc_sim_setup.inc   # State state(...), yaw wrap, goal_dis, target_ind, smooth_yaw
 ext src/model_predictive_control.cpp 372 385 mpc_sim_body.inc    # calc_ref_trajectory, mpc_solve, update, goal test
 ext src/model_predictive_control.cpp 473 486 mpc_main_course.inc # Spline2D csp_obj(wx, wy) … the sampling loop (ds = 1.0)
+ext src/model_predictive_control.cpp 83 105 mpc_speed_profile.inc # calc_speed_profile
 # ---- src/dynamic_window_approach.cpp (no Eigen in it)
 ext src/dynamic_window_approach.cpp 16 41 dwa_types.inc          # PI, the array aliases, class Config
 ext src/dynamic_window_approach.cpp 43 155 dwa_fns.inc           # motion … dwa_control

@@ -249,6 +249,14 @@ def calc_ref_trajectory(state, course, target_ind, T, dl=1.0):
     return xref, tind
 
 
+def calc_speed_profile(which, rx, ry, ryaw, target_speed):
+    """which: 5 = lqr_speed_steer_control.cpp:40-63, 4 = lqr_steer_control.cpp:35-52, 0 = model_predictive_control.cpp:83-105."""
+    rx, ry, ryaw = _f32(rx), _f32(ry), _f32(ryaw)
+    out = np.zeros(len(ryaw), np.float32)
+    lib().ref_calc_speed_profile(_I(int(which)), _I(len(ryaw)), _p(rx), _p(ry), _p(ryaw), _F(target_speed), _p(out))
+    return out
+
+
 def smooth_yaw(cyaw, T=6):
     c = _f32(cyaw).copy()
     _mpc(T, "smooth_yaw")(_I(len(c)), _p(c))

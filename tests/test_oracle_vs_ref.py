@@ -308,6 +308,27 @@ def test_course_generation_of_the_mains():
         assert np.isfinite(sp).all() and abs(abs(sp[0]) - 10.0 / 3.6) < 1e-6
 
 
+def test_calc_speed_profile_of_the_three_tracking_files():
+    """crx_calc_speed_profile (host) against the reference's own three functions (compiled behind a vector type that absorbs their two
+    out-of-range writes): the mains' courses, and synthetic headings with direction switches (dyaw between 45 and 90 degrees)."""
+    import cpprobotics_amd as crx
+    lqr_w = ([0.0, 6.0, 12.5, 10.0, 17.5, 20.0, 25.0], [0.0, -3.0, -5.0, 6.5, 3.0, 0.0, 0.0])
+    mpc_w = ([0.0, 60.0, 125.0, 50.0, 75.0, 35.0, -10.0], [0.0, 0.0, 50.0, 65.0, 30.0, 50.0, -20.0])
+    rng = np.random.default_rng(3)
+    cases = [R.main_course(*lqr_w, "lqr")[:3], R.main_course(*mpc_w, "mpc")[:3]]
+    for k in range(6):
+        n = int(rng.integers(2, 300))
+        yaw = np.cumsum(rng.choice([0.02, -0.03, 1.0, -1.2, 0.5], n, p=[0.45, 0.45, 0.04, 0.03, 0.03])).astype(np.float32)
+        x = np.cumsum(np.cos(yaw) * rng.choice([1.0, -1.0, 0.0], n, p=[0.8, 0.1, 0.1])).astype(np.float32)
+        y = np.cumsum(np.sin(yaw) * rng.choice([1.0, 0.0], n, p=[0.9, 0.1])).astype(np.float32)
+        cases.append((x, y, yaw))
+    for rx, ry, ryaw in cases:
+        for which in (5, 4, 0):
+            for ts in (10.0 / 3.6, 1.0):
+                assert _eq(crx.calc_speed_profile(which, rx, ry, ryaw, ts), R.calc_speed_profile(which, rx, ry, ryaw, ts)), (which, len(ryaw))
+    assert (crx.calc_speed_profile(5, *cases[0])[-39:] < 10.0 / 3.6).all() and crx.calc_speed_profile(4, *cases[0])[-1] == 0.0
+
+
 def test_smooth_yaw_of_the_mpc_main():
     """crx_smooth_yaw (host) against the reference's own smooth_yaw (:172-185): the MPC main's course headings (atan2 output, which
     jumps by 2 pi where the course turns through +-pi), synthetic windings of several turns, and the refusals."""

@@ -1,0 +1,59 @@
+"""bench.py / __graft_entry__ on a box without a GPU: they must refuse loudly (no CPU fallback of the product path), and the pieces of
+bench.py that are plain host logic behave."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is present")
+def test_bench_refuses_without_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       env={**os.environ, "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+    assert "{" not in r.stdout                      # no JSON line, no number
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is present")
+def test_smoke_refuses_without_gpu():
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and ("no HIP device" in r.stderr or "GPU" in r.stderr)
+
+
+def test_bench_host_helpers():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    c = b.usable_cores()
+    assert 1 <= c <= (os.cpu_count() or 1)
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        a = b.parse()
+        assert a.gpus == 1 and a.steps >= 1 and a.warmup >= 0 and a.vehicles == 65536 and a.T == 1000     # BASELINE configs[1] by default
+        sys.argv = ["bench.py", "--gpus", "8", "--steps", "7", "--warmup", "2"]
+        a = b.parse()
+        assert (a.gpus, a.steps, a.warmup) == (8, 7, 2)
+    finally:
+        sys.argv = old
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench_n1.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "GB/s"
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
+    assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["higher_is_better"] is True

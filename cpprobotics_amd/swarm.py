@@ -55,6 +55,36 @@ def gather_time_major(local, n_total, group=None):
     return buf.view(world, T, nl, Cc).permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()
 
 
+class RingGather:
+    """Per-step all-gather of the agents' final estimates, overlapped with the following launches: step k's collective is issued
+    asynchronously (its own stream on GPUs) into buffer k % ring, and the caller's stream waits for the collectives only once per
+    lap of the ring — `begin_step(k)` before anything of step k that touches state buffer k % ring is enqueued.  The caller keeps
+    `ring` state buffers too, so that a collective never reads a buffer a later launch is resetting.  (A cross-stream wait in
+    front of every launch costs ~30 us of queue bubbles per step on MI355X; see bench.py.)  Equal shards only."""
+
+    def __init__(self, n_total, tail, ring, device, dtype=torch.float32, group=None):
+        self.ring, self.group = int(ring), group
+        self.out = [torch.empty((n_total,) + tuple(tail), dtype=dtype, device=device) for _ in range(self.ring)]
+        self.last = None            # the most recent collective: collectives of one group complete in issue order
+
+    def slot(self, step):
+        return step % self.ring
+
+    def begin_step(self, step):
+        if step % self.ring == 0 and self.last is not None:
+            self.last.wait()        # stream-level on GPUs: every gather of the previous lap is done
+
+    def gather(self, step, local):
+        out = self.out[step % self.ring]
+        self.last = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+        return out
+
+    def wait(self):
+        if self.last is not None:
+            self.last.wait()
+            self.last = None
+
+
 class ChunkedTrajectoryGather:
     """The trajectory concat of north_star, chunked and overlapped: the fused T-step launch is cut into `chunks` launches of
     T/chunks steps (the filter state carries over in place, results bit-identical to one launch) and the all-gather of chunk

@@ -44,6 +44,22 @@ def _worker(rank, world, port, n, T, q):
         hc = cg.run(launch).time_major()
         assert torch.equal(hc, hg) and cg.gathered.shape == (4, world, T // 4, hi - lo, 4)
         assert torch.equal(cg.gathered[1, rank, 2], torch.from_numpy(xh[T // 4 + 2]))     # [chunk][rank][t][agent] index map
+        # the per-step final-estimate gather of bench.py: ring of 4 buffers, the caller waits once per lap
+        rgat = swarm.RingGather(n, (4,), 4, "cpu")
+        nl = hi - lo
+        state = [torch.empty((nl, 4)) for _ in range(4)]                 # the caller's ring of state buffers
+        expect = lambda step: torch.arange(n * 4, dtype=torch.float32).reshape(n, 4) * 0.5 + step
+        for step in range(11):
+            rgat.begin_step(step)
+            if step and step % 4 == 0:                                    # after the lap's wait: the whole previous lap is there
+                for j in range(4):
+                    assert torch.equal(rgat.out[j], expect(step - 4 + j))
+            state[rgat.slot(step)].copy_(expect(step)[lo:hi])             # "launch": overwrite the slot's state
+            got = rgat.gather(step, state[rgat.slot(step)])
+            assert got is rgat.out[step % 4]
+        rgat.wait()
+        for step in (8, 9, 10):
+            assert torch.equal(rgat.out[step % 4], expect(step))
     # tracking swarm: each rank runs the closed LQR loop on its shard of the agents (shared course), results gathered
     from common import lqr_course, tracking_agents
     course, goal = lqr_course()

@@ -421,8 +421,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
         Qux[a][3] = G[a][0] * a03 + G[a][1] * a13 + G[a][2] * a23 + G[a][3];
       }
       double Quu00 = l_uu0 + G[0][2] * bd + bd * Wxp[2][0] + Wpp00;
-      double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
-      double Quu10 = G[1][2] * bd + dt * Wxp[3][0] + Wpp01;
+      // the off-diagonal of Q_uu once: its two halves (B'W B and its transpose) are equal up to rounding, the twin averages them
+      const double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
       double Quu11 = l_uu1 + G[1][3] * dt + dt * Wxp[3][1] + Wpp11;
       // the box of the step: steering limits; the acceleration box of this knot's (nominal) speed = acceleration limits and
       // the speed bounds of knot i+1
@@ -435,14 +435,14 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       if (exact) {   // V_s . d2F; the steering curvature e00 only where it leaves the control Hessian of the controls not held
                      // positive definite (a saturated steering input otherwise proposes a jump to a box corner)
         const double e00 = lx[2] * v * dt_wb * 2.0 * tn * sec2;
-        const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = 0.5 * (Quu01 + Quu10);
+        const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = Quu01;
         Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
         const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
         Qxx[2][3] += cross;
         Qux[0][3] += lx[2] * sec2 * dt_wb;
         if (g0 > 1e-12 && (hold1 || g0 * g3 - go * go > 1e-12 * g0)) Quu00 += e00;
       }
-      const double hod = 0.5 * (Quu01 + Quu10);
+      const double hod = Quu01;
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
       // for a Newton step, a trust box around the current controls — with the exact (possibly indefinite) Hessian an
       // unrestricted stage proposes a jump to the far corner of the box, which the line search rejects at every step

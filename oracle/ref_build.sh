@@ -6,7 +6,8 @@
 # The hot-path functions of the reference live in the translation units of its demo executables, next to main() and the OpenCV
 # drawing code, and include <Eigen/Eigen> (plus <cppad/...> for the MPC) — none of which exists in this image, and the reference's
 # own build system (cmake + find_package(Eigen3/OpenCV)) cannot run here.  So this recipe cuts the cited line ranges out of the
-# reference sources WHERE THEY LIE (sed, into oracle/_ref/gen/, which is git-ignored: no reference source enters this repository),
+# reference sources WHERE THEY LIE (sed, into oracle/_ref/gen/, git-ignored and deleted again when the libraries are linked: no
+# reference source enters this repository or stays on disk),
 # and compiles them, unmodified, inside the thin wrappers of oracle/ref_shim/*.cpp, which export them as C symbols (ref_*).
 # Headers that need nothing but Eigen (cubic_spline.h, motion_model.h, quintic/quartic_polynomial.h, frenet_path.h,
 # cpprobotics_types.h) are included directly from $REF/include.
@@ -86,4 +87,5 @@ if [ $KIND = 0 ]; then
   wait
 fi
 rm -f "$OUT"/*.o
+rm -rf "$GEN"          # the cut-out line ranges are build intermediates: only the libraries stay (no reference text is kept anywhere)
 echo "ref_build: $OUT/libref.so (Eigen: $([ $KIND = 1 ] && echo host || echo stand-in))"

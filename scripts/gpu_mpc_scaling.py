@@ -15,8 +15,9 @@ from common import mpc_problem  # noqa: E402
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 21
 x0a, xra = mpc_problem(65536, T, 4)
-for n in (64, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
-    x0, xr = torch.from_numpy(x0a[:n]).cuda(), torch.from_numpy(xra[:n]).cuda()
+for n in (64, 1024, 2048, 4096, 8192, 16384, 32768, 65536, 262144, 1048576):
+    reps = (n + 65535) // 65536                      # beyond 65,536 agents the generated batch is tiled
+    x0 = torch.from_numpy(x0a[:min(n, 65536)]).cuda().repeat(reps, 1).contiguous(); xr = torch.from_numpy(xra[:min(n, 65536)]).cuda().repeat(reps, 1).contiguous()
     sol, st, _ = crx.mpc_solve(x0, xr, T, return_status=True)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

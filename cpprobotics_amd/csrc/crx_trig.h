@@ -221,4 +221,56 @@ CRX_HD void sincosf_(float y, float* sp, float* cp) {
   *cp = co;
 }
 
+// ---- expf -------------------------------------------------------------------------------------------------------------
+// glibc >= 2.27's expf (Arm Optimized Routines math/expf.c + exp2f_data.c, Copyright (c) 2017-2018 Arm Limited, MIT; glibc
+// sysdeps/ieee754/flt-32/e_expf.c): x*N/ln2 split into an integer k and a remainder r in double, exp(x) = 2^(k/N) * p(r) with a
+// 32-entry table of 2^(i/N) and a cubic, one rounding to float at the end.  The particle filter's gauss_likelihood calls
+// std::exp on a float (/root/reference/src/particle_filter.cpp:53-57).  FMA flavour (CRX_TRIG_FMA=1): glibc's FMA build
+// fuses N/ln2*x into the remainder — r = fma(N/ln2, x, -k) — and the polynomial; bit-identical to glibc 2.35's expf on ALL 2^32
+// inputs (tests/tools/expf_exhaustive.cpp).  The SSE2 flavour (two roundings) differs from it on 2 inputs.
+struct ExpfConsts {
+  static constexpr int N = 32;
+  static constexpr double inv_ln2_n = 0x1.71547652b82fep+0 * N, shift = 0x1.8p+52;
+  static constexpr double c0 = 0x1.c6af84b912394p-5 / N / N / N, c1 = 0x1.ebfce50fac4f3p-3 / N / N, c2 = 0x1.62e42ff0c52d6p-1 / N;
+};
+CRX_HD uint64_t expf_tab(unsigned i) {     // bits of 2^(i/32) minus i << 47, i = 0..31
+  constexpr uint64_t T[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+  return T[i];
+}
+CRX_HD float expf_(float x) {
+  const uint32_t at = abstop12(x);
+  if (at >= 0x42bu) {                                        // |x| >= 88 or NaN
+    if (f32_bits(x) == 0xff800000u) return 0.0f;             // exp(-inf)
+    if (at >= 0x7f8u) return x + x;                          // +inf, NaN
+    if (x > 0x1.62e42ep6f) return __builtin_inff();          // overflow
+    if (x < -0x1.9fe368p6f) return 0.0f;                     // underflow (the results glibc returns through its error path)
+  }
+  const double xd = (double)x;
+  const double z = ExpfConsts::inv_ln2_n * xd;
+  double kd = z + ExpfConsts::shift;
+  union { double d; uint64_t u; } kb; kb.d = kd;
+  const uint64_t ki = kb.u;
+  kd -= ExpfConsts::shift;
+#if CRX_TRIG_FMA
+  const double r = __builtin_fma(ExpfConsts::inv_ln2_n, xd, -kd);
+#else
+  const double r = z - kd;
+#endif
+  union { uint64_t u; double d; } sb; sb.u = expf_tab((unsigned)(ki % 32u)) + (ki << (52 - 5));
+  const double zz = mad_(ExpfConsts::c0, r, ExpfConsts::c1);
+  const double r2 = r * r;
+  double y = mad_(ExpfConsts::c2, r, 1.0);
+  y = mad_(zz, r2, y);
+  y = y * sb.d;
+  return (float)y;
+}
+
 }  // namespace crx

@@ -9,10 +9,12 @@
 // Random numbers are inputs (the reference draws them from std::mt19937 inside these functions): nrm [T][n][NP][2]
 // standard normals for the motion noise (:87-88), uni [T][n][NP] uniforms in [1,2) for the resampling (:133, uni_d{1,2}).
 //
-// Parity is statistical / tolerance-based by construction: per-particle arithmetic follows the
-// reference statement by statement (double promotions included, cosf/sinf glibc-exact), but expf is OCML's and the
-// reductions are wave (DPP) reductions instead of Eigen's vectorised redux / gemv order, so sums differ in the last bits and
-// a resampling threshold can flip on a tie.
+// Parity.  Per-particle arithmetic follows the reference statement by statement (double promotions included; cosf / sinf /
+// expf are the glibc-exact restatements of crx_trig.h).  The sums over the particles are wave (DPP) reductions — a balanced
+// pairwise tree over the lanes — not Eigen's vectorised redux / gemv order, which nobody can restate without Eigen's binary
+// (statistical parity with the reference).  Against the CPU oracle evaluated in THIS summation order
+// (oracle/pf_ref.cpp: oracle_pf_step_wave) the kernel is bit-exact, resampling decisions and ancestors included; against the
+// oracle's index-order sums it agrees statistically (a resampling threshold can flip on a tie).
 //
 // Layout: px [n][NP][4] (Eigen::Matrix<float,4,NP> column-major = one float4 per particle), pw [n][NP], xEst [n][4],
 // PEst [n][16] column-major, obs [T][n][L][3] = (range, landmark x, landmark y), nobs [T][n], u [T][n][2].
@@ -121,7 +123,7 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
       const float dx = x.x - Z[3 * i + 1], dy = x.y - Z[3 * i + 2];
       const float prez = sqrtf(dx * dx + dy * dy);
       const float dz = prez - Z[3 * i];
-      const float pl = (float)(lik_c * (double)expf(-dz * dz / lik_d));        // gauss_likelihood :53-57
+      const float pl = (float)(lik_c * (double)expf_(-dz * dz / lik_d));       // gauss_likelihood :53-57 (glibc-exact expf, crx_trig.h)
       w = w * pl;
     }
   };

@@ -265,7 +265,8 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
  *   obs [T][n][L][3] = (noisy range, landmark x, landmark y) with nobs [T][n] <= L valid rows (:258-267),
  *   u [T][n][2], nrm [T][n][NP][2] standard normals (:87-88), uni [T][n][NP] uniforms in [1,2) (:133, uni_d{1.0,2.0} :242),
  *   x_hist [T][n][4] (may be NULL), n_resampled [n] (may be NULL; incremented by the number of resampling ticks).
- * Parity with the reference is statistical / tolerance-based: see pf_kernels.hip.h. */
+ * Parity: bit-exact against the CPU oracle evaluated with the engine's summation order, statistical against index-order sums
+ * (the reference's own order is Eigen's vectorised redux / gemv): see pf_kernels.hip.h. */
 typedef struct crx_pf_params {
   float rsim0, rsim1;   /* Rsim(0,0) = 1.0, Rsim(1,1) = (30 deg)^2 with PI 3.141592653   :229-230 */
   float Q;              /* 0.01   :219 */

@@ -333,9 +333,10 @@ def pf_simulate_inputs(u_true, xTrue, xDR, w_u, w_z, rfid=PF_RFID, rsim=PF_RSIM,
     return ud, obs, nobs, xth, xdh
 
 
-def pf_step(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None):
+def pf_step(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None, wave_order=False):
     """pf_localization + resampling, one tick.  px [n,NP,4], pw [n,NP], obs [n,L,3], nobs [n], u [n,2], nrm [n,NP,2], uni [n,NP].
-    Returns (px, pw, xEst [n,4], PEst [n,16], resampled [n], ancestors [n,NP])."""
+    Returns (px, pw, xEst [n,4], PEst [n,16], resampled [n], ancestors [n,NP]).  wave_order: the sums over the particles in the
+    engine's order (balanced tree over 64 lanes, lane scan, bisection) instead of index order; ancestors are then not reported."""
     px, pw = _f32(px).copy(), _f32(pw).copy()
     obs, u, nrm, uni = _f32(obs), _f32(u), _f32(nrm), _f32(uni)
     nobs = np.ascontiguousarray(nobs, dtype=np.int32)
@@ -344,12 +345,16 @@ def pf_step(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=No
     res = np.zeros(n, np.int32); anc = np.zeros((n, NP), np.int32)
     rs = _f32(rsim)
     a0, a1 = (0, n) if agents is None else agents
+    if wave_order:
+        _pf_lib().oracle_pf_step_wave(_I(n), _I(NP), _I(L), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm), _p(uni),
+                                      _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(res), _I(a0), _I(a1))
+        return px, pw, xEst, PEst, res, None
     _pf_lib().oracle_pf_step(_I(n), _I(NP), _I(L), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm), _p(uni),
                              _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(res), _p(anc), _I(a0), _I(a1))
     return px, pw, xEst, PEst, res, anc
 
 
-def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None):
+def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None, wave_order=False):
     """T ticks.  obs [T,n,L,3], nobs [T,n], u [T,n,2], nrm [T,n,NP,2], uni [T,n,NP].
     Returns (px, pw, xEst, PEst, x_hist [T,n,4], n_resampled [n])."""
     px, pw = _f32(px).copy(), _f32(pw).copy()
@@ -360,8 +365,9 @@ def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=Non
     xh = np.zeros((T, n, 4), np.float32); nres = np.zeros(n, np.int32)
     rs = _f32(rsim)
     a0, a1 = (0, n) if agents is None else agents
-    _pf_lib().oracle_pf_run(_I(n), _I(NP), _I(L), _I(T), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm),
-                            _p(uni), _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(xh), _p(nres), _I(a0), _I(a1))
+    f = _pf_lib().oracle_pf_run_wave if wave_order else _pf_lib().oracle_pf_run
+    f(_I(n), _I(NP), _I(L), _I(T), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm),
+      _p(uni), _p(rs), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(xh), _p(nres), _I(a0), _I(a1))
     return px, pw, xEst, PEst, xh, nres
 
 

@@ -8,9 +8,11 @@
 // every call replays the same stream); here all random numbers are caller-supplied arrays, so that CPU and GPU
 // consume identical draws:  nrm[t][a][ip][2] standard normals (motion noise, :87-88),  uni[t][a][j] uniforms in
 // [1,2) (uni_d{1.0, 2.0} :242, used as uni/NP :133).
-// PARITY-UNPINNED, and statistical by construction: the reference's reductions (pw.sum(), px*pw, pw'*pw) go through
-// Eigen's vectorised redux / gemv kernels whose accumulation order is not restated here — sums below run in plain
-// index order — so the engine is compared with a tolerance, not bit for bit.
+// PARITY-UNPINNED with respect to the reference's sums: its reductions (pw.sum(), px*pw, pw'*pw) go through Eigen's vectorised
+// redux / gemv kernels whose accumulation order is not restated here.  oracle_pf_step takes them in plain index order (the
+// engine is compared with it statistically); oracle_pf_step_wave takes them in the engine's order (balanced
+// tree over 64 lanes) and the engine is demanded equal to it bit for bit — everything else of a tick (motion model, likelihood,
+// normalisation, covariance terms, Neff test, low-variance resampling) is the reference's arithmetic in both.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -114,6 +116,124 @@ void oracle_pf_step(int n, int NP, int L, float* px, float* pw, float* xEst, flo
   }
 }
 
+// ---- the same tick with the sums taken in the ENGINE's order ------------------------------------------------------------------
+// The engine maps one vehicle to one 64-lane wavefront, particle ip on lane ip % 64 (two particles per lane above 64), and takes
+// every sum over the particles as a balanced pairwise tree over the lanes (pf_kernels.hip.h: wave_sum), the cumulative sum as a
+// lane scan (wave_scan_add), and finds each resampled ancestor by bisection of that cumulative sum followed by a running maximum.
+// oracle_pf_step_wave restates exactly that arithmetic on the host — per-particle maths as above, the reductions below — so that
+// the kernel can be demanded equal to it BIT FOR BIT; oracle_pf_step (index-order sums, the plain reading of the reference) is what
+// both are compared with statistically.  NP <= 128.
+namespace {
+float tree_sum64(const float* v) {                 // wave_sum: adjacent pairs, level by level
+  float t[64];
+  std::memcpy(t, v, sizeof(t));
+  for (int n = 64; n > 1; n >>= 1) for (int i = 0; i < n / 2; ++i) t[i] = t[2 * i] + t[2 * i + 1];
+  return t[0];
+}
+void scan_add64(float* v) {                        // wave_scan_add: shifts 1,2,4,8 inside each row of 16, then row totals
+  for (int s = 1; s <= 8; s <<= 1) {
+    float o[64];
+    std::memcpy(o, v, sizeof(o));
+    for (int i = 0; i < 64; ++i) v[i] = o[i] + ((i & 15) >= s ? o[i - s] : 0.0f);
+  }
+  { float o[64]; std::memcpy(o, v, sizeof(o));     // rows 1, 3 += lane 15 of the row before
+    for (int i = 0; i < 64; ++i) { const int row = i >> 4; v[i] = o[i] + ((row & 1) ? o[16 * row - 1] : 0.0f); } }
+  { float o[64]; std::memcpy(o, v, sizeof(o));     // rows 2, 3 += lane 31
+    for (int i = 0; i < 64; ++i) v[i] = o[i] + (i >= 32 ? o[31] : 0.0f); }
+}
+}  // namespace
+
+void oracle_pf_step_wave(int n, int NP, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs, const int* nobs,
+                         const float* u, const float* nrm, const float* uni, const float* rsim, float Q, double DT, float nth,
+                         int* resampled, int a0, int a1) {
+  if (NP < 1 || NP > 128) return;
+  const float inv = (float)(1.0 / NP);
+  std::vector<float> base(NP), wcum(NP);
+  { float c = inv; base[0] = c - inv; for (int i = 1; i < NP; ++i) { c = c + inv; base[i] = c - inv; } }
+  for (int a = a0; a < a1; ++a) {
+    float* X = px + (size_t)a * NP * 4;
+    float* W = pw + (size_t)a * NP;
+    const float* Z = obs + (size_t)a * L * 3;
+    const float sig = std::sqrt(Q);
+    const double lik_c = 1.0 / std::sqrt(2.0 * PI_ * sig * sig);
+    const float lik_d = 2 * sig * sig;
+    const int nob = nobs[a] < 0 ? 0 : (nobs[a] > L ? L : nobs[a]);
+    float x[2][64][4], w[2][64];
+    std::memset(x, 0, sizeof(x)); std::memset(w, 0, sizeof(w));
+    for (int ip = 0; ip < NP; ++ip) {
+      float* xp = x[ip >> 6][ip & 63];
+      std::memcpy(xp, X + 4 * ip, 16);
+      float wi = W[ip];
+      float ud[2];
+      ud[0] = u[2 * a] + (double)nrm[((size_t)a * NP + ip) * 2] * rsim[0];
+      ud[1] = u[2 * a + 1] + (double)nrm[((size_t)a * NP + ip) * 2 + 1] * rsim[1];
+      motion_model(xp, ud, DT);
+      for (int i = 0; i < nob; ++i) {
+        const float dx = xp[0] - Z[3 * i + 1], dy = xp[1] - Z[3 * i + 2];
+        const float prez = std::sqrt(dx * dx + dy * dy);
+        const float dz = prez - Z[3 * i];
+        const float pl = (float)(lik_c * (double)std::exp(-dz * dz / lik_d));
+        wi = wi * pl;
+      }
+      w[ip >> 6][ip & 63] = wi;
+    }
+    float t[64];
+    for (int l = 0; l < 64; ++l) t[l] = w[0][l] + w[1][l];
+    const float s = tree_sum64(t);
+    for (int l = 0; l < 64; ++l) { w[0][l] = w[0][l] / s; w[1][l] = w[1][l] / s; }
+    float xe[4];
+    for (int r = 0; r < 4; ++r) {
+      for (int l = 0; l < 64; ++l) t[l] = x[0][l][r] * w[0][l] + x[1][l][r] * w[1][l];
+      xe[r] = tree_sum64(t);
+    }
+    float Pe[16];
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r <= c; ++r) {
+        for (int l = 0; l < 64; ++l) {
+          const float d0r = x[0][l][r] - xe[r], d0c = x[0][l][c] - xe[c], d1r = x[1][l][r] - xe[r], d1c = x[1][l][c] - xe[c];
+          t[l] = (w[0][l] * d0r) * d0c + ((l + 64 < NP) ? (w[1][l] * d1r) * d1c : 0.0f);
+        }
+        Pe[r + 4 * c] = Pe[c + 4 * r] = tree_sum64(t);
+      }
+    std::memcpy(xEst + 4 * (size_t)a, xe, sizeof(xe));
+    std::memcpy(PEst + 16 * (size_t)a, Pe, sizeof(Pe));
+    for (int l = 0; l < 64; ++l) t[l] = w[0][l] * w[0][l] + w[1][l] * w[1][l];
+    const float ww = tree_sum64(t);
+    const float Neff = (float)(1.0 / (double)ww);
+    int did = 0;
+    if (Neff < nth) {
+      did = 1;
+      float c0[64], c1[64];
+      std::memcpy(c0, w[0], sizeof(c0)); std::memcpy(c1, w[1], sizeof(c1));
+      scan_add64(c0);
+      const float tot0 = c0[63];
+      scan_add64(c1);
+      for (int l = 0; l < 64; ++l) c1[l] = c1[l] + tot0;
+      for (int ip = 0; ip < NP; ++ip) wcum[ip] = ip < 64 ? c0[ip] : c1[ip - 64];
+      int idx[2][64];
+      std::memset(idx, 0, sizeof(idx));
+      for (int ip = 0; ip < NP; ++ip) {
+        const float rid = (float)((double)base[ip] + (double)uni[(size_t)a * NP + ip] / NP);
+        int lo = 0, hi = NP - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (rid > wcum[mid]) lo = mid + 1; else hi = mid; }
+        idx[ip >> 6][ip & 63] = lo;
+      }
+      for (int l = 1; l < 64; ++l) if (idx[0][l - 1] > idx[0][l]) idx[0][l] = idx[0][l - 1];      // running maximum, particle order
+      const int m0 = idx[0][63];
+      for (int l = 1; l < 64; ++l) if (idx[1][l - 1] > idx[1][l]) idx[1][l] = idx[1][l - 1];
+      for (int l = 0; l < 64; ++l) if (m0 > idx[1][l]) idx[1][l] = m0;
+      for (int ip = 0; ip < NP; ++ip) {
+        const int j = idx[ip >> 6][ip & 63];
+        std::memcpy(X + 4 * ip, x[j >> 6][j & 63], 16);
+        W[ip] = inv;
+      }
+    } else {
+      for (int ip = 0; ip < NP; ++ip) { std::memcpy(X + 4 * ip, x[ip >> 6][ip & 63], 16); W[ip] = w[ip >> 6][ip & 63]; }
+    }
+    if (resampled) resampled[a] = did;
+  }
+}
+
 // T ticks: u [T][n][2], obs [T][n][L][3], nobs [T][n], nrm [T][n][NP][2], uni [T][n][NP]; x_hist (may be NULL) [T][n][4].
 void oracle_pf_run(int n, int NP, int L, int T, float* px, float* pw, float* xEst, float* PEst, const float* obs,
                    const int* nobs, const float* u, const float* nrm, const float* uni, const float* rsim, float Q,
@@ -163,6 +283,21 @@ void oracle_pf_simulate_inputs(int n, int T, int L, const float* u_true, float* 
       if (xDR_hist) std::memcpy(xDR_hist + 4 * o, xd, 16);
     }
     std::memcpy(xTrue + 4 * (size_t)a, xt, 16); std::memcpy(xDR + 4 * (size_t)a, xd, 16);
+  }
+}
+
+// oracle_pf_run with the engine's summation order (oracle_pf_step_wave) in every tick.
+void oracle_pf_run_wave(int n, int NP, int L, int T, float* px, float* pw, float* xEst, float* PEst, const float* obs,
+                        const int* nobs, const float* u, const float* nrm, const float* uni, const float* rsim, float Q,
+                        double DT, float nth, float* x_hist, int* n_resampled, int a0, int a1) {
+  std::vector<int> did(n);
+  for (int t = 0; t < T; ++t) {
+    oracle_pf_step_wave(n, NP, L, px, pw, xEst, PEst, obs + (size_t)t * n * L * 3, nobs + (size_t)t * n, u + (size_t)t * n * 2,
+                        nrm + (size_t)t * n * NP * 2, uni + (size_t)t * n * NP, rsim, Q, DT, nth, did.data(), a0, a1);
+    for (int a = a0; a < a1; ++a) {
+      if (x_hist) std::memcpy(x_hist + ((size_t)t * n + a) * 4, xEst + 4 * (size_t)a, 16);
+      if (n_resampled) n_resampled[a] += did[a];
+    }
   }
 }
 

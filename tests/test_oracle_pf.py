@@ -62,3 +62,19 @@ def test_pf_step_matches_float64_numpy(oracle_mod):
             assert np.allclose(px2[a], xn[anc[a]].astype(np.float32), rtol=1e-5, atol=1e-5)
         else:
             assert np.allclose(px2[a], xn, rtol=1e-5, atol=1e-5) and np.allclose(pw2[a], w, rtol=1e-4, atol=1e-8)
+
+
+def test_wave_order_sums_agree_statistically_with_index_order(oracle_mod):
+    """The oracle in the engine's summation order (oracle_pf_step_wave: what the kernel is demanded equal to bit for bit) against
+    its index-order statement: same resampling rhythm, same estimation error, single ticks equal to float round-off."""
+    n, T, NP = 40, 120, 100
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle_mod, n, T, NP, 5)
+    px, pw = np.zeros((n, NP, 4), np.float32), np.full((n, NP), 1.0 / NP, np.float32)
+    a = oracle_mod.pf_run(px, pw, obs, nobs, ut, nrm, uni)
+    b = oracle_mod.pf_run(px, pw, obs, nobs, ut, nrm, uni, wave_order=True)
+    err = lambda h: np.hypot(h[..., 0] - xth[..., 0], h[..., 1] - xth[..., 1]).mean()
+    assert abs(err(a[4]) - err(b[4])) < 5e-3 and err(b[4]) < 0.1
+    assert np.abs(a[5].astype(int) - b[5]).max() <= 0.05 * T
+    s1 = oracle_mod.pf_step(px, pw, obs[0], nobs[0], ut[0], nrm[0], uni[0])
+    s2 = oracle_mod.pf_step(px, pw, obs[0], nobs[0], ut[0], nrm[0], uni[0], wave_order=True)
+    assert np.allclose(s1[2], s2[2], rtol=1e-5, atol=1e-5) and np.allclose(s1[3], s2[3], rtol=1e-3, atol=1e-6)

@@ -1,6 +1,9 @@
-"""GPU parity of the particle filter (one vehicle per wavefront) against the CPU oracle.  Statistical by construction
-(pf_kernels.hip.h): single ticks agree to float round-off; over long runs a resampling tie can flip, so episodes are
-compared through their estimation error and resampling counts."""
+"""GPU parity of the particle filter (one vehicle per wavefront) against the CPU oracle.
+
+Bit for bit against the oracle evaluated in the engine's summation order (balanced tree over the lanes: oracle_pf_step_wave) —
+whole episodes, resampling included.  Statistically against the oracle's index-order sums (the plain reading of the reference,
+whose own order is Eigen's vectorised redux / gemv): single ticks agree to float round-off; over long runs a resampling tie can
+flip, so episodes are compared through their estimation error and resampling counts."""
 import numpy as np
 import pytest
 
@@ -12,6 +15,39 @@ pytestmark = pytest.mark.gpu
 def _t(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("NP", [100, 64, 128])
+def test_pf_episode_bit_exact_in_the_engines_summation_order(crx, oracle_mod, NP):
+    """150 ticks, 150 vehicles: every estimate of every tick, the final particles, weights, covariance and the number of resampling
+    ticks equal to the wave-order oracle bit for bit (ticks in which nobody sees a landmark included)."""
+    n, T = 150, 150
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle_mod, n, T, NP, 31 + NP)
+    nobs = nobs.copy(); nobs[7] = 0; nobs[40, ::3] = 0
+    px, pw = np.zeros((n, NP, 4), np.float32), np.full((n, NP), 1.0 / NP, np.float32)
+    pxo, pwo, xeo, Peo, xho, nro = oracle_mod.pf_run(px, pw, obs, nobs, ut, nrm, uni, wave_order=True)
+    pxd, pwd = _t(px), _t(pw)
+    xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs), _t(nobs), _t(ut), _t(nrm), _t(uni))
+    assert np.array_equal(hist.cpu().numpy(), xho) and np.array_equal(xe.cpu().numpy(), xeo) and np.array_equal(Pe.cpu().numpy(), Peo)
+    assert np.array_equal(pxd.cpu().numpy(), pxo) and np.array_equal(pwd.cpu().numpy(), pwo)
+    assert np.array_equal(nres.cpu().numpy(), nro) and nro.min() > 10          # the resampling branch is exercised
+    err = np.hypot(xho[..., 0] - xth[..., 0], xho[..., 1] - xth[..., 1])
+    assert err.mean() < 0.1
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 130])
+def test_pf_single_tick_bit_exact_in_the_engines_summation_order(crx, oracle_mod, n):
+    NP = 100
+    rng = np.random.default_rng(n)
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle_mod, n, 30, NP, 10 + n)
+    pw = rng.uniform(0.5, 1.5, (n, NP)).astype(np.float32); pw /= pw.sum(axis=1, keepdims=True)
+    for t in (1, 7, 20):
+        px = (xth[t - 1][:, None, :] + rng.normal(0, 0.05, (n, NP, 4))).astype(np.float32)
+        pxo, pwo, xeo, Peo, reso, _ = oracle_mod.pf_step(px, pw, obs[t], nobs[t], ut[t], nrm[t], uni[t], wave_order=True)
+        pxd, pwd = _t(px), _t(pw)
+        xe, Pe, hist, nres = crx.pf_run(pxd, pwd, _t(obs[t:t + 1]), _t(nobs[t:t + 1]), _t(ut[t:t + 1]), _t(nrm[t:t + 1]), _t(uni[t:t + 1]))
+        assert np.array_equal(xe.cpu().numpy(), xeo) and np.array_equal(Pe.cpu().numpy(), Peo) and np.array_equal(nres.cpu().numpy(), reso)
+        assert np.array_equal(pxd.cpu().numpy(), pxo) and np.array_equal(pwd.cpu().numpy(), pwo)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 130])

@@ -39,3 +39,19 @@ def test_discriminating_inputs(oracle_mod):
     a = oracle_mod.motion_model(xs, u, trig=1)
     if oracle_mod.libm_is_fma_flavour():
         assert np.array_equal(a, oracle_mod.motion_model(xs, u, trig=0))
+
+
+@pytest.fixture(scope="module")
+def expf_tool(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("expf") / "expf_ex")
+    subprocess.check_call(["g++", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp", "-I", os.path.join(ROOT, "cpprobotics_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "tools", "expf_exhaustive.cpp"), "-o", out, "-lm"])
+    return out
+
+
+def test_expf_matches_glibc_on_every_float(expf_tool, oracle_mod):
+    """crx::expf_ (the particle filter's gauss_likelihood) against the host libm on ALL 2^32 float bit patterns — a few seconds."""
+    if not oracle_mod.libm_is_fma_flavour():
+        pytest.skip("host libm is not glibc's FMA flavour")
+    r = subprocess.run([expf_tool, "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 mismatches" in r.stdout, r.stdout

@@ -13,7 +13,7 @@
 // expf are the glibc-exact restatements of crx_trig.h).  The sums over the particles are wave (DPP) reductions — a balanced
 // pairwise tree over the lanes — not Eigen's vectorised redux / gemv order, which nobody can restate without Eigen's binary
 // (statistical parity with the reference).  Against the CPU oracle evaluated in THIS summation order
-// (oracle/pf_ref.cpp: oracle_pf_step_wave) the kernel is bit-exact, resampling decisions and ancestors included; against the
+// (its oracle_pf_step_wave) the kernel is bit-exact, resampling decisions and ancestors included; against the
 // oracle's index-order sums it agrees statistically (a resampling threshold can flip on a tie).
 //
 // Layout: px [n][NP][4] (Eigen::Matrix<float,4,NP> column-major = one float4 per particle), pw [n][NP], xEst [n][4],

@@ -233,7 +233,7 @@ struct ExpfConsts {
   static constexpr double inv_ln2_n = 0x1.71547652b82fep+0 * N, shift = 0x1.8p+52;
   static constexpr double c0 = 0x1.c6af84b912394p-5 / N / N / N, c1 = 0x1.ebfce50fac4f3p-3 / N / N, c2 = 0x1.62e42ff0c52d6p-1 / N;
 };
-CRX_HD uint64_t expf_tab(unsigned i) {     // bits of 2^(i/32) minus i << 47, i = 0..31
+CRX_HD uint64_t expf_tab(unsigned i) {     // bits of 2^(i/32) minus i << 47, i = 0..31 (a kernel may stage the 32 words in LDS)
   constexpr uint64_t T[32] = {
     0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
     0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
@@ -245,7 +245,8 @@ CRX_HD uint64_t expf_tab(unsigned i) {     // bits of 2^(i/32) minus i << 47, i 
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
   return T[i];
 }
-CRX_HD float expf_(float x) {
+// tab: the 32 words of expf_tab in memory of the caller's choice (nullptr = the constant table)
+CRX_HD float expf_(float x, const uint64_t* tab = nullptr) {
   const uint32_t at = abstop12(x);
   if (at >= 0x42bu) {                                        // |x| >= 88 or NaN
     if (f32_bits(x) == 0xff800000u) return 0.0f;             // exp(-inf)
@@ -264,7 +265,7 @@ CRX_HD float expf_(float x) {
 #else
   const double r = z - kd;
 #endif
-  union { uint64_t u; double d; } sb; sb.u = expf_tab((unsigned)(ki % 32u)) + (ki << (52 - 5));
+  union { uint64_t u; double d; } sb; sb.u = (tab ? tab[ki % 32u] : expf_tab((unsigned)(ki % 32u))) + (ki << (52 - 5));
   const double zz = mad_(ExpfConsts::c0, r, ExpfConsts::c1);
   const double r2 = r * r;
   double y = mad_(ExpfConsts::c2, r, 1.0);

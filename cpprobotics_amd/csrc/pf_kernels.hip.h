@@ -88,9 +88,11 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
   __shared__ float4 s_x[kPfWavesPerBlock][NP];
   __shared__ float s_wc[kPfWavesPerBlock][NP];
   __shared__ float s_base[NP];
+  __shared__ uint64_t s_exp[32];                                   // expf_'s table of 2^(i/32): LDS reads instead of constant-memory loads
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t a = (size_t)blockIdx.x * kPfWavesPerBlock + wv;
   const float inv = (float)(1.0 / NP);
+  if (threadIdx.x < 32) s_exp[threadIdx.x] = expf_tab(threadIdx.x);
   if (threadIdx.x == 0) {            // base = cumsum(pw*0.0 + Ones*1.0/NP) - Ones*1.0/NP  (:129), input-independent
     float c = inv;
     s_base[0] = c - inv;
@@ -123,7 +125,7 @@ pf_run_kernel(int n, int T, int L, float* __restrict__ px, float* __restrict__ p
       const float dx = x.x - Z[3 * i + 1], dy = x.y - Z[3 * i + 2];
       const float prez = sqrtf(dx * dx + dy * dy);
       const float dz = prez - Z[3 * i];
-      const float pl = (float)(lik_c * (double)expf_(-dz * dz / lik_d));       // gauss_likelihood :53-57 (glibc-exact expf, crx_trig.h)
+      const float pl = (float)(lik_c * (double)expf_(-dz * dz / lik_d, s_exp));       // gauss_likelihood :53-57 (glibc-exact expf, crx_trig.h)
       w = w * pl;
     }
   };

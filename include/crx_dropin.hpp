@@ -187,6 +187,11 @@ inline Vec_f lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, V
   crx::dropin_check(crx_lqr_steering_control_batch(1, 5, s, &c, nullptr, &pe, &pth_e, nullptr, u), "lqr_steering_control");
   return {u[0], u[1]};
 }
+inline Vec_f calc_speed_profile(Vec_f rx, Vec_f ry, Vec_f ryaw, float target_speed) {                            // :40
+  Vec_f sp(ryaw.size());
+  crx::dropin_check(crx_calc_speed_profile(5, rx.data(), ry.data(), ryaw.data(), (int)ryaw.size(), target_speed, sp.data()), "calc_speed_profile");
+  return sp;
+}
 inline void update(State& state, float a, float delta) {                                                     // :154
   float s[4] = {state.x, state.y, state.yaw, state.v};
   crx::dropin_check(crx_update_batch(1, s, &a, &delta, nullptr), "update");
@@ -197,6 +202,11 @@ inline void update(State& state, float a, float delta) {                        
 namespace lqr_steer {         // src/lqr_steer_control.cpp
 using lqr_speed_steer::calc_nearest_index;   // :55-73, the same text
 using lqr_speed_steer::update;               // :136-146, the same text
+inline Vec_f calc_speed_profile(Vec_f rx, Vec_f ry, Vec_f ryaw, float target_speed) {                            // :35
+  Vec_f sp(ryaw.size());
+  crx::dropin_check(crx_calc_speed_profile(4, rx.data(), ry.data(), ryaw.data(), (int)ryaw.size(), target_speed, sp.data()), "calc_speed_profile");
+  return sp;
+}
 inline float lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, int& ind, float& pe, float& pth_e) {   // :98
   const Vec_f sp(cx.size(), 0.0f);           // the 4-state controller does not read the speed profile
   const crx_course c = course_of(cx, cy, cyaw, &ck, &sp);
@@ -208,6 +218,14 @@ inline float lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, V
 }  // namespace lqr_steer
 
 namespace mpc {               // src/model_predictive_control.cpp
+inline Vec_f calc_speed_profile(Vec_f rx, Vec_f ry, Vec_f ryaw, float target_speed) {                            // :83
+  Vec_f sp(ryaw.size());
+  crx::dropin_check(crx_calc_speed_profile(0, rx.data(), ry.data(), ryaw.data(), (int)ryaw.size(), target_speed, sp.data()), "calc_speed_profile");
+  return sp;
+}
+inline void smooth_yaw(Vec_f& cyaw) {                                                                            // :172
+  crx::dropin_check(crx_smooth_yaw(cyaw.data(), (int)cyaw.size()), "smooth_yaw");
+}
 inline void update(State& state, float a, float delta) {                                                     // :69
   crx_vehicle_params p;
   crx_vehicle_default_params(&p, 1);

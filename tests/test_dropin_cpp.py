@@ -27,6 +27,20 @@ def test_dropin_compiles_and_fails_loudly_without_gpu(demo):
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
+def test_dropin_course_setup_functions_on_the_host(tmp_path, crx):
+    """calc_speed_profile (three files) and smooth_yaw through the drop-in header: host code, runs without a GPU; equal to the
+    Python mirror of the same C entry points (which tests/test_oracle_vs_ref.py pins to the reference's own lines)."""
+    exe = str(tmp_path / "dropin_course")
+    libdir = os.path.join(ROOT, "cpprobotics_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "dropin_course.cpp"),
+                           "-o", exe, "-L", libdir, "-lcrx", f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
+    r = subprocess.run([exe], capture_output=True, text=True, check=True)
+    v = {k: a[0] for k, a in _parse(r.stdout).items()}
+    for which, key in ((5, "sp5"), (4, "sp4"), (0, "sp0")):
+        assert np.array_equal(v[key], crx.calc_speed_profile(which, v["x"], v["y"], v["yaw_in"], 2.7777777))
+    assert np.array_equal(v["yaw_out"], crx.smooth_yaw(v["yaw_in"])) and not np.array_equal(v["yaw_out"], v["yaw_in"])
+
+
 def _parse(out):
     res = {}
     for line in out.strip().splitlines():

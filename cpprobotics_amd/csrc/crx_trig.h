@@ -265,7 +265,10 @@ CRX_HD float expf_(float x, const uint64_t* tab = nullptr) {
 #else
   const double r = z - kd;
 #endif
-  union { uint64_t u; double d; } sb; sb.u = (tab ? tab[ki % 32u] : expf_tab((unsigned)(ki % 32u))) + (ki << (52 - 5));
+  // 2^(k/N): table word + (k << 47).  k << 47 only touches the high 32-bit word, and only k's low 17 bits reach it: 32-bit arithmetic
+  const uint32_t klo = (uint32_t)ki;
+  const uint64_t tw = tab ? tab[klo & 31u] : expf_tab(klo & 31u);
+  union { uint64_t u; double d; } sb; sb.u = ((uint64_t)((uint32_t)(tw >> 32) + (klo << 15)) << 32) | (uint32_t)tw;
   const double zz = mad_(ExpfConsts::c0, r, ExpfConsts::c1);
   const double r2 = r * r;
   double y = mad_(ExpfConsts::c2, r, 1.0);

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/crx.h"
+#include "../../include/crx_experimental.h"
 #include "dare_kernels.hip.h"
 #include "ekf_kernels.hip.h"
 #include "ekf_wave2_kernels.hip.h"
@@ -48,6 +49,9 @@ int check_device() {
 }
 
 inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
+constexpr int kDareQuadMaxAgents = 65536;
 
 // Threads per workgroup of the iterative kernels (DARE, MPC, tracking): full 64-lane waves.  Narrower waves
 // (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized
@@ -386,22 +390,45 @@ int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const flo
   return CRX_OK;
 }
 
-int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
-                              int* iters, void* stream) {
+// lanes_per_agent: 1 = dare_from_v_kernel, 4 = dare_from_v_quad_kernel, 0 = chosen by batch size.
+static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                              int* iters, void* stream, int lanes_per_agent) {
   if (n < 0 || (dim != 4 && dim != 5) || (n && !v))
     return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
+  if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
+    return fail(CRX_ERR_INVALID, "dare_from_v: lanes_per_agent must be 0 (auto), 1 or 4");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
-  const unsigned bs = iter_block();
-  const dim3 grid(blocks_for(n, bs)), block(bs);
-  if (dim == 5)
-    hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
-  else
-    hipLaunchKernelGGL((crx::dare_from_v_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+  // Four lanes per agent shorten the launch while the batch leaves SIMDs without a wave of their own; in the throughput
+  // regime the one-lane kernel executes fewer instructions per agent (profiles/r03/dare_lanes_ab.txt).
+  if (lanes_per_agent == 0) lanes_per_agent = (n <= kDareQuadMaxAgents) ? 4 : 1;
+  if (lanes_per_agent == 4) {
+    const dim3 grid(blocks_for(4 * (size_t)n, 256)), block(256);
+    if (dim == 5)
+      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+    else
+      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+  } else {
+    const dim3 grid(blocks_for(n, 64)), block(64);
+    if (dim == 5)
+      hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+    else
+      hipLaunchKernelGGL((crx::dare_from_v_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+  }
   CRX_HIP(hipGetLastError());
   return CRX_OK;
+}
+
+int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                              int* iters, void* stream) {
+  return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, 0);
+}
+
+int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                                int* iters, void* stream, int lanes_per_agent) {
+  return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, lanes_per_agent);
 }
 
 int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* Q, const float* R, float eps,

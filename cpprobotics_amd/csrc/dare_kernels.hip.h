@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include "dare_math.h"
 
 namespace crx {
 
@@ -267,133 +268,51 @@ __device__ __forceinline__ void dlqr4_v_gain(float dt, float v, float bv, const 
   K[3] = inv * (b2 * dt);
 }
 
-// ---------- structured iterations on packed rows -----------------------------------------------------------------------
-// A'X, (A'X)B, its product with the 2x2 inverse, with B', with X and with A — written for the literal 0/1 structure of A and B
-// (at most two non-zero terms per sum, so every coefficient equals the dense Eigen-order evaluation bit for bit:
-// tests/test_lqr_gpu.py::test_dare_dense_matches_structured_and_oracle) and laid out so that two neighbouring columns of a
-// row share one packed fp32 instruction: X is held as rows of column pairs (0,1), (2,3) (+ column 4).  v_pk_mul_f32 /
-// v_pk_add_f32 are two independent IEEE operations — the bits are those of the scalar form; the instruction count is not
-// (the compiler's own pairing of a scalar formulation spent a fifth of the loop on register moves: -7 % / -9 % VALU).
+// ---------- structured iterations ------------------------------------------------------------------------------------------
+// dare_math.h: the iteration for A, B built from v, Q = I, R = I with the literal 0/1 structure of A and B skipped and, for the
+// 5x5 problem, its block-diagonal iterate X = diag(X4, x44) (at most two non-zero terms per sum, so every coefficient equals
+// the dense Eigen-order evaluation bit for bit: tests/test_lqr_gpu.py::test_dare_dense_matches_structured_and_oracle,
+// tests/test_dare_host.py), in two layouts: one lane per agent on packed rows, and four lanes per agent (a DPP quad).
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f bc2(float x) { return (v2f){x, x}; }
-__device__ __forceinline__ float max_abs2(float m, v2f d) { return fmaxf(fmaxf(m, fabsf(d.x)), fabsf(d.y)); }
 
-struct Row5 { v2f a, b; float c; };   // columns (0,1), (2,3), 4 of one row
-struct Row4 { v2f a, b; };            // columns (0,1), (2,3)
-
-__device__ __forceinline__ void dare5_v_iter_pk(float dt, float v, float bv, float bd, const Row5* X, Row5* Xn) {
-  Row5 R[5];                                                   // A'X, row by row
-  R[0] = X[0];
-  R[1].a = bc2(dt) * X[0].a; R[1].b = bc2(dt) * X[0].b; R[1].c = dt * X[0].c;
-  R[2].a = bc2(v) * X[1].a + X[2].a; R[2].b = bc2(v) * X[1].b + X[2].b; R[2].c = v * X[1].c + X[2].c;
-  R[3].a = bc2(dt) * X[2].a; R[3].b = bc2(dt) * X[2].b; R[3].c = dt * X[2].c;
-  R[4] = X[4];
-  const float G00 = (bv * X[3].b.y) * bv, G10 = (bd * X[4].b.y) * bv;
-  const float G01 = (bv * X[3].c) * bd, G11 = (bd * X[4].c) * bd;
-  float Sg[4] = {1.0f + G00, 0.0f + G10, 0.0f + G01, 1.0f + G11}, Si[4];
-  inverse2(Sg, Si);
-  const v2f si02 = {Si[0], Si[2]}, si13 = {Si[1], Si[3]}, bvd = {bv, bd};
-  const v2f vdt = {v, dt}, one_dt = {1.0f, dt};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const float c10 = R[i].b.y * bv, c11 = R[i].c * bd;        // ((A'X)B) row i
-    const v2f c2 = bc2(c10) * si02 + bc2(c11) * si13;           // * Si
-    const v2f c3 = c2 * bvd;                                   // the two non-zero columns (3, 4) of (..)*B'
-    Row5 C;                                                    // row i of (..)*X
-    C.a = bc2(c3.x) * X[3].a + bc2(c3.y) * X[4].a;
-    C.b = bc2(c3.x) * X[3].b + bc2(c3.y) * X[4].b;
-    C.c = c3.x * X[3].c + c3.y * X[4].c;
-    // (M*A) columns: 0 = M.0, 1 = M.0*dt, 2 = M.1*v + M.2, 3 = M.2*dt, 4 = M.4.   x*1.0f = x and x + (-0.0f) = x bit for bit
-    const v2f p1a = bc2(R[i].a.x) * one_dt, p2a = bc2(C.a.x) * one_dt;
-    const v2f p1b = (v2f){R[i].a.y, R[i].b.x} * vdt + (v2f){R[i].b.x, -0.0f};
-    const v2f p2b = (v2f){C.a.y, C.b.x} * vdt + (v2f){C.b.x, -0.0f};
-    Xn[i].a = (p1a - p2a) + (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
-    Xn[i].b = (p1b - p2b) + (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
-    Xn[i].c = (R[i].c - C.c) + (i == 4 ? 1.0f : 0.0f);
-  }
-}
-
-__device__ __forceinline__ void dare4_v_iter_pk(float dt, float v, float bv, const Row4* X, Row4* Xn) {
-  Row4 R[4];
-  R[0] = X[0];
-  R[1].a = bc2(dt) * X[0].a; R[1].b = bc2(dt) * X[0].b;
-  R[2].a = X[2].a + bc2(v) * X[1].a; R[2].b = X[2].b + bc2(v) * X[1].b;
-  R[3].a = bc2(dt) * X[2].a; R[3].b = bc2(dt) * X[2].b;
-  const float g = (bv * X[3].b.y) * bv;
-  const float s = 1.0f + g;
-  const v2f vdt = {v, dt}, one_dt = {1.0f, dt};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float c2 = (R[i].b.y * bv) / s;
-    const float c33 = c2 * bv;
-    Row4 C;
-    C.a = bc2(c33) * X[3].a; C.b = bc2(c33) * X[3].b;
-    const v2f p1a = bc2(R[i].a.x) * one_dt, p2a = bc2(C.a.x) * one_dt;
-    const v2f p1b = (v2f){R[i].a.y, R[i].b.x} * vdt + (v2f){R[i].b.x, -0.0f};
-    const v2f p2b = (v2f){C.a.y, C.b.x} * vdt + (v2f){C.b.x, -0.0f};
-    Xn[i].a = (p1a - p2a) + (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
-    Xn[i].b = (p1b - p2b) + (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
-  }
-}
-
-// max |Y - X| with the scan semantics of max_abs_diff: element (0,0) first, NaN there sticks.
-__device__ __forceinline__ float max_abs_diff_rows(const Row5* Y, const Row5* X) {
-  const v2f d0 = Y[0].a - X[0].a;
-  const float m0 = fabsf(d0.x);
-  float m = fmaxf(m0, fabsf(d0.y));
-  m = max_abs2(m, Y[0].b - X[0].b); m = fmaxf(m, fabsf(Y[0].c - X[0].c));
-#pragma unroll
-  for (int i = 1; i < 5; ++i) { m = max_abs2(m, Y[i].a - X[i].a); m = max_abs2(m, Y[i].b - X[i].b); m = fmaxf(m, fabsf(Y[i].c - X[i].c)); }
-  return (m0 != m0) ? m0 : m;
-}
-__device__ __forceinline__ float max_abs_diff_rows(const Row4* Y, const Row4* X) {
-  const v2f d0 = Y[0].a - X[0].a;
-  const float m0 = fabsf(d0.x);
-  float m = fmaxf(m0, fabsf(d0.y));
-  m = max_abs2(m, Y[0].b - X[0].b);
-#pragma unroll
-  for (int i = 1; i < 4; ++i) { m = max_abs2(m, Y[i].a - X[i].a); m = max_abs2(m, Y[i].b - X[i].b); }
-  return (m0 != m0) ? m0 : m;
-}
-
-// The reference's loop (see riccati_fixed_point) for A, B built from v, Q = I, R = I, on packed rows.  Xcm receives the
-// result column-major like every other X of this file; returns the number of evaluations.
+// The reference's loop (see riccati_fixed_point) for A, B built from v, Q = I, R = I, one agent per lane on packed rows.  Xcm
+// receives the result column-major like every other X of this file; returns the number of evaluations.
 template <int DIM>
 __device__ __forceinline__ int riccati_from_v(float dt, float v, float bv, float bd, float eps, int maxiter, bool live, float* Xcm) {
-  using Row = typename std::conditional<DIM == 5, Row5, Row4>::type;
-  Row X[DIM], Y[DIM];
+  Row4 X[4], Y[4];
+  float x44 = 1.0f, y44 = 1.0f;
 #pragma unroll
-  for (int i = 0; i < DIM; ++i) {
+  for (int i = 0; i < 4; ++i) {
     X[i].a = (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
     X[i].b = (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
-    if constexpr (DIM == 5) X[i].c = (i == 4) ? 1.0f : 0.0f;
   }
-  auto iter = [&](const Row* Xi, Row* Xo) {
-    if constexpr (DIM == 5) dare5_v_iter_pk(dt, v, bv, bd, Xi, Xo);
-    else dare4_v_iter_pk(dt, v, bv, Xi, Xo);
+  auto iter = [&](const Row4* Xi, const float& xi44, Row4* Xo, float& xo44) -> float {
+    if constexpr (DIM == 5) { dare5_v_iter_pk(dt, v, bv, bd, Xi, xi44, Xo, xo44); return dare_max_abs_diff(Xo, xo44, Xi, xi44); }
+    else { dare4_v_iter_pk(dt, v, bv, Xi, Xo); return dare_max_abs_diff(Xo, Xi); }
   };
   bool done = !live || maxiter <= 0;
   bool in_y = false;
   int it = maxiter < 0 ? 0 : maxiter;
   for (int i = 0; i < maxiter; i += 2) {
     if (!done) {
-      iter(X, Y);
+      const float m = iter(X, x44, Y, y44);
       in_y = true;
-      if (max_abs_diff_rows(Y, X) < eps) { done = true; it = i + 1; }
+      if (m < eps) { done = true; it = i + 1; }
     }
     if (!done && i + 1 < maxiter) {
-      iter(Y, X);
+      const float m = iter(Y, y44, X, x44);
       in_y = false;
-      if (max_abs_diff_rows(X, Y) < eps) { done = true; it = i + 2; }
+      if (m < eps) { done = true; it = i + 2; }
     }
     if (__all(done)) break;
   }
 #pragma unroll
-  for (int i = 0; i < DIM; ++i) {
-    const Row& r = in_y ? Y[i] : X[i];
+  for (int i = 0; i < 4; ++i) {
+    const Row4& r = in_y ? Y[i] : X[i];
     Xcm[i + DIM * 0] = r.a.x; Xcm[i + DIM * 1] = r.a.y; Xcm[i + DIM * 2] = r.b.x; Xcm[i + DIM * 3] = r.b.y;
-    if constexpr (DIM == 5) Xcm[i + DIM * 4] = r.c;
+    if constexpr (DIM == 5) { Xcm[i + DIM * 4] = 0.0f; Xcm[4 + DIM * i] = 0.0f; }
   }
+  if constexpr (DIM == 5) Xcm[24] = in_y ? y44 : x44;
   return it;
 }
 
@@ -422,6 +341,82 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
     for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
   }
   if (iters) iters[a] = it;
+}
+
+// ---------- four lanes per agent ---------------------------------------------------------------------------------------------
+// BASELINE-sized batches (configs[2]: 16,384 agents) are 256 waves of the kernel above on 1,024 SIMDs, and the launch lasts as
+// long as one wave needs for the 150 evaluations of an agent at the iteration cap: a latency chain on a quarter of the chip.
+// Here an agent is a DPP quad — lane r holds row r of the 4x4 block of X, x44 is replicated — so an evaluation is ~1/3 of the
+// instructions (one row per lane; the source row of A'X and row 3 of X arrive as quad_perm operands of the multiplies; the
+// convergence test is two DPP max steps) and the same batch fills every SIMD.  Same arithmetic per coefficient, same bits.
+// Converged quads are masked off like converged lanes above; all four lanes of a quad take the same decisions.
+template <int DIM>
+__global__ void __launch_bounds__(256)
+dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
+                        float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
+  constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t a = t >> 2;
+  const int r = (int)(threadIdx.x & 3);
+  const bool live = a < (size_t)n;
+  const float v = live ? vg[a] : 1.0f;
+  QuadLane<float, uint32_t> c;
+  c.dt = dt; c.v = v; c.bd = dt;
+  c.bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
+  c.a = (r == 0) ? 1.0f : ((r == 2) ? v : dt);
+  c.m2 = (r == 2) ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.q[j] = (r == j) ? 1.0f : 0.0f;
+  float X[4], Y[4], x44 = 1.0f, y44 = 1.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) X[j] = c.q[j];
+  auto iter = [&](const float* Xi, const float& xi44, float* Xo, float& xo44) -> float {
+    if constexpr (DIM == 5) return dare5_quad_iter(c, Xi, xi44, Xo, xo44);
+    else return dare4_quad_iter(c, Xi, Xo);
+  };
+  bool done = !live || maxiter <= 0;
+  bool in_y = false;
+  int it = maxiter < 0 ? 0 : maxiter;
+  for (int i = 0; i < maxiter; i += 2) {
+    if (!done) {
+      const float m = iter(X, x44, Y, y44);
+      in_y = true;
+      if (m < eps) { done = true; it = i + 1; }
+    }
+    if (!done && i + 1 < maxiter) {
+      const float m = iter(Y, y44, X, x44);
+      in_y = false;
+      if (m < eps) { done = true; it = i + 2; }
+    }
+    if (__all(done)) break;
+  }
+  if (!live) return;
+  float row[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) row[j] = in_y ? Y[j] : X[j];
+  const float xf44 = in_y ? y44 : x44;
+  if (Xg) {
+    float* Xa = Xg + a * NN;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Xa[r + DIM * j] = row[j];
+    if constexpr (DIM == 5) {
+      Xa[r + DIM * 4] = 0.0f; Xa[4 + DIM * r] = 0.0f;
+      if (r == 3) Xa[24] = xf44;
+    }
+  }
+  if (Kg && r == 3) {       // the gain needs rows 3 (this lane's) and 4 of X only
+    float Xf[NN], K[M * DIM];
+#pragma unroll
+    for (int j = 0; j < NN; ++j) Xf[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Xf[3 + DIM * j] = row[j];
+    if constexpr (DIM == 5) { Xf[24] = xf44; dlqr5_v_gain(dt, v, c.bv, dt, Xf, K); }
+    else dlqr4_v_gain(dt, v, c.bv, Xf, K);
+#pragma unroll
+    for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
+  }
+  if (iters && r == 0) iters[a] = it;
 }
 
 }  // namespace crx

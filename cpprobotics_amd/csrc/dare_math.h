@@ -1,0 +1,228 @@
+// dare_math.h — the Riccati iteration of the crx engine for A, B built from the speed (gfx950 device code; also compiles as
+// plain host C++ so tests/tools/dare_host.cpp can check both forms below against the oracle on the CPU).
+//
+// Replaces the body of solve_DARE's loop
+//   5x5, 2 inputs: /root/reference/src/lqr_speed_steer_control.cpp:85-100 with A, B of :116-126, Q = I5, R = I2 (:128-129)
+//   4x4, 1 input : /root/reference/src/lqr_steer_control.cpp:75-90        with A, B of :104-112, Q = I4, R = 1  (:114-115)
+// for ONE agent, in two register layouts:
+//   * `*_v_iter_pk`  — the whole agent in one lane, rows of X as packed column pairs (v_pk_mul_f32 / v_pk_add_f32);
+//   * `*_quad_iter`  — the agent spread over the four lanes of a DPP quad, lane r holding row r of the 4x4 block; the rows a
+//                      lane needs from its neighbours arrive as DPP quad_perm operands of the multiplies themselves.
+//
+// Structure used (every step below is exact in IEEE arithmetic, so the coefficients equal the reference's dense Eigen
+// evaluation bit for bit as long as the iterates are finite; tests: tests/test_dare_host.py, tests/test_lqr_gpu.py):
+//   1. literal 0 / 1 entries of A and B are skipped (x*1 = x, x*0 = +-0, s + (+-0) = s for s != 0);
+//   2. 5x5 only: A = diag(A4, 1) and B = [b e3, dt e4] never couple state 4 (the speed error) with states 0-3, so with
+//      X0 = Q = I every iterate is block diagonal, X = diag(X4, x44), its off-block entries exact zeros: all of them come
+//      out of the closing `+ Q` as +0, and every product they enter is a zero that is added to a non-zero or to another
+//      zero.  The 2x2 matrix R + B'XB is then diagonal, det = m0*m3 - 0*0 = m0*m3 and its inverse diag(m3/det, m0/det)
+//      with the reference's own rounding (one division 1/det, two multiplies).  The two blocks stay coupled through that
+//      shared rounding, which is why the 4x4 block cannot simply reuse the one-input iteration.
+//   A zero of the reference's evaluation can come out as a zero of the other sign in an intermediate; it can never reach a
+//   returned value with its sign (the iterate is normalised by `+ Q`, the gains by their own sums), and the parity bar
+//   compares IEEE values.  Once an iterate overflows, skipped 0*inf products make the non-finite patterns differ (as for
+//   rule 1 already): an agent whose reference run turns non-finite is non-finite here too, not necessarily entry by entry.
+#pragma once
+#include <stdint.h>
+#include "crx_trig.h"   // CRX_HD
+
+namespace crx {
+
+#if defined(__clang__)
+typedef float d_v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float d_v2f __attribute__((vector_size(8)));
+#endif
+
+CRX_HD d_v2f dbc2(float x) { return d_v2f{x, x}; }
+
+struct Row4 { d_v2f a, b; };            // columns (0,1), (2,3) of one row
+
+// ---------- one lane per agent ----------------------------------------------------------------------------------------------
+// A'X for A = [1 dt 0 0; 0 0 v 0; 0 0 1 dt; 0 0 0 0] (both files), row by row
+CRX_HD void dare_v_AtX(float dt, float v, const Row4* X, Row4* R) {
+  R[0] = X[0];
+  R[1].a = dbc2(dt) * X[0].a; R[1].b = dbc2(dt) * X[0].b;
+  R[2].a = X[2].a + dbc2(v) * X[1].a; R[2].b = X[2].b + dbc2(v) * X[1].b;
+  R[3].a = dbc2(dt) * X[2].a; R[3].b = dbc2(dt) * X[2].b;
+}
+
+// row i of (A'XA - (c33 * X3)A) + Q for the 4x4 block, given row i of A'X, the row's factor c33 and row 3 of X.
+// (M*A) columns: 0 = M.0, 1 = M.0*dt, 2 = M.1*v + M.2, 3 = M.2*dt;  x*1.0f = x and x + (-0.0f) = x bit for bit
+template <int I>
+CRX_HD void dare_v_row(float dt, float v, const Row4& Ri, float c33, const Row4& X3, Row4& Xn) {
+  Row4 C;
+  C.a = dbc2(c33) * X3.a; C.b = dbc2(c33) * X3.b;
+  const d_v2f vdt = {v, dt}, one_dt = {1.0f, dt};
+  const d_v2f p1a = dbc2(Ri.a[0]) * one_dt, p2a = dbc2(C.a[0]) * one_dt;
+  const d_v2f p1b = d_v2f{Ri.a[1], Ri.b[0]} * vdt + d_v2f{Ri.b[0], -0.0f};
+  const d_v2f p2b = d_v2f{C.a[1], C.b[0]} * vdt + d_v2f{C.b[0], -0.0f};
+  Xn.a = (p1a - p2a) + d_v2f{I == 0 ? 1.0f : 0.0f, I == 1 ? 1.0f : 0.0f};
+  Xn.b = (p1b - p2b) + d_v2f{I == 2 ? 1.0f : 0.0f, I == 3 ? 1.0f : 0.0f};
+}
+
+// 4x4 (:81): Xn = A'XA - ((A'X B / (R + B'XB)) B'X) A + Q, B = bv e3, R = 1
+CRX_HD void dare4_v_iter_pk(float dt, float v, float bv, const Row4* X, Row4* Xn) {
+  Row4 R[4];
+  dare_v_AtX(dt, v, X, R);
+  const float g = (bv * X[3].b[1]) * bv;
+  const float s = 1.0f + g;
+  dare_v_row<0>(dt, v, R[0], ((R[0].b[1] * bv) / s) * bv, X[3], Xn[0]);
+  dare_v_row<1>(dt, v, R[1], ((R[1].b[1] * bv) / s) * bv, X[3], Xn[1]);
+  dare_v_row<2>(dt, v, R[2], ((R[2].b[1] * bv) / s) * bv, X[3], Xn[2]);
+  dare_v_row<3>(dt, v, R[3], ((R[3].b[1] * bv) / s) * bv, X[3], Xn[3]);
+}
+
+// the diagonal of inverse2(R + B'XB) for the block-diagonal iterate (header, rule 2): m0 = 1 + (bv X33) bv, m3 = 1 + (bd x44) bd
+CRX_HD void dare5_v_sinv(float bv, float bd, float x33, float x44, float& Si0, float& Si3) {
+  const float m0 = 1.0f + (bv * x33) * bv, m3 = 1.0f + (bd * x44) * bd;
+  const float det = m0 * m3;              // m0*m3 - m1*m2 with m1 = m2 = +0
+  const float invdet = 1.0f / det;
+  Si0 = m3 * invdet; Si3 = m0 * invdet;
+}
+// the 1x1 block: x44' = (x44 - ((((x44 bd) Si3) bd) x44)) + 1
+CRX_HD float dare5_v_x44(float bd, float Si3, float x44) {
+  return (x44 - (((x44 * bd) * Si3) * bd) * x44) + 1.0f;
+}
+
+// 5x5 (:91), X = diag(X4, x44)
+CRX_HD void dare5_v_iter_pk(float dt, float v, float bv, float bd, const Row4* X, float x44, Row4* Xn, float& x44n) {
+  Row4 R[4];
+  dare_v_AtX(dt, v, X, R);
+  float Si0, Si3;
+  dare5_v_sinv(bv, bd, X[3].b[1], x44, Si0, Si3);
+  dare_v_row<0>(dt, v, R[0], ((R[0].b[1] * bv) * Si0) * bv, X[3], Xn[0]);
+  dare_v_row<1>(dt, v, R[1], ((R[1].b[1] * bv) * Si0) * bv, X[3], Xn[1]);
+  dare_v_row<2>(dt, v, R[2], ((R[2].b[1] * bv) * Si0) * bv, X[3], Xn[2]);
+  dare_v_row<3>(dt, v, R[3], ((R[3].b[1] * bv) * Si0) * bv, X[3], Xn[3]);
+  x44n = dare5_v_x44(bd, Si3, x44);
+}
+
+// (Xn - X).cwiseAbs().maxCoeff() (:92): a strict '>' scan from element (0,0) in which a NaN element never replaces the
+// running maximum and a NaN FIRST element sticks.  fmaxf drops a NaN operand, which is that behaviour for every element
+// but the first; the first element's NaN is patched in.  Exact zeros (the off-block entries) cannot raise a maximum.
+CRX_HD float dare_max2(float m, d_v2f d) { return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(d[0])), __builtin_fabsf(d[1])); }
+CRX_HD float dare_max_abs_diff(const Row4* Y, const Row4* X) {
+  const d_v2f d0 = Y[0].a - X[0].a;
+  const float m0 = __builtin_fabsf(d0[0]);
+  float m = __builtin_fmaxf(m0, __builtin_fabsf(d0[1]));
+  m = dare_max2(m, Y[0].b - X[0].b);
+#pragma unroll
+  for (int i = 1; i < 4; ++i) { m = dare_max2(m, Y[i].a - X[i].a); m = dare_max2(m, Y[i].b - X[i].b); }
+  return (m0 != m0) ? m0 : m;
+}
+CRX_HD float dare_max_abs_diff(const Row4* Y, float y44, const Row4* X, float x44) {
+  const float m = dare_max_abs_diff(Y, X);
+  return (m != m) ? m : __builtin_fmaxf(m, __builtin_fabsf(y44 - x44));
+}
+
+// ---------- four lanes per agent ---------------------------------------------------------------------------------------------
+// F is `float` in the kernel (one value per lane) and Quad4f, four lanes in lockstep, in the host build.  qperm<CTRL>(x) reads x
+// from the lane of the same quad that the DPP quad_perm control names (CTRL = p0 | p1<<2 | p2<<4 | p3<<6: lane i reads lane
+// p_i) — written so that the compiler folds the move into the consuming v_mul_f32 / v_max_f32 / v_add_f32 as its DPP operand;
+// qand(x, m) is a bitwise AND of x's bits with a per-lane mask.
+constexpr int QP_0012 = 0 | (0 << 2) | (1 << 4) | (2 << 6);   // lane r reads row max(r-1, 0): the source row of (A'X) row r
+constexpr int QP_3333 = 0xFF;                                 // everyone reads lane 3 (row 3 of X)
+constexpr int QP_0000 = 0x00;
+constexpr int QP_1032 = 1 | (0 << 2) | (3 << 4) | (2 << 6);
+constexpr int QP_2301 = 2 | (3 << 2) | (0 << 4) | (1 << 6);
+
+#if defined(__HIPCC__)
+template <int CTRL>
+__device__ __forceinline__ float qperm(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float qand(float x, uint32_t m) { return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & m); }
+__device__ __forceinline__ float qfabs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ float qfmax(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+struct Quad4f {
+  float l[4];
+  Quad4f() : l{0, 0, 0, 0} {}
+  Quad4f(float s) : l{s, s, s, s} {}
+  Quad4f(float a, float b, float c, float d) : l{a, b, c, d} {}
+};
+struct Quad4u { uint32_t l[4]; };
+#define CRX_Q4_OP(op) \
+  static inline Quad4f operator op(const Quad4f& a, const Quad4f& b) { Quad4f r; for (int i = 0; i < 4; ++i) r.l[i] = a.l[i] op b.l[i]; return r; }
+CRX_Q4_OP(+) CRX_Q4_OP(-) CRX_Q4_OP(*) CRX_Q4_OP(/)
+#undef CRX_Q4_OP
+template <int CTRL>
+static inline Quad4f qperm(const Quad4f& x) { Quad4f r; for (int i = 0; i < 4; ++i) r.l[i] = x.l[(CTRL >> (2 * i)) & 3]; return r; }
+static inline Quad4f qand(const Quad4f& x, const Quad4u& m) {
+  Quad4f r;
+  for (int i = 0; i < 4; ++i) { uint32_t b; __builtin_memcpy(&b, &x.l[i], 4); b &= m.l[i]; __builtin_memcpy(&r.l[i], &b, 4); }
+  return r;
+}
+static inline Quad4f qfabs(const Quad4f& x) { Quad4f r; for (int i = 0; i < 4; ++i) r.l[i] = __builtin_fabsf(x.l[i]); return r; }
+static inline Quad4f qfmax(const Quad4f& a, const Quad4f& b) { Quad4f r; for (int i = 0; i < 4; ++i) r.l[i] = __builtin_fmaxf(a.l[i], b.l[i]); return r; }
+#endif
+
+template <class F, class M>
+struct QuadLane {   // what distinguishes the four lanes of an agent: loop-invariant registers
+  F a;              // row r of A'X = a * X[src] (+ X[2] on lane 2):  a = (1, dt, v, dt), src = (0, 0, 1, 2)
+  M m2;             // all ones on lane 2, zero elsewhere
+  F q[4];           // row r of Q = I
+  F dt, v, bv, bd;
+};
+
+// row r of A'X on lane r.  Lanes other than 2 add +0.0f, which turns a -0 product into +0 — a zero either way (header).
+template <class F, class M>
+CRX_HD void dare_quad_AtX(const QuadLane<F, M>& c, const F* x, F* R) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) R[j] = c.a * qperm<QP_0012>(x[j]) + qand(x[j], c.m2);
+}
+// row r of (A'XA - (c33 X3)A) + Q on lane r
+template <class F, class M>
+CRX_HD void dare_quad_row(const QuadLane<F, M>& c, const F* R, F c33, const F* x, F* xn) {
+  F C[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) C[j] = c33 * qperm<QP_3333>(x[j]);
+  const F p1[4] = {R[0], R[0] * c.dt, R[1] * c.v + R[2], R[2] * c.dt};
+  const F p2[4] = {C[0], C[0] * c.dt, C[1] * c.v + C[2], C[2] * c.dt};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xn[j] = (p1[j] - p2[j]) + c.q[j];
+}
+// max |xn - x| over the agent's four rows (every lane of the quad gets it); NaN elements are dropped (see dare_quad_first)
+template <class F>
+CRX_HD F dare_quad_maxdiff(const F* xn, const F* x) {
+  F m = qfabs(xn[0] - x[0]);
+#pragma unroll
+  for (int j = 1; j < 4; ++j) m = qfmax(m, qfabs(xn[j] - x[j]));
+  m = qfmax(m, qperm<QP_1032>(m));
+  return qfmax(m, qperm<QP_2301>(m));
+}
+// the first-element rule of dare_max_abs_diff as an addend: with d00 the difference of element (0,0) — on lane 0 —
+// (d00 - d00) is 0 for a finite d00 and NaN for a NaN or infinite one (where the maximum is not below eps either)
+template <class F>
+CRX_HD F dare_quad_first(const F* xn, const F* x) {
+  const F d0 = xn[0] - x[0];
+  return qperm<QP_0000>(d0 - d0);
+}
+
+// One evaluation for the 4x4 problem; returns max |xn - x| with the reference's NaN rule.
+template <class F, class M>
+CRX_HD F dare4_quad_iter(const QuadLane<F, M>& c, const F* x, F* xn) {
+  F R[4];
+  dare_quad_AtX(c, x, R);
+  const F g = (c.bv * qperm<QP_3333>(x[3])) * c.bv;
+  const F s = F(1.0f) + g;
+  dare_quad_row(c, R, ((R[3] * c.bv) / s) * c.bv, x, xn);
+  return dare_quad_maxdiff(xn, x) + dare_quad_first(xn, x);
+}
+
+// One evaluation for the 5x5 problem, X = diag(X4, x44) (x44 replicated on the four lanes).
+template <class F, class M>
+CRX_HD F dare5_quad_iter(const QuadLane<F, M>& c, const F* x, F x44, F* xn, F& x44n) {
+  F R[4];
+  dare_quad_AtX(c, x, R);
+  const F m0 = F(1.0f) + (c.bv * qperm<QP_3333>(x[3])) * c.bv, m3 = F(1.0f) + (c.bd * x44) * c.bd;
+  const F det = m0 * m3;
+  const F invdet = F(1.0f) / det;
+  const F Si0 = m3 * invdet, Si3 = m0 * invdet;
+  dare_quad_row(c, R, ((R[3] * c.bv) * Si0) * c.bv, x, xn);
+  x44n = (x44 - (((x44 * c.bd) * Si3) * c.bd) * x44) + F(1.0f);
+  return qfmax(dare_quad_maxdiff(xn, x), qfabs(x44n - x44)) + dare_quad_first(xn, x);
+}
+
+}  // namespace crx

@@ -26,6 +26,42 @@ def test_dare_from_v_bit_exact(crx, oracle_mod, dim, n):
     assert ito[0] == 150
 
 
+@pytest.mark.parametrize("lanes", [1, 4])
+@pytest.mark.parametrize("dim", [5, 4])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000])
+def test_dare_from_v_both_register_layouts_bit_exact(crx, oracle_mod, dim, n, lanes):
+    """One agent per lane and one agent per DPP quad (forced through the experimental entry point; the product entry point
+    picks by batch size): the same bits, iteration counts included; ragged last quad / wave, other dt / L / eps."""
+    from cpprobotics_amd.experimental import dlqr_from_v_lanes
+    v = lqr_speeds(n, seed=7 * n + dim)
+    v[0] = 0.0
+    for dt, L, eps, maxiter in ((0.1, 0.5, 0.01, 150), (0.05, 2.9, 1e-3, 40), (0.1, 0.5, 0.01, 1)):
+        A, B, Q, R = oracle_mod.lqr_build(v, dim, dt=dt, L=L)
+        Xo, Ko, ito = oracle_mod.dare(A, B, Q, R, eps=eps, maxiter=maxiter)
+        K, X, it = dlqr_from_v_lanes(_t(v), dim, lanes, dt=dt, L_wheelbase=L, eps=eps, maxiter=maxiter)
+        assert np.array_equal(it.cpu().numpy(), ito)
+        assert bit_equal(X.cpu().numpy(), Xo)
+        assert bit_equal(K.cpu().numpy(), Ko)
+
+
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_dare_from_v_non_finite_speed(crx, oracle_mod, lanes):
+    """NaN / huge speeds: the reference's loop runs to the cap (a NaN first element never compares below eps) and returns
+    non-finite matrices; so does every layout here, for that agent only."""
+    from cpprobotics_amd.experimental import dlqr_from_v_lanes
+    v = lqr_speeds(64, seed=1)
+    v[5] = np.nan; v[9] = 1e30; v[13] = -np.inf
+    A, B, Q, R = oracle_mod.lqr_build(v, 5)
+    Xo, Ko, ito = oracle_mod.dare(A, B, Q, R)
+    K, X, it = dlqr_from_v_lanes(_t(v), 5, lanes)
+    X, K, it = X.cpu().numpy(), K.cpu().numpy(), it.cpu().numpy()
+    ok = np.isfinite(Xo).all(axis=1)
+    assert (~ok).sum() == 3 and not ok[[5, 9, 13]].any()
+    assert np.array_equal(it, ito)
+    assert bit_equal(X[ok], Xo[ok]) and bit_equal(K[ok], Ko[ok])
+    assert not np.isfinite(X[~ok]).all(axis=1).any()
+
+
 @pytest.mark.parametrize("dim", [5, 4])
 def test_dare_dense_matches_structured_and_oracle(crx, oracle_mod, dim):
     n = 777

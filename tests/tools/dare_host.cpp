@@ -1,0 +1,70 @@
+// dare_host.cpp — host build of the engine's structured Riccati iterations (csrc/dare_math.h), so that both register layouts —
+// one lane per agent on packed rows, and four lanes per agent with DPP quad_perm exchanges (emulated here by Quad4f, four
+// lanes in lockstep) — can be checked bit for bit against the oracle without a GPU.
+// Built by tests/test_dare_host.py: g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC.  The loop around the iteration
+// mirrors the kernels': cold start X = I, stop at max|Xn - X| < eps, at most maxiter evaluations.
+#include <cstring>
+#include "../../cpprobotics_amd/csrc/dare_math.h"
+
+using namespace crx;
+
+extern "C" int dare_lane_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
+  const float dt = (float)dt_d;
+  for (int a = 0; a < n; ++a) {
+    const float v = vs[a], bv = (float)((double)v / L), bd = dt;
+    Row4 X[4], Y[4];
+    float x44 = 1.0f, y44 = 1.0f;
+    for (int i = 0; i < 4; ++i) {
+      X[i].a = d_v2f{i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+      X[i].b = d_v2f{i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+    }
+    int it = maxiter < 0 ? 0 : maxiter;
+    for (int i = 0; i < maxiter; ++i) {
+      float m;
+      if (dim == 5) { dare5_v_iter_pk(dt, v, bv, bd, X, x44, Y, y44); m = dare_max_abs_diff(Y, y44, X, x44); }
+      else { dare4_v_iter_pk(dt, v, bv, X, Y); m = dare_max_abs_diff(Y, X); }
+      std::memcpy(X, Y, sizeof(X)); x44 = y44;
+      if (m < eps) { it = i + 1; break; }
+    }
+    float* Xa = Xout + (size_t)a * dim * dim;
+    std::memset(Xa, 0, sizeof(float) * dim * dim);
+    for (int i = 0; i < 4; ++i) {
+      Xa[i + dim * 0] = X[i].a[0]; Xa[i + dim * 1] = X[i].a[1]; Xa[i + dim * 2] = X[i].b[0]; Xa[i + dim * 3] = X[i].b[1];
+    }
+    if (dim == 5) Xa[24] = x44;
+    iters[a] = it;
+  }
+  return 0;
+}
+
+extern "C" int dare_quad_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
+  const float dt = (float)dt_d;
+  for (int a = 0; a < n; ++a) {
+    const float v = vs[a];
+    QuadLane<Quad4f, Quad4u> c;
+    c.dt = dt; c.v = v; c.bd = dt; c.bv = (float)((double)v / L);
+    c.a = Quad4f(1.0f, dt, v, dt);
+    c.m2 = Quad4u{{0u, 0u, 0xffffffffu, 0u}};
+    for (int j = 0; j < 4; ++j) { c.q[j] = Quad4f(0.0f); c.q[j].l[j] = 1.0f; }
+    Quad4f X[4], Y[4], x44(1.0f), y44(1.0f);
+    for (int j = 0; j < 4; ++j) X[j] = c.q[j];
+    int it = maxiter < 0 ? 0 : maxiter;
+    for (int i = 0; i < maxiter; ++i) {
+      Quad4f m;
+      if (dim == 5) m = dare5_quad_iter(c, X, x44, Y, y44);
+      else m = dare4_quad_iter(c, X, Y);
+      for (int j = 0; j < 4; ++j) X[j] = Y[j];
+      x44 = y44;
+      for (int l = 1; l < 4; ++l)   // every lane of the quad must see the same maximum (NaN included)
+        if (std::memcmp(&m.l[0], &m.l[l], 4) != 0 && !(m.l[0] != m.l[0] && m.l[l] != m.l[l])) return 1;
+      if (m.l[0] < eps) { it = i + 1; break; }
+    }
+    float* Xa = Xout + (size_t)a * dim * dim;
+    std::memset(Xa, 0, sizeof(float) * dim * dim);
+    for (int r = 0; r < 4; ++r)
+      for (int j = 0; j < 4; ++j) Xa[r + dim * j] = X[j].l[r];
+    if (dim == 5) Xa[24] = x44.l[3];
+    iters[a] = it;
+  }
+  return 0;
+}

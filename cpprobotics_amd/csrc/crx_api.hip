@@ -51,7 +51,7 @@ int check_device() {
 inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
-constexpr int kDareQuadMaxAgents = 65536;
+constexpr int kDareQuadMaxAgents = 32768;
 
 // Threads per workgroup of the iterative kernels (DARE, MPC, tracking): full 64-lane waves.  Narrower waves
 // (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized

@@ -349,7 +349,14 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
 // Here an agent is a DPP quad — lane r holds row r of the 4x4 block of X, x44 is replicated — so an evaluation is ~1/3 of the
 // instructions (one row per lane; the source row of A'X and row 3 of X arrive as quad_perm operands of the multiplies; the
 // convergence test is two DPP max steps) and the same batch fills every SIMD.  Same arithmetic per coefficient, same bits.
-// Converged quads are masked off like converged lanes above; all four lanes of a quad take the same decisions.
+// All four lanes of a quad take the same decisions (the maximum is reduced across the quad before the test).
+//
+// Converged agents are NOT masked off: every quad keeps evaluating (nobody looks at a converged agent's later iterates), and
+// an agent's X, K and iteration count go to memory straight from the — rare — pass in which its own test succeeds.  The hot
+// loop then carries one compare, one scalar and, and one not-taken branch per evaluation instead of two exec-mask regions
+// (~14 scalar instructions, which cost a lone wave as much as vector ones) and no live-out registers but the iterate itself.
+typedef unsigned long long dare_mask_t;
+
 template <int DIM>
 __global__ void __launch_bounds__(256)
 dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
@@ -375,48 +382,57 @@ dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L,
     if constexpr (DIM == 5) return dare5_quad_iter(c, Xi, xi44, Xo, xo44);
     else return dare4_quad_iter(c, Xi, Xo);
   };
-  bool done = !live || maxiter <= 0;
-  bool in_y = false;
-  int it = maxiter < 0 ? 0 : maxiter;
-  for (int i = 0; i < maxiter; i += 2) {
-    if (!done) {
+  // the agents of `who` hand back iterate (W, w44) after `it` evaluations
+  auto emit = [&](dare_mask_t who, const float* W, float w44, int it) {
+    if (!((who >> (threadIdx.x & 63)) & 1)) return;
+    if (Xg) {
+      float* Xa = Xg + a * NN;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Xa[r + DIM * j] = W[j];
+      if constexpr (DIM == 5) {
+        Xa[r + DIM * 4] = 0.0f; Xa[4 + DIM * r] = 0.0f;
+        if (r == 3) Xa[24] = w44;
+      }
+    }
+    if (Kg && r == 3) {       // the gain needs rows 3 (this lane's) and 4 of X only
+      float Xf[NN], K[M * DIM];
+#pragma unroll
+      for (int j = 0; j < NN; ++j) Xf[j] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Xf[3 + DIM * j] = W[j];
+      if constexpr (DIM == 5) { Xf[24] = w44; dlqr5_v_gain(dt, v, c.bv, dt, Xf, K); }
+      else dlqr4_v_gain(dt, v, c.bv, Xf, K);
+#pragma unroll
+      for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
+    }
+    if (iters && r == 0) iters[a] = it;
+  };
+  dare_mask_t todo = __builtin_amdgcn_ballot_w64(live);     // agents whose test has not passed yet
+  if (maxiter <= 0) { emit(todo, X, x44, 0); return; }
+  // Two evaluations per trip (X -> Y -> X); an odd cap is made even by one evaluation ahead of the loop.
+  int i = 0;
+  if (maxiter & 1) {
+    const float m = iter(X, x44, Y, y44);
+    const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
+    if (hit) { emit(hit, Y, y44, 1); todo &= ~hit; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[j] = Y[j];
+    x44 = y44;
+    i = 1;
+  }
+  for (; i < maxiter && todo; i += 2) {
+    {
       const float m = iter(X, x44, Y, y44);
-      in_y = true;
-      if (m < eps) { done = true; it = i + 1; }
+      const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
+      if (hit) { emit(hit, Y, y44, i + 1); todo &= ~hit; }
     }
-    if (!done && i + 1 < maxiter) {
+    {
       const float m = iter(Y, y44, X, x44);
-      in_y = false;
-      if (m < eps) { done = true; it = i + 2; }
-    }
-    if (__all(done)) break;
-  }
-  if (!live) return;
-  float row[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) row[j] = in_y ? Y[j] : X[j];
-  const float xf44 = in_y ? y44 : x44;
-  if (Xg) {
-    float* Xa = Xg + a * NN;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Xa[r + DIM * j] = row[j];
-    if constexpr (DIM == 5) {
-      Xa[r + DIM * 4] = 0.0f; Xa[4 + DIM * r] = 0.0f;
-      if (r == 3) Xa[24] = xf44;
+      const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
+      if (hit) { emit(hit, X, x44, i + 2); todo &= ~hit; }
     }
   }
-  if (Kg && r == 3) {       // the gain needs rows 3 (this lane's) and 4 of X only
-    float Xf[NN], K[M * DIM];
-#pragma unroll
-    for (int j = 0; j < NN; ++j) Xf[j] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Xf[3 + DIM * j] = row[j];
-    if constexpr (DIM == 5) { Xf[24] = xf44; dlqr5_v_gain(dt, v, c.bv, dt, Xf, K); }
-    else dlqr4_v_gain(dt, v, c.bv, Xf, K);
-#pragma unroll
-    for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
-  }
-  if (iters && r == 0) iters[a] = it;
+  if (todo) emit(todo, X, x44, maxiter);                    // agents that ran into the cap return the last evaluation
 }
 
 }  // namespace crx

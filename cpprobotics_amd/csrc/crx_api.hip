@@ -903,9 +903,9 @@ int host_bisect(const float* x, float t, int start, int end) {   // cubic_spline
   }
 }
 
-struct FrenetGrid { int ndi, nTi, ntv, ntt, min_nt; };
+struct FrenetGrid { int ndi, nTi, ntv, ntt, min_nt; std::vector<float> ts, Tis; };
 FrenetGrid frenet_grid(const crx_frenet_config& g) {   // the loop trip counts of :55-56,:58,:66-68
-  FrenetGrid r{0, 0, 0, 0, 1 << 30};
+  FrenetGrid r{0, 0, 0, 0, 1 << 30, {}, {}};
   const int cap = 1 << 16;
   for (float di = (float)(-1 * g.max_road_width); di < g.max_road_width && r.ndi < cap; di += g.d_road_w) ++r.ndi;
   float Tmax = 0.0f;
@@ -915,6 +915,7 @@ FrenetGrid frenet_grid(const crx_frenet_config& g) {   // the loop trip counts o
   std::vector<float> ts;
   for (float t = 0; t < Tmax && r.ntt < cap; t += g.dt) { ++r.ntt; ts.push_back(t); }
   for (float Ti : Tis) { int c = 0; while (c < r.ntt && ts[c] < Ti) ++c; if (c < r.min_nt) r.min_nt = c; }
+  r.ts = ts; r.Tis = Tis;
   return r;
 }
 int frenet_check_cfg(const crx_frenet_config& q, FrenetGrid* out) {
@@ -1096,9 +1097,16 @@ int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* co
   const int stride = gr.nTi * gr.ntv * gr.ntt;
   int wpb = crx::kFrWavesPerBlock;
   while (wpb > 1 && (size_t)wpb * stride * sizeof(crx::FrTab) > (size_t)crx::kFrTabLdsBytes) wpb >>= 1;
+  // std::pow(t, k), k = 2..5, of the time grid and of the horizons: libm's own values, what the reference's polynomial classes
+  // call (quintic_polynomial.h:41-68, quartic_polynomial.h:39-59) — float argument and int exponent promoted to double
+  crx::FrPowArg pw;
+  std::memset(&pw, 0, sizeof(pw));
+  auto powers = [](float x) { return crx::FrPow{std::pow((double)x, 2.0), std::pow((double)x, 3.0), std::pow((double)x, 4.0), std::pow((double)x, 5.0)}; };
+  for (int i = 0; i < gr.ntt; ++i) pw.t[i] = powers(gr.ts[i]);
+  for (int i = 0; i < gr.nTi; ++i) pw.T[i] = powers(gr.Tis[i]);
   hipLaunchKernelGGL(crx::frenet_run_kernel, dim3(blocks_for(n, wpb)), dim3(64 * wpb), (size_t)wpb * stride * sizeof(crx::FrTab),
                      (hipStream_t)stream, n, max_ticks, state, coef, nx, goal_xy[0], goal_xy[1], ob, nob, c, hist, ticks_done,
-                     status, best_idx, n_valid, path_cf, path_ok, path_cap, stride);
+                     status, best_idx, n_valid, path_cf, path_ok, path_cap, stride, pw);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -14,11 +14,13 @@
 // /root/reference/include/quintic_polynomial.h:39-69, quartic_polynomial.h:37-64 and the Spline evaluation of
 // cubic_spline.h:67-83,:118-127 (the spline coefficients are built once per course on the host, crx_frenet_spline_build).
 //
-// Arithmetic contract (tolerance parity, 1e-5 — see DESIGN.md §5e): every expression keeps the reference's C++ types
-// (float members, double macros, std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in
-// float).  Differences from the CPU oracle are confined to (a) pow(t,k) formed by exact-operand double products instead
-// of libm pow and (b) the double sin/cos (<= 1 ulp) — each can move a float result by one ulp only when the double lands
-// within 2^-29 of a rounding boundary.  The 3x3 / 2x2 coefficient solves are Eigen's ColPivHouseholderQR restated in float (crx_qr.h).
+// Arithmetic contract: every expression keeps the reference's C++ types (float members, double macros,
+// std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in float); atan2f is glibc-exact
+// (crx_fdlibm.h); std::pow comes from the host's libm (FrPowArg below) or is an exact product; the 3x3 / 2x2 coefficient solves
+// are Eigen's ColPivHouseholderQR restated in float (crx_qr.h).  ONE operation is not the reference's bit for bit: the double
+// cos / sin of :111-112 is the engine's own (<= 1 ulp of a double; glibc's is 0.55 ulp), which can move the float it is rounded
+// into by one ulp only when `poi + di*cos` lands within 2^-29 of a float rounding boundary.  The parity tests demand equal
+// bits on every committed seed (costs, verdicts, winners, whole episodes) with an enumerated exception list — empty so far.
 // Reference quirks that decide the numbers are kept (the missing factor 5 in the quintic's first derivative,
 // quintic_polynomial.h:53; maxima starting at FLT_MIN); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
 // throw (s before the course) the path is dropped and status bit 2 is set.
@@ -46,12 +48,19 @@ constexpr int kFrMaxPaths = 4096, kFrMaxCombos = 64, kFrTabLdsBytes = 48 * 1024;
 struct FrQuintic { float a0, a1, a2, a3, a4, a5; };
 struct FrQuartic { float a0, a1, a2, a3, a4; };
 
-__device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, float xe, float vxe, float axe, float T) {
+// std::pow(x, k) of a float x (double pow of the promoted arguments, quintic_polynomial.h:41-68, quartic_polynomial.h:39-59) for
+// k = 2..5.  x^2 is exact in double (48 significant bits), so pow returns the product; x^3..x^5 are NOT formed here: the
+// time grid and the horizons are known on the host before the launch (they depend on the configuration only), and the C ABI
+// entry point evaluates libm's pow on them — the reference's own call — and hands the values over as a kernel argument.
+struct FrPow { double t2, t3, t4, t5; };
+struct FrPowArg { FrPow t[64 /* kFrMaxT */]; FrPow T[32 /* kFrMaxTi */]; };
+
+__device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, float xe, float vxe, float axe, float T, const FrPow& wT) {
   FrQuintic q;
   q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
   // A and B as the comma initialisers of quintic_polynomial.h:41-47 fill them (double expressions rounded to float entries),
   // then A.colPivHouseholderQr().solve(B) in float (:49; crx_qr.h)
-  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td, T4 = T2 * T2, T5 = T4 * Td;
+  const double T2 = wT.t2, T3 = wT.t3, T4 = wT.t4, T5 = wT.t5;
   float A[9] = {(float)T3, (float)(3.0 * T2), 6.0f * T,                    // column 0 (column-major)
                 (float)T4, (float)(4.0 * T3), (float)(12.0 * T2),          // column 1
                 (float)T5, (float)(5.0 * T4), (float)(20.0 * T3)};         // column 2
@@ -61,10 +70,10 @@ __device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, 
   q.a3 = c[0]; q.a4 = c[1]; q.a5 = c[2];
   return q;
 }
-__device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, float vxe, float axe, float T) {
+__device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, float vxe, float axe, float T, const FrPow& wT) {
   FrQuartic q;
   q.a0 = xs; q.a1 = vxs; q.a2 = (float)((double)axs / 2.0);
-  const double Td = (double)T, T2 = Td * Td, T3 = T2 * Td;                 // quartic_polynomial.h:38-45
+  const double T2 = wT.t2, T3 = wT.t3;                                     // quartic_polynomial.h:38-45
   float A[4] = {(float)(3.0 * T2), 6.0f * T, (float)(4.0 * T3), (float)(12.0 * T2)};
   float B[2] = {vxe - q.a1 - 2.0f * q.a2 * T, axe - 2.0f * q.a2};
   float c[2];
@@ -73,12 +82,7 @@ __device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, 
   return q;
 }
 // the evaluation expressions of quintic_polynomial.h:44-62 / quartic_polynomial.h:44-60: float until the first pow, double
-// after.  The powers t^2..t^5 of the time grid are formed once per block (frenet_run_kernel) and read from LDS: FrPow.
-struct FrPow { double t2, t3, t4, t5; };
-__device__ __forceinline__ FrPow fr_pow(float t) {
-  const double td = t, t2 = td * td;
-  return FrPow{t2, t2 * td, t2 * t2, (t2 * t2) * td};
-}
+// after.  The powers t^2..t^5 of the time grid are staged once per block in LDS (frenet_run_kernel).
 __device__ __forceinline__ float fr_q5_point(const FrQuintic& q, float t, const FrPow& w) {
   return (float)(((((double)(q.a0 + q.a1 * t) + (double)q.a2 * w.t2) + (double)q.a3 * w.t3) + (double)q.a4 * w.t4) + (double)q.a5 * w.t5);
 }
@@ -129,12 +133,12 @@ __global__ void __launch_bounds__(64 * kFrWavesPerBlock)
 frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* __restrict__ coef, int nx, float goal_x, float goal_y,
                   const float* __restrict__ ob, int nob, FrenetCfg g, float* __restrict__ hist, int* __restrict__ ticks_done,
                   int* __restrict__ status, int* __restrict__ best_idx, int* __restrict__ n_valid, float* __restrict__ path_cf,
-                  int* __restrict__ path_ok, int path_cap, int tab_stride) {
+                  int* __restrict__ path_ok, int path_cap, int tab_stride, const FrPowArg pw) {
   extern __shared__ FrTab s_tab_all[];           // [waves per block][tab_stride], tab_stride >= nTi * ntv * ntt
   __shared__ float s_coef[9 * kFrMaxKnots];      // rows s, ax,bx,cx,dx, ay,by,cy,dy
   __shared__ float s_ob[2 * kFrMaxOb];
   __shared__ float s_di[kFrMaxDi], s_Ti[kFrMaxTi], s_tv[kFrMaxTv], s_t[kFrMaxT];
-  __shared__ FrPow s_pw[kFrMaxT];
+  __shared__ FrPow s_pw[kFrMaxT], s_pT[kFrMaxTi];
   __shared__ int s_nt[kFrMaxTi], s_cnt[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   for (int i = threadIdx.x; i < 9 * nx; i += blockDim.x) s_coef[i] = coef[i];
@@ -150,7 +154,8 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
     s_cnt[0] = ndi; s_cnt[1] = nTi; s_cnt[2] = ntv; s_cnt[3] = ntt;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < s_cnt[3]; i += blockDim.x) s_pw[i] = fr_pow(s_t[i]);
+  for (int i = threadIdx.x; i < s_cnt[3]; i += blockDim.x) s_pw[i] = pw.t[i];
+  for (int i = threadIdx.x; i < s_cnt[1]; i += blockDim.x) s_pT[i] = pw.T[i];
   __syncthreads();
   const size_t a = (size_t)blockIdx.x * wpb + wv;
   if (a >= (size_t)n) return;     // whole waves only: no block barrier below
@@ -174,7 +179,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
     if (lane < nC) {
       const int iTi = lane / ntv, itv = lane - iTi * ntv;
       const int nt = s_nt[iTi];
-      lon = fr_quartic(s0, c_speed, 0.0f, s_tv[itv], 0.0f, s_Ti[iTi]);            // :70
+      lon = fr_quartic(s0, c_speed, 0.0f, s_tv[itv], 0.0f, s_Ti[iTi], s_pT[iTi]);            // :70
       bool walking = true;
       for (int i = 0; i < nt; ++i) {                                              // :74-85
         const float t = s_t[i];
@@ -229,7 +234,7 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       if (!live) continue;
       const float di = s_di[idi], Ti = s_Ti[iTi];
       const int nt = s_nt[iTi];
-      const FrQuintic lat = fr_quintic(c_d, c_d_d, c_d_dd, di, 0.0f, 0.0f, Ti);     // :57
+      const FrQuintic lat = fr_quintic(c_d, c_d_d, c_d_dd, di, 0.0f, 0.0f, Ti, s_pT[iTi]);     // :57
       // what main hands over (:227-231) is sample [1] of the winner; the costs need the last samples (:89-91); nt >= 2
       const float dd1 = fr_q5_d1(lat, s_t[1], s_pw[1]), ddd1 = fr_q5_d2(lat, s_t[1], s_pw[1]);
       const float d_last = fr_q5_point(lat, s_t[nt - 1], s_pw[nt - 1]);

@@ -1,15 +1,23 @@
-"""GPU parity of the Frenet optimal-trajectory planner (one agent per wavefront) against the CPU oracle.
+"""GPU parity of the Frenet optimal-trajectory planner (one agent per wavefront) against the CPU oracle: EQUAL BITS.
 
-Tolerance parity: the kernel forms pow(t,k) by double products and uses its own double sin/cos, the oracle
-calls libm as the reference does; a float result can differ by one ulp when the double lands on a rounding boundary, so
-costs and hand-over states are compared at 1e-5 relative, check_paths verdicts and the winner exactly wherever no candidate
-sits within 1e-6 of a threshold or of the winner's cost."""
+Every cost, every check_paths verdict, every winner, every tick of every episode must equal the oracle's (itself equal to the
+reference's own lines bit for bit, tests/test_oracle_vs_ref.py).  The kernel's std::pow values are libm's (evaluated by the C ABI
+entry point on the time grid), atan2f / sqrtf are glibc-exact; the one operation that is not the reference's own is the double
+cos / sin of frenet_optimal_trajectory.cpp:111-112 (<= 1 ulp of a double), which can move the float it is rounded into only
+when the double lands within 2^-29 of a float rounding boundary.  If that ever happens on a committed seed the case is listed
+in KNOWN_EXCEPTIONS by (test, agent, path) with the reason — the list is empty: no committed seed hits it."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-RTOL = 1e-5
+# {(test name, agent, path or tick): reason}.  An entry exempts that one (agent, path) from the equal-bits demand.
+KNOWN_EXCEPTIONS = {}
+
+
+def _equal(a, b):
+    """Equal as IEEE values (+0 == -0), NaN == NaN."""
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
 
 
 def _t(a):
@@ -30,10 +38,6 @@ def _course(crx, oracle_mod):
     return crx.FrenetCourse(O.FRENET_WX, O.FRENET_WY), O.FRENET_OBSTACLES
 
 
-def _close(a, b, rtol=RTOL, atol=1e-6):
-    return np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
-
-
 def _cfg(crx, **kw):
     c = crx.frenet_default_config()
     for k, v in kw.items():
@@ -41,7 +45,7 @@ def _cfg(crx, **kw):
     return c
 
 
-@pytest.mark.parametrize("n", [1, 5, 203])
+@pytest.mark.parametrize("n", [1, 5, 203, 2000])
 def test_frenet_single_plan(crx, oracle_mod, n):
     course, ob = _course(crx, oracle_mod)
     st = _states(n, 10 + n)
@@ -50,30 +54,22 @@ def test_frenet_single_plan(crx, oracle_mod, n):
     r = crx.frenet_optimal_planning(sd, course, _t(ob), _cfg(crx), want_paths=True)
     P = o["n_paths"][0]
     assert P == 168 and r["path_cf"].shape[1] == P
-    cf, ok = r["path_cf"].cpu().numpy(), r["path_ok"].cpu().numpy()
-    assert _close(cf, o["path_cf"])
-    assert (ok != o["path_ok"]).mean() < 1e-3                      # a verdict can flip only on a threshold boundary
-    best, nv, status = r["best_idx"].cpu().numpy(), r["n_valid"].cpu().numpy(), r["status"].cpu().numpy()
-    same = (ok == o["path_ok"]).all(axis=1)
-    assert np.array_equal(status[same], o["status"][same]) and np.array_equal(nv[same], o["n_valid"][same])
-    # the winner: identical unless another survivor's cost is within rounding of it
-    agree = best == o["best"]
-    for a in np.flatnonzero(~agree & same):
-        okc = o["path_cf"][a][o["path_ok"][a].astype(bool)]
-        assert (np.abs(okc - okc.min()) <= RTOL * abs(okc.min())).sum() >= 2
-    assert agree[same].mean() > 0.99
-    moved = (o["best"] >= 0) & agree & same
+    assert not KNOWN_EXCEPTIONS
+    assert _equal(r["path_cf"].cpu().numpy(), o["path_cf"])                      # all n x 168 costs
+    assert _equal(r["path_ok"].cpu().numpy(), o["path_ok"])                      # all n x 168 check_paths verdicts
+    assert _equal(r["best_idx"].cpu().numpy(), o["best"])                        # every winner
+    assert _equal(r["n_valid"].cpu().numpy(), o["n_valid"]) and _equal(r["status"].cpu().numpy(), o["status"])
+    moved = o["best"] >= 0
     h = r["hist"].cpu().numpy()[0]
-    assert _close(h[moved], np.concatenate([o["out"][moved, :5], o["out"][moved, 5:8]], axis=1))
-    assert _close(sd.cpu().numpy()[moved], o["out"][moved, :5])
-    stuck = (o["best"] < 0) & same
-    assert np.array_equal(sd.cpu().numpy()[stuck], st[stuck]) and (status[stuck] & 1).all()
+    assert _equal(h[moved], np.concatenate([o["out"][moved, :5], o["out"][moved, 5:8]], axis=1))
+    assert _equal(sd.cpu().numpy()[moved], o["out"][moved, :5])
+    assert _equal(sd.cpu().numpy()[~moved], st[~moved]) and (r["status"].cpu().numpy()[~moved] & 1).all()
 
 
 def test_frenet_reference_episode(crx, oracle_mod):
     course, ob = _course(crx, oracle_mod)
     O = oracle_mod.oracle_lib
-    n, max_ticks = 9, 300
+    n, max_ticks = 17, 300
     st = np.repeat(O.FRENET_STATE0[None, :], n, axis=0)
     st[1:, 2] += np.linspace(-1.5, 1.5, n - 1).astype(np.float32)          # neighbours of the reference's start
     o = oracle_mod.frenet_run(st, course.coef, course.goal, max_ticks, ob, want_hist=True)
@@ -81,54 +77,54 @@ def test_frenet_reference_episode(crx, oracle_mod):
     r = crx.frenet_run(sd, course, _t(ob), max_ticks, _cfg(crx), want_hist=True)
     ticks = r["ticks"].cpu().numpy()
     h = r["hist"].cpu().numpy()
-    # the reference's own start (agent 0): same length, same fate, same trajectory
-    assert ticks[0] == o["ticks"][0] and r["status"].cpu().numpy()[0] == o["status"][0]
-    assert o["status"][0] == 0 and ticks[0] < max_ticks                   # the reference's start must reach the goal
+    # the reference's own start (agent 0) must reach the goal, as the reference does
+    assert o["status"][0] == 0 and o["ticks"][0] < max_ticks
     assert np.hypot(h[ticks[0] - 1, 0, 5] - course.goal[0], h[ticks[0] - 1, 0, 6] - course.goal[1]) <= 1.0
-    assert np.allclose(h[: ticks[0], 0], o["hist"][: ticks[0], 0], rtol=1e-4, atol=1e-4)
-    # the neighbours: a long closed loop amplifies one-ulp differences only through a changed winner; demand agreement for most
-    same = ticks == o["ticks"]
-    assert same.mean() >= 0.75
-    for a in np.flatnonzero(same):
-        assert np.allclose(h[: ticks[a], a], o["hist"][: ticks[a], a], rtol=1e-3, atol=1e-3)
+    # every agent: same length, same fate, every tick of the trajectory (hand-over state, position, winner's cost) equal
+    assert _equal(ticks, o["ticks"]) and _equal(r["status"].cpu().numpy(), o["status"])
+    assert _equal(r["best_idx"].cpu().numpy(), o["best_idx"]) and _equal(r["n_valid"].cpu().numpy(), o["n_valid"])
+    for a in range(n):
+        assert _equal(h[: ticks[a], a], o["hist"][: ticks[a], a]), a
+    assert _equal(sd.cpu().numpy(), o["state"])
 
 
 def test_frenet_edge_cases(crx, oracle_mod):
     import torch
     course, ob = _course(crx, oracle_mod)
     s_end = float(course.coef[0, -1])
+
+    def same(r, o):
+        assert _equal(r["path_cf"].cpu().numpy(), o["path_cf"]) and _equal(r["path_ok"].cpu().numpy(), o["path_ok"])
+        assert _equal(r["best_idx"].cpu().numpy(), o["best"]) and _equal(r["n_valid"].cpu().numpy(), o["n_valid"])
+        assert _equal(r["status"].cpu().numpy(), o["status"])
+
     # (a) no obstacles; (b) agents about to run off the end of the course (paths truncated at csp.s.back(), some to < 2 points)
     st = _states(64, 3)
     st[:16, 0] = np.linspace(s_end - 6.0, s_end - 0.01, 16).astype(np.float32)
     st[16, 0] = s_end + 1.0                                           # beyond the course: every path has no point -> no survivor
     for obs in (np.zeros((0, 2), np.float32), ob):
         o = oracle_mod.frenet_plan(st, course.coef, obs)
-        sd = _t(st)
-        r = crx.frenet_optimal_planning(sd, course, _t(obs) if len(obs) else torch.zeros((0, 2), device="cuda"), want_paths=True)
-        ok = r["path_ok"].cpu().numpy()
-        assert (ok != o["path_ok"]).mean() < 1e-3
-        assert _close(r["path_cf"].cpu().numpy(), o["path_cf"])
+        r = crx.frenet_optimal_planning(_t(st), course, _t(obs) if len(obs) else torch.zeros((0, 2), device="cuda"), want_paths=True)
+        same(r, o)
         assert r["best_idx"].cpu().numpy()[16] == -1 and r["status"].cpu().numpy()[16] & 1
-        same = (ok == o["path_ok"]).all(axis=1)
-        assert (r["best_idx"].cpu().numpy()[same] == o["best"][same]).mean() > 0.97
     # (c) an obstacle wall: nothing survives anywhere near it
     wall = np.stack([np.full(40, 12.0), np.linspace(-15, 5, 40)], axis=1).astype(np.float32)
     st2 = _states(8, 4); st2[:, 0] = 9.0
     o = oracle_mod.frenet_plan(st2, course.coef, wall)
-    r = crx.frenet_optimal_planning(_t(st2), course, _t(wall))
-    assert np.array_equal(r["n_valid"].cpu().numpy(), o["n_valid"]) and np.array_equal(r["best_idx"].cpu().numpy(), o["best"])
-    # (d) a different sample grid and course
+    r = crx.frenet_optimal_planning(_t(st2), course, _t(wall), want_paths=True)
+    same(r, o)
+    # (d) a different sample grid (time step 0.25: other powers of the time grid) and course
     rng = np.random.default_rng(8)
     wx = np.cumsum(rng.uniform(6.0, 15.0, 12)).astype(np.float32); wy = rng.uniform(-6, 6, 12).astype(np.float32)
     c2 = crx.FrenetCourse(wx, wy)
-    kw = dict(max_road_width=4.0, d_road_w=0.5, mint=3.0, maxt=4.1, dt=0.25, n_s_sample=2, d_t_s=1.0, robot_radius=1.0)
-    st3 = _states(50, 9, s_hi=float(c2.coef[0, -1]) * 0.9)
-    ob3 = np.stack([rng.uniform(wx[0], wx[-1], 30), rng.uniform(-8, 8, 30)], axis=1).astype(np.float32)
-    o = oracle_mod.frenet_plan(st3, c2.coef, ob3, cfg=oracle_mod.frenet_config(**kw))
-    r = crx.frenet_optimal_planning(_t(st3), c2, _t(ob3), _cfg(crx, **kw), want_paths=True)
-    assert r["path_cf"].shape[1] == o["n_paths"][0] == crx.frenet_num_paths(_cfg(crx, **kw))
-    assert _close(r["path_cf"].cpu().numpy(), o["path_cf"]) and (r["path_ok"].cpu().numpy() != o["path_ok"]).mean() < 1e-3
-    assert (r["best_idx"].cpu().numpy() == o["best"]).mean() > 0.95
+    for kw in (dict(max_road_width=4.0, d_road_w=0.5, mint=3.0, maxt=4.1, dt=0.25, n_s_sample=2, d_t_s=1.0, robot_radius=1.0),
+               dict(max_road_width=3.0, d_road_w=0.75, mint=2.1, maxt=3.0, dt=0.3, n_s_sample=1, d_t_s=2.0, robot_radius=0.7)):
+        st3 = _states(50, 9, s_hi=float(c2.coef[0, -1]) * 0.9)
+        ob3 = np.stack([rng.uniform(wx[0], wx[-1], 30), rng.uniform(-8, 8, 30)], axis=1).astype(np.float32)
+        o = oracle_mod.frenet_plan(st3, c2.coef, ob3, cfg=oracle_mod.frenet_config(**kw))
+        r = crx.frenet_optimal_planning(_t(st3), c2, _t(ob3), _cfg(crx, **kw), want_paths=True)
+        assert r["path_cf"].shape[1] == o["n_paths"][0] == crx.frenet_num_paths(_cfg(crx, **kw))
+        same(r, o)
 
 
 def test_frenet_empty_batch(crx, oracle_mod):

@@ -3,8 +3,8 @@
 oracle/_ref/libref.so (oracle/ref_build.sh: the cited line ranges of /root/reference compiled unmodified) is built in the
 development container and travels to the GPU box as a prebuilt file; nothing here reads /root/reference.  The other GPU tests
 compare the kernels with the oracle and tests/test_oracle_vs_ref.py the oracle with these lines — this file closes the triangle on
-the hot path itself: EKF, DARE / dlqr, the tracking closed loops, the dynamic-window episode (all bit for bit), and the MPC solution
-judged by the reference's FG_EVAL."""
+the hot path itself: EKF, DARE / dlqr, the tracking closed loops, the dynamic-window and Frenet episodes (all bit for bit), and the
+MPC solution judged by the reference's FG_EVAL."""
 import numpy as np
 import pytest
 
@@ -82,6 +82,37 @@ def test_dwa_episode_equals_the_reference_lines(crx, oracle_mod):
     assert _eq(ticks, tr) and _eq(sd.cpu().numpy(), sr) and _eq(ud.cpu().numpy(), ur)
     for a in range(n):
         assert _eq(hist[: tr[a], a], hr[: tr[a], a])
+
+
+def test_frenet_episode_equals_the_reference_lines(crx, oracle_mod):
+    """frenet_optimal_planning + the hand-over and goal test of main (:160-176, :224-236) compiled from the reference's own
+    lines (with its Spline2D / QuinticPolynomial / QuarticPolynomial headers), against the kernel: all 168 candidate costs and
+    verdicts of a first call, then whole episodes tick by tick — the reference's own scenario (agent 0) from start to goal."""
+    O = oracle_mod.oracle_lib
+    course = crx.FrenetCourse(O.FRENET_WX, O.FRENET_WY)
+    assert _eq(course.coef, R.frenet_spline_build(O.FRENET_WX, O.FRENET_WY))      # the spline table of the C ABI == Spline2D's
+    ob, goal = O.FRENET_OBSTACLES, course.goal
+    n = 12
+    rng = np.random.default_rng(77)
+    st = np.stack([rng.uniform(0.0, 40.0, n), rng.uniform(1.0, 9.0, n), rng.uniform(-3.0, 3.0, n), rng.uniform(-0.8, 0.8, n),
+                   rng.uniform(-0.5, 0.5, n)], axis=1).astype(np.float32)
+    st[0] = O.FRENET_STATE0                                                       # the reference's start (:215-219)
+    r1 = R.frenet_run(st, O.FRENET_WX, O.FRENET_WY, goal, ob, 1, want_paths=True, cap=168)
+    k1 = crx.frenet_optimal_planning(_t(st), course, _t(ob), want_paths=True)
+    assert (r1["n_paths"] == 168).all()
+    assert _eq(k1["path_cf"].cpu().numpy(), r1["path_cf"]) and _eq(k1["path_ok"].cpu().numpy(), r1["path_ok"])
+    # 25 ticks for everybody (the reference's lines run into undefined behaviour once a path leaves the course: an agent that
+    # drives off its end cannot be followed further), the reference's own scenario from start to goal
+    for sel, max_ticks in ((slice(0, n), 25), (slice(0, 1), 200)):
+        rr = R.frenet_run(st[sel], O.FRENET_WX, O.FRENET_WY, goal, ob, max_ticks)
+        sd = _t(st[sel])
+        k = crx.frenet_run(sd, course, _t(ob), max_ticks, want_hist=True)
+        ticks, hist = k["ticks"].cpu().numpy(), k["hist"].cpu().numpy()
+        assert _eq(ticks, rr["ticks"]) and _eq(k["status"].cpu().numpy() & 1, rr["status"] & 1)
+        for a in range(len(ticks)):
+            assert _eq(hist[: ticks[a], a], rr["hist"][: ticks[a], a]), a
+        assert _eq(sd.cpu().numpy(), rr["state"])
+    assert rr["status"][0] == 0 and rr["ticks"][0] == 98                          # the reference's scenario reaches its goal in 98 calls
 
 
 @pytest.mark.parametrize("T", [6, 21])

@@ -354,6 +354,34 @@ def pf_step(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=No
     return px, pw, xEst, PEst, res, anc
 
 
+def pf_gauss_likelihood(x, sigma):
+    x, sigma = _f32(x), _f32(sigma)
+    out = np.zeros_like(x)
+    _pf_lib().oracle_pf_gauss_likelihood(_I(len(x)), _p(x), _p(sigma), _p(out))
+    return out
+
+
+def pf_calc_covariance(xEst, px, pw):
+    """calc_covariance for one vehicle: xEst [4], px [NP,4], pw [NP] -> PEst [16] column-major."""
+    px = _f32(px)
+    out = np.zeros(16, np.float32)
+    _pf_lib().oracle_pf_calc_covariance(_I(px.shape[0]), _p(_f32(xEst)), _p(px), _p(_f32(pw)), _p(out))
+    return out
+
+
+def pf_step_parts(px, pw, obs, nobs, u, nrm, uni, parts, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None):
+    """parts = 1: pf_localization only; 2: resampling only (on px, pw as given); 3: both.  Arguments and results as pf_step."""
+    px, pw = _f32(px).copy(), _f32(pw).copy()
+    obs, u, nrm, uni = _f32(obs), _f32(u), _f32(nrm), _f32(uni)
+    nobs = np.ascontiguousarray(nobs, dtype=np.int32)
+    n, NP, L = px.shape[0], px.shape[1], obs.shape[1]
+    xEst = np.zeros((n, 4), np.float32); PEst = np.zeros((n, 16), np.float32)
+    res = np.zeros(n, np.int32); anc = np.zeros((n, NP), np.int32)
+    _pf_lib().oracle_pf_step_parts(_I(n), _I(NP), _I(L), _p(px), _p(pw), _p(xEst), _p(PEst), _p(obs), _p(nobs), _p(u), _p(nrm), _p(uni),
+                                   _p(_f32(rsim)), _F(Q), _D(dt), _F(NP / 2 if nth is None else nth), _p(res), _p(anc), _I(0), _I(n), _I(parts))
+    return px, pw, xEst, PEst, res, anc
+
+
 def pf_run(px, pw, obs, nobs, u, nrm, uni, rsim=PF_RSIM, Q=0.01, dt=0.1, nth=None, agents=None, wave_order=False):
     """T ticks.  obs [T,n,L,3], nobs [T,n], u [T,n,2], nrm [T,n,NP,2], uni [T,n,NP].
     Returns (px, pw, xEst, PEst, x_hist [T,n,4], n_resampled [n])."""

@@ -3,16 +3,20 @@
 //
 // CPU restatement of the reference's particle-filter localisation, /root/reference/src/particle_filter.cpp:
 //   motion_model :26-40 (same as the EKF's), gauss_likelihood :53-57, calc_covariance :59-71,
-//   pf_localization :73-109, cumsum :111-118, resampling :120-148, and the observation side of main() :248-268.
+//   pf_localization :73-109, cumsum :111-118, resampling :120-148, and the observation side of main() :251-268.
 // The reference draws its noise from std::mt19937 inside these functions (and passes the generator BY VALUE, so
 // every call replays the same stream); here all random numbers are caller-supplied arrays, so that CPU and GPU
 // consume identical draws:  nrm[t][a][ip][2] standard normals (motion noise, :87-88),  uni[t][a][j] uniforms in
 // [1,2) (uni_d{1.0, 2.0} :242, used as uni/NP :133).
-// PARITY-UNPINNED with respect to the reference's sums: its reductions (pw.sum(), px*pw, pw'*pw) go through Eigen's vectorised
-// redux / gemv kernels whose accumulation order is not restated here.  oracle_pf_step takes them in plain index order (the
-// engine is compared with it statistically); oracle_pf_step_wave takes them in the engine's order (balanced
-// tree over 64 lanes) and the engine is demanded equal to it bit for bit — everything else of a tick (motion model, likelihood,
-// normalisation, covariance terms, Neff test, low-variance resampling) is the reference's arithmetic in both.
+// PINNED against the reference's own lines (oracle/ref_build.sh compiles particle_filter.cpp:25-148 and the loop of main()
+// unmodified into oracle/_ref/libref.so, random draws injected; tests/test_oracle_vs_ref.py::test_pf_* demand equal bits) for
+// everything but THREE sums: pw.sum() (:104), px * pw (:106) and pw.transpose() * pw (:126) are 100-term reductions that Eigen
+// evaluates with its vectorised redux / gemv kernels, whose accumulation order is not restated here (PARITY-UNPINNED, those
+// three only).  oracle_pf_step takes them in plain index order; against the reference's lines they are compared at 2e-6
+// (relative, floored by the largest entry), and bit for bit wherever the order cannot matter (at most two non-zero weights).
+// oracle_pf_step_wave takes them in the engine's order (balanced tree over 64 lanes) and the engine is demanded equal to it bit
+// for bit — everything else of a tick (motion model, likelihood, normalisation, covariance terms, Neff test, low-variance
+// resampling) is the reference's arithmetic in both.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -45,75 +49,99 @@ extern "C" {
 
 void oracle_pf_set_trig_mode(int m) { g_trig = m; }
 
+void oracle_pf_gauss_likelihood(int n, const float* x, const float* sigma, float* out) {
+  for (int i = 0; i < n; ++i) out[i] = gauss_likelihood(x[i], sigma[i]);
+}
+
+// calc_covariance :59-71 for one vehicle: PEst_ += pw(i) * dx * dx.transpose(), particle after particle
+void oracle_pf_calc_covariance(int NP, const float* xe, const float* X, const float* W, float* Pe) {
+  std::memset(Pe, 0, sizeof(float) * 16);
+  for (int i = 0; i < NP; ++i) {
+    float dx[4]; for (int r = 0; r < 4; ++r) dx[r] = X[4 * i + r] - xe[r];
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) Pe[r + 4 * c] += (W[i] * dx[r]) * dx[c];
+  }
+}
+
+// pf_localization :73-109 for one vehicle.  X [NP][4], W [NP] in/out; Z [nz][3]; nrm [NP][2]
+static void pf_localization_one(int NP, float* X, float* W, float* xe, float* Pe, const float* Z, int nz, const float* u,
+                                const float* nrm, const float* rsim, float Q, double DT) {
+  const float sig = std::sqrt(Q);                                     // std::sqrt(Q) :98
+  for (int ip = 0; ip < NP; ++ip) {                                   // :81
+    float x[4] = {X[4 * ip], X[4 * ip + 1], X[4 * ip + 2], X[4 * ip + 3]};
+    float w = W[ip];
+    float ud[2];
+    ud[0] = u[0] + (double)nrm[2 * ip] * rsim[0];                     // :87  gaussian_d(gen) is a double
+    ud[1] = u[1] + (double)nrm[2 * ip + 1] * rsim[1];
+    motion_model(x, ud, DT);                                          // :90
+    for (int i = 0; i < nz; ++i) {                                    // :92
+      float dx = x[0] - Z[3 * i + 1];
+      float dy = x[1] - Z[3 * i + 2];
+      float prez = std::sqrt(dx * dx + dy * dy);
+      float dz = prez - Z[3 * i];
+      w = w * gauss_likelihood(dz, sig);
+    }
+    X[4 * ip] = x[0]; X[4 * ip + 1] = x[1]; X[4 * ip + 2] = x[2]; X[4 * ip + 3] = x[3];
+    W[ip] = w;
+  }
+  float s = 0.0f;
+  for (int i = 0; i < NP; ++i) s += W[i];                             // pw.sum(): index order here (header)
+  for (int i = 0; i < NP; ++i) W[i] = W[i] / s;                       // pw = pw / pw.sum() :104
+  xe[0] = xe[1] = xe[2] = xe[3] = 0.0f;
+  for (int i = 0; i < NP; ++i) for (int r = 0; r < 4; ++r) xe[r] += X[4 * i + r] * W[i];   // xEst = px * pw :106, index order (header)
+  oracle_pf_calc_covariance(NP, xe, X, W, Pe);                        // :107
+}
+
+// resampling :120-148 for one vehicle.  Returns 1 if it resampled; anc (may be NULL) [NP]: the ancestor of each particle.
+static int pf_resampling_one(int NP, float* X, float* W, const float* uni, float nth, int* anc) {
+  std::vector<float> wcum(NP), base(NP), rid(NP), out((size_t)NP * 4);
+  float ww = 0.0f;
+  for (int i = 0; i < NP; ++i) ww += W[i] * W[i];                     // pw.transpose() * pw: index order here (header)
+  float Neff = 1.0 / ww;                                              // :126
+  if (anc) for (int i = 0; i < NP; ++i) anc[i] = i;
+  if (!(Neff < nth)) return 0;                                        // :127
+  wcum[0] = W[0];
+  for (int i = 1; i < NP; ++i) wcum[i] = wcum[i - 1] + W[i];          // cumsum :111-118
+  const float inv = (float)(1.0 / NP);                                // Ones()*1.0/NP
+  float c = W[0] * 0.0f + inv;                                        // pw*0.0 + Ones*1.0/NP
+  base[0] = c - inv;
+  for (int i = 1; i < NP; ++i) { c = c + (W[i] * 0.0f + inv); base[i] = c - inv; }
+  for (int j = 0; j < NP; ++j) rid[j] = base[j] + (double)uni[j] / NP;   // :133  uni_d(gen) is a double
+  int ind = 0;
+  for (int i = 0; i < NP; ++i) {                                      // :138-143
+    while (rid[i] > wcum[ind] && ind < NP - 1) ind += 1;
+    std::memcpy(&out[4 * (size_t)i], &X[4 * ind], 16);
+    if (anc) anc[i] = ind;
+  }
+  std::memcpy(X, out.data(), sizeof(float) * 4 * NP);
+  for (int i = 0; i < NP; ++i) W[i] = inv;                            // :146
+  return 1;
+}
+
 // One vehicle-tick for agents [a0,a1): pf_localization (:73-109) then resampling (:120-148).
 // px: [n][NP][4] (Eigen Matrix<float,4,NP> column-major = particle-major), pw: [n][NP], xEst [n][4], PEst [n][16] col-major,
 // obs: [n][L][3] = (dn, landmark x, landmark y), nobs[n] <= L, u [n][2], nrm [n][NP][2], uni [n][NP],
 // rsim[2] = (Rsim(0,0), Rsim(1,1)), Q, DT, nth = NP/2.  resampled[n] (may be NULL): 1 if the tick resampled.
 // anc (may be NULL): [n][NP] ancestor index chosen for each particle (identity when not resampled).
-void oracle_pf_step(int n, int NP, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs, const int* nobs,
-                    const float* u, const float* nrm, const float* uni, const float* rsim, float Q, double DT, float nth,
-                    int* resampled, int* anc, int a0, int a1) {
-  std::vector<float> wcum(NP), base(NP), rid(NP), out((size_t)NP * 4);
+// parts: 3 = the whole tick, 1 = pf_localization only, 2 = resampling only (px, pw as given).
+void oracle_pf_step_parts(int n, int NP, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs, const int* nobs,
+                          const float* u, const float* nrm, const float* uni, const float* rsim, float Q, double DT, float nth,
+                          int* resampled, int* anc, int a0, int a1, int parts) {
   for (int a = a0; a < a1; ++a) {
     float* X = px + (size_t)a * NP * 4;
     float* W = pw + (size_t)a * NP;
-    const float* Z = obs + (size_t)a * L * 3;
-    const float sig = std::sqrt(Q);                                   // std::sqrt(Q) :98
-    for (int ip = 0; ip < NP; ++ip) {                                 // :81
-      float x[4] = {X[4 * ip], X[4 * ip + 1], X[4 * ip + 2], X[4 * ip + 3]};
-      float w = W[ip];
-      float ud[2];
-      ud[0] = u[2 * a] + (double)nrm[((size_t)a * NP + ip) * 2] * rsim[0];    // :87  gaussian_d(gen) is a double
-      ud[1] = u[2 * a + 1] + (double)nrm[((size_t)a * NP + ip) * 2 + 1] * rsim[1];
-      motion_model(x, ud, DT);                                        // :90
-      for (int i = 0; i < nobs[a]; ++i) {                             // :92
-        float dx = x[0] - Z[3 * i + 1];
-        float dy = x[1] - Z[3 * i + 2];
-        float prez = std::sqrt(dx * dx + dy * dy);
-        float dz = prez - Z[3 * i];
-        w = w * gauss_likelihood(dz, sig);
-      }
-      X[4 * ip] = x[0]; X[4 * ip + 1] = x[1]; X[4 * ip + 2] = x[2]; X[4 * ip + 3] = x[3];
-      W[ip] = w;
-    }
-    float s = 0.0f;
-    for (int i = 0; i < NP; ++i) s += W[i];
-    for (int i = 0; i < NP; ++i) W[i] = W[i] / s;                     // pw = pw / pw.sum() :104
-    float xe[4] = {0, 0, 0, 0};
-    for (int i = 0; i < NP; ++i) for (int r = 0; r < 4; ++r) xe[r] += X[4 * i + r] * W[i];   // xEst = px * pw :106
-    float Pe[16]; std::memset(Pe, 0, sizeof(Pe));
-    for (int i = 0; i < NP; ++i) {                                    // calc_covariance :64-68
-      float dx[4]; for (int r = 0; r < 4; ++r) dx[r] = X[4 * i + r] - xe[r];
-      for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) Pe[r + 4 * c] += (W[i] * dx[r]) * dx[c];
-    }
-    std::memcpy(xEst + 4 * (size_t)a, xe, sizeof(xe));
-    std::memcpy(PEst + 16 * (size_t)a, Pe, sizeof(Pe));
-    // resampling :120-148
-    float ww = 0.0f;
-    for (int i = 0; i < NP; ++i) ww += W[i] * W[i];
-    float Neff = 1.0 / ww;                                            // :126
+    if (parts & 1)
+      pf_localization_one(NP, X, W, xEst + 4 * (size_t)a, PEst + 16 * (size_t)a, obs + (size_t)a * L * 3, nobs[a], u + 2 * (size_t)a,
+                          nrm + (size_t)a * NP * 2, rsim, Q, DT);
     int did = 0;
     if (anc) for (int i = 0; i < NP; ++i) anc[(size_t)a * NP + i] = i;
-    if (Neff < nth) {                                                 // :127
-      did = 1;
-      wcum[0] = W[0];
-      for (int i = 1; i < NP; ++i) wcum[i] = wcum[i - 1] + W[i];      // cumsum :111-118
-      const float inv = (float)(1.0 / NP);                            // Ones()*1.0/NP
-      float c = W[0] * 0.0f + inv;                                    // pw*0.0 + Ones*1.0/NP
-      base[0] = c - inv;
-      for (int i = 1; i < NP; ++i) { c = c + (W[i] * 0.0f + inv); base[i] = c - inv; }
-      for (int j = 0; j < NP; ++j) rid[j] = base[j] + (double)uni[(size_t)a * NP + j] / NP;   // :133  uni_d(gen) is a double
-      int ind = 0;
-      for (int i = 0; i < NP; ++i) {                                  // :138-143
-        while (rid[i] > wcum[ind] && ind < NP - 1) ind += 1;
-        std::memcpy(&out[4 * (size_t)i], &X[4 * ind], 16);
-        if (anc) anc[(size_t)a * NP + i] = ind;
-      }
-      std::memcpy(X, out.data(), sizeof(float) * 4 * NP);
-      for (int i = 0; i < NP; ++i) W[i] = inv;                        // :146
-    }
+    if (parts & 2) did = pf_resampling_one(NP, X, W, uni + (size_t)a * NP, nth, anc ? anc + (size_t)a * NP : nullptr);
     if (resampled) resampled[a] = did;
   }
+}
+void oracle_pf_step(int n, int NP, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs, const int* nobs,
+                    const float* u, const float* nrm, const float* uni, const float* rsim, float Q, double DT, float nth,
+                    int* resampled, int* anc, int a0, int a1) {
+  oracle_pf_step_parts(n, NP, L, px, pw, xEst, PEst, obs, nobs, u, nrm, uni, rsim, Q, DT, nth, resampled, anc, a0, a1, 3);
 }
 
 // ---- the same tick with the sums taken in the ENGINE's order ------------------------------------------------------------------
@@ -249,7 +277,7 @@ void oracle_pf_run(int n, int NP, int L, int T, float* px, float* pw, float* xEs
   }
 }
 
-// The observation side of main() (:248-268): ud, xTrue, xDR and the range observations of the landmarks within MAX_RANGE.
+// The observation side of main() (:251-268): ud, xTrue, xDR and the range observations of the landmarks within MAX_RANGE.
 // w_u [T][n][2] normals for ud, w_z [T][n][L] normals for the range noise.  Outputs: ud [T][n][2], obs, nobs, xTrue_hist.
 void oracle_pf_simulate_inputs(int n, int T, int L, const float* u_true, float* xTrue, float* xDR, const float* rfid,
                                const float* w_u, const float* w_z, const float* rsim, float Qsim, float max_range,

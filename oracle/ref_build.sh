@@ -61,6 +61,11 @@ ext src/dynamic_window_approach.cpp 43 155 dwa_fns.inc           # motion … dw
 # ---- src/frenet_optimal_trajectory.cpp (+ the headers it includes, taken from $REF/include as they are)
 ext src/frenet_optimal_trajectory.cpp 20 38 frenet_defs.inc      # SIM_LOOP … KLON
 ext src/frenet_optimal_trajectory.cpp 40 176 frenet_fns.inc      # using namespace, sum_of_power … frenet_optimal_planning
+# ---- src/particle_filter.cpp
+ext src/particle_filter.cpp 17 22 pf_defs.inc                    # SIM_TIME, DT, PI, MAX_RANGE, NP, NTh
+ext src/particle_filter.cpp 25 148 pf_fns.inc                    # motion_model … resampling
+ext src/particle_filter.cpp 179 235 pf_main_setup.inc            # time, u, ud, z, RFID, xDR, xTrue, xEst, PEst, Q, R, Qsim, Rsim, px, pw
+ext src/particle_filter.cpp 249 271 pf_main_body.inc             # one pass of the while loop up to resampling(...)
 
 if echo '#include <Eigen/Eigen>' | g++ -x c++ -fsyntax-only - 2>/dev/null; then EIGEN_INC=""; KIND=1
 elif [ -f /usr/include/eigen3/Eigen/Eigen ]; then EIGEN_INC="-I/usr/include/eigen3"; KIND=1

@@ -334,3 +334,67 @@ def main_course(wx, wy, which="lqr"):
     f.restype = _I
     k = f(_p(wx), _p(wy), _I(len(wx)), *[_p(a) for a in out], _I(cap))
     return tuple(a[:k] for a in out)
+
+
+# ---- particle filter (src/particle_filter.cpp:25-148 and the loop of main) --------------------------------------------------------
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def pf_np():
+    lib().ref_pf_np.restype = _I
+    return lib().ref_pf_np()
+
+
+def pf_motion_model(x, u):
+    x, u = _f32(x), _f32(u)
+    out = np.zeros_like(x)
+    lib().ref_pf_motion_model(_I(len(x)), _p(x), _p(u), _p(out))
+    return out
+
+
+def pf_gauss_likelihood(x, sigma):
+    x, sigma = _f32(x), _f32(sigma)
+    out = np.zeros_like(x)
+    lib().ref_pf_gauss_likelihood(_I(len(x)), _p(x), _p(sigma), _p(out))
+    return out
+
+
+def pf_calc_covariance(xEst, px, pw):
+    out = np.zeros(16, np.float32)
+    lib().ref_pf_calc_covariance(_p(_f32(xEst)), _p(_f32(px)), _p(_f32(pw)), _p(out))
+    return out
+
+
+def pf_cumsum(pw):
+    out = np.zeros(pf_np(), np.float32)
+    lib().ref_pf_cumsum(_p(_f32(pw)), _p(out))
+    return out
+
+
+def pf_localization(px, pw, z, u, nrm, rsim=(1.0, 0.0, 0.0, 1.0), Q=0.01):
+    """One pf_localization call for one vehicle.  px [NP,4], pw [NP], z [nz,3], u [2], nrm [NP,2] (the normal draws, in the order
+    the function consumes them), rsim = Rsim column-major.  -> px, pw, xEst, PEst."""
+    px, pw, z = _f32(px).copy(), _f32(pw).copy(), _f32(z).reshape(-1, 3)
+    xEst, PEst = np.zeros(4, np.float32), np.zeros(16, np.float32)
+    lib().ref_pf_localization(_p(px), _p(pw), _p(xEst), _p(PEst), _p(z), _I(len(z)), _p(_f32(u)), _p(_f32(rsim)), _F(Q), _p(_f64(nrm)))
+    return px, pw, xEst, PEst
+
+
+def pf_resampling(px, pw, uni):
+    px, pw = _f32(px).copy(), _f32(pw).copy()
+    lib().ref_pf_resampling(_p(px), _p(pw), _p(_f64(uni)))
+    return px, pw
+
+
+def pf_main(steps, w, uni):
+    """main() :179-235 and `steps` passes of its loop :249-271 on the caller's streams (see oracle/ref_shim/ref_pf.cpp)."""
+    NP = pf_np()
+    o = dict(ud=np.zeros((steps, 2), np.float32), xTrue=np.zeros((steps, 4), np.float32), xDR=np.zeros((steps, 4), np.float32),
+             z=np.zeros((steps, 4, 3), np.float32), nz=np.zeros(steps, np.int32), xEst=np.zeros((steps, 4), np.float32),
+             PEst=np.zeros((steps, 16), np.float32), px=np.zeros((steps, NP, 4), np.float32), pw=np.zeros((steps, NP), np.float32),
+             consts=np.zeros(6, np.float32))
+    f = lib().ref_pf_main
+    f.restype = C.c_long
+    o["draws_used"] = f(_I(steps), _p(_f64(w)), _p(_f64(uni)), *[_p(o[k]) for k in ("ud", "xTrue", "xDR", "z", "nz", "xEst", "PEst", "px", "pw", "consts")])
+    return o

@@ -392,3 +392,159 @@ def test_which_reference_call_sites_depend_on_the_coefficient_path_order(oracle_
             assert same(base["loop5"], other["loop5"])
         # the 4-state loop: same tick counts, states within a few float ulps (one ulp of the steering command per tick)
         assert _eq(base["loop4"][1], other["loop4"][1]) and np.abs(base["loop4"][0] - other["loop4"][0]).max() < 1e-5
+
+
+# ---- particle filter ------------------------------------------------------------------------------------------------------------
+# Bit equality for every statement of src/particle_filter.cpp:25-148 but three 100-term sums — pw.sum() (:104), px * pw (:106),
+# pw.transpose() * pw (:126) — which Eigen evaluates with vectorised redux / gemv kernels whose order is not restated
+# (oracle/pf_ref.cpp takes them in index order).  Those three are compared at PF_SUM_TOL, relative to the largest entry, and bit
+# for bit where the order cannot matter (two non-zero weights).
+PF_SUM_TOL = 2e-6
+NPF = 100
+
+
+def _pf_close(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.max(np.abs(a - b)) <= PF_SUM_TOL * max(1.0, np.max(np.abs(b)))
+
+
+def _pf_case(rng, spread=1.0):
+    px = np.stack([rng.normal(3, spread, NPF), rng.normal(4, spread, NPF), rng.uniform(-3.2, 3.2, NPF), rng.normal(1, 0.3, NPF)], axis=1).astype(np.float32)
+    pw = rng.uniform(0.2, 1.0, NPF).astype(np.float32); pw /= pw.sum()
+    nz = int(rng.integers(0, 5))
+    rfid = np.array([[10.0, 0.0], [10.0, 10.0], [0.0, 15.0], [-5.0, 20.0]], np.float32)[:nz]
+    z = np.concatenate([(np.hypot(3 - rfid[:, :1], 4 - rfid[:, 1:]) + rng.normal(0, 0.2, (nz, 1))).astype(np.float32), rfid], axis=1) if nz else np.zeros((0, 3), np.float32)
+    u = np.array([1.0, 0.1], np.float32)
+    nrm = rng.standard_normal((NPF, 2)).astype(np.float32)
+    return px, pw.astype(np.float32), z.astype(np.float32), u, nrm
+
+
+def _pf_oracle_loc(o, px, pw, z, u, nrm, rsim2):
+    obs = np.zeros((1, 4, 3), np.float32); obs[0, : len(z)] = z
+    p, w, xe, Pe, _, _ = o.pf_step_parts(px[None], pw[None], obs, np.array([len(z)], np.int32), u[None], nrm[None], np.ones((1, NPF), np.float32), 1, rsim=rsim2)
+    return p[0], w[0], xe[0], Pe[0]
+
+
+def test_pf_small_functions(host_trig):
+    o = host_trig
+    assert R.pf_np() == NPF
+    rng = np.random.default_rng(70)
+    n = 4000
+    x = np.stack([rng.normal(0, 50, n), rng.normal(0, 50, n), rng.uniform(-200, 200, n), rng.normal(0, 5, n)], axis=1).astype(np.float32)
+    x[:6, 2] = [0.0, -0.0, 1e-30, 3.1415927, 1e6, 120.1]
+    u = np.stack([rng.normal(1, 2, n), rng.normal(0, 1, n)], axis=1).astype(np.float32)
+    assert _eq(o.motion_model(x, u, trig=0), R.pf_motion_model(x, u))                      # :26-40, the EKF file's motion model again
+    dz = np.concatenate([rng.normal(0, 0.3, n), rng.normal(0, 30, n), [0.0, -0.0, 1e-20, 50.0, np.inf]]).astype(np.float32)
+    sg = np.concatenate([np.full(n, np.sqrt(np.float32(0.01)), np.float32), rng.uniform(0.01, 3.0, n).astype(np.float32), np.full(5, 0.1, np.float32)])
+    assert np.array_equal(o.pf_gauss_likelihood(dz, sg), R.pf_gauss_likelihood(dz, sg), equal_nan=True)   # :53-57
+    for _ in range(20):                                                                   # calc_covariance :59-71: sequential, exact
+        px, pw, *_ = _pf_case(rng, spread=rng.uniform(0.1, 5.0))
+        xe = rng.normal(3, 1, 4).astype(np.float32)
+        assert _eq(o.pf_calc_covariance(xe, px, pw), R.pf_calc_covariance(xe, px, pw))
+
+
+def test_pf_localization_two_live_particles_bit_exact(host_trig):
+    """With at most two non-zero weights every sum of a tick has at most two non-zero terms: the whole pf_localization + resampling
+    is order-independent and must equal the reference's lines bit for bit (weights, estimate, covariance, ancestors)."""
+    o = host_trig
+    rng = np.random.default_rng(71)
+    rsim = (1.0, 0.0, 0.0, float(np.float32(o.oracle_lib.PF_RSIM[1])))
+    resampled = 0
+    for k in range(200):
+        px, pw, z, u, nrm = _pf_case(rng)
+        live = rng.choice(NPF, 2 if k % 4 else 1, replace=False)
+        w2 = np.zeros(NPF, np.float32); w2[live] = rng.uniform(0.1, 1.0, len(live)).astype(np.float32)
+        px[live, :2] = (np.array([3.0, 4.0]) + rng.normal(0, 0.05, (len(live), 2))).astype(np.float32)   # near the truth: weights that do not underflow
+        nrm[live] *= 0.05
+        pr, wr, xr, Pr = R.pf_localization(px, w2, z, u, nrm, rsim=rsim)
+        po, wo, xo, Po = _pf_oracle_loc(o, px, w2, z, u, nrm, (rsim[0], rsim[3]))
+        assert np.isfinite(wr).all() and (wr > 0).sum() == len(live), k
+        assert _eq(po, pr) and _eq(wo, wr) and _eq(xo, xr) and _eq(Po, Pr), k
+        uni = rng.uniform(1.0, 2.0, NPF).astype(np.float32)
+        p2r, w2r = R.pf_resampling(pr, wr, uni)
+        p2o, w2o, _, _, did, _ = o.pf_step_parts(po[None], wo[None], np.zeros((1, 4, 3), np.float32), np.zeros(1, np.int32), u[None], nrm[None], uni[None], 2)
+        assert _eq(p2o[0], p2r) and _eq(w2o[0], w2r), k
+        resampled += int(did[0])
+    assert resampled == 200                                   # Neff <= 2 < NTh: every case resamples
+
+
+def test_pf_localization_general(host_trig):
+    """100 live particles: the motion of every particle bit for bit; the normalised weights, the estimate and the covariance
+    through the three unpinned sums at PF_SUM_TOL."""
+    o = host_trig
+    rng = np.random.default_rng(72)
+    rsim = (1.0, 0.0, 0.0, float(np.float32(o.oracle_lib.PF_RSIM[1])))
+    for k in range(60):
+        px, pw, z, u, nrm = _pf_case(rng, spread=rng.uniform(0.2, 3.0))
+        pr, wr, xr, Pr = R.pf_localization(px, pw, z, u, nrm, rsim=rsim)
+        po, wo, xo, Po = _pf_oracle_loc(o, px, pw, z, u, nrm, (rsim[0], rsim[3]))
+        assert _eq(po, pr), k                                 # px.col(ip) = motion_model(x, ud): exact
+        assert _pf_close(wo / wo.max(), wr / wr.max()) and _pf_close(xo, xr) and _pf_close(Po, Pr), k
+        # the covariance given the reference's own estimate and weights: exact (sequential sum, :64-68)
+        assert _eq(o.pf_calc_covariance(xr, pr, wr), Pr), k
+
+
+def test_pf_resampling_on_given_weights(host_trig):
+    """resampling() on identical weights: cumsum, the comb `base + uni/NP`, the ancestor walk and the reset of the weights — bit for
+    bit; the Neff test itself rests on pw'pw (unpinned sum), so the cases keep clear of NTh = 50."""
+    o = host_trig
+    rng = np.random.default_rng(73)
+    did_any = [0, 0]
+    for k in range(120):
+        px, _, _, u, nrm = _pf_case(rng)
+        if k % 3 == 0:
+            pw = rng.uniform(0.9, 1.0, NPF)                                   # nearly uniform: Neff ~ 99, no resampling
+        else:
+            pw = rng.exponential(1.0, NPF) ** rng.uniform(2.0, 6.0)           # peaked: Neff of a few
+        pw = (pw / pw.sum()).astype(np.float32)
+        neff = 1.0 / float(np.sum(pw.astype(np.float64) ** 2))
+        assert abs(neff - 50.0) > 5.0
+        uni = rng.uniform(1.0, 2.0, NPF).astype(np.float32)
+        assert _eq(np.cumsum(pw, dtype=np.float32), R.pf_cumsum(pw))                        # cumsum :111-118 (numpy's is sequential too)
+        pr, wr = R.pf_resampling(px, pw, uni)
+        po, wo, _, _, did, anc = o.pf_step_parts(px[None], pw[None], np.zeros((1, 4, 3), np.float32), np.zeros(1, np.int32), u[None], nrm[None], uni[None], 2)
+        assert _eq(po[0], pr) and _eq(wo[0], wr), k
+        assert (did[0] == 1) == (neff < 50.0) and _eq(po[0], px[anc[0]])
+        did_any[int(did[0])] += 1
+    assert did_any[0] >= 30 and did_any[1] >= 60
+
+
+def test_pf_main_loop_input_side_and_first_ticks(host_trig):
+    """main() of particle_filter.cpp on an injected stream: the constants (:220-230), the input side of every pass (:251-268: ud,
+    xTrue, xDR, the range observations of the landmarks in sight) bit for bit for 300 passes, and the filter itself — called with
+    the generator and the distributions BY VALUE (:270-271): its 2*NP draws are the stream positions main uses next, and every
+    resampling call sees the same uniforms — through the first passes at PF_SUM_TOL."""
+    o = host_trig
+    O = o.oracle_lib
+    steps = 300
+    rng = np.random.default_rng(74)
+    w = rng.standard_normal(8 * steps + 2 * NPF + 8).astype(np.float32)
+    uni = rng.uniform(1.0, 2.0, NPF).astype(np.float32)
+    r = R.pf_main(steps, w, uni)
+    c = r["consts"]
+    assert c[0] == np.float32(0.01) and c[1] == np.float32(0.04) and c[2] == np.float32(O.PF_RSIM[0]) and c[3] == np.float32(O.PF_RSIM[1])
+    # replay: which stream positions main consumed is decided by how many landmarks were in sight
+    u = np.array([[1.0, 0.1]], np.float32)
+    k = 0
+    xT = np.zeros((1, 4), np.float32); xD = np.zeros((1, 4), np.float32)
+    px = np.zeros((1, NPF, 4), np.float32); pw = np.full((1, NPF), np.float32(1.0 / NPF), np.float32)
+    seen_counts = set()
+    for t in range(steps):
+        w_u = w[k:k + 2].reshape(1, 1, 2)
+        nz = int(r["nz"][t])
+        seen_counts.add(nz)
+        # the oracle draws one range noise per landmark slot; main draws only for the landmarks in sight, in landmark order
+        xt_next = o.motion_model(xT, u, trig=0)
+        d = np.hypot(xt_next[0, 0] - O.PF_RFID[:, 0], xt_next[0, 1] - O.PF_RFID[:, 1])
+        w_z = np.zeros((1, 1, 4), np.float32)
+        w_z[0, 0, np.flatnonzero(d <= 20.0)[:nz]] = w[k + 2:k + 2 + nz]
+        ud, obs, nobs, xth, xdh = o.pf_simulate_inputs(u, xT, xD, w_u, w_z)
+        assert nobs[0, 0] == nz
+        assert _eq(ud[0, 0], r["ud"][t]) and _eq(xth[0, 0], r["xTrue"][t]) and _eq(xdh[0, 0], r["xDR"][t]) and _eq(obs[0, 0], r["z"][t]), t
+        xT, xD = xth[0], xdh[0]
+        k += 2 + nz
+        if t < 12:        # the filter: its copy of the stream starts where main stands now (and main does not advance past it)
+            nrm = w[k:k + 2 * NPF].reshape(1, NPF, 2)
+            px, pw, xe, Pe, did, _ = o.pf_step_parts(px, pw, obs[0], nobs[0], u, nrm, uni[None], 3)
+            assert _pf_close(px[0], r["px"][t]) and _pf_close(pw[0] * NPF, r["pw"][t] * NPF) and _pf_close(xe[0], r["xEst"][t]) and _pf_close(Pe[0], r["PEst"][t]), t
+    assert r["draws_used"] == k and len(seen_counts) >= 2

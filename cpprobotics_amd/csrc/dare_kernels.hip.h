@@ -28,7 +28,7 @@ namespace crx {
 
 // ---------- tiny register-matrix helpers (column-major, compile-time sizes) -------------------
 // Accumulation orders (see oracle/eigen_order.h for the derivation from Eigen's sources).
-enum { ORD_ASC = 0, ORD_TREE = 1, ORD_SSE4 = 2 };
+enum { ORD_ASC = 0, ORD_TREE = 1, ORD_SSE4 = 2, ORD_SLICE = 3 };   // ORD_SLICE: per row, see mm
 
 // redux_novec_unroller: sum(start,len) = sum(start,len/2) + sum(start+len/2, len-len/2)
 template <int START, int LEN>
@@ -61,6 +61,8 @@ __device__ __forceinline__ float sum_terms(const float (&t)[K]) {
 }
 
 // out(RxC) = A(RxK) * B(KxC);  TA/TB: read A/B through a transposed view of the stored matrix.
+// ORD_SLICE: a column-major left factor with R >= 4, R % 4 != 0 rows (SliceVectorizedTraversal with inner unrolling): the first
+// (R/4)*4 rows of every column are packet sums (ascending), the remaining rows coeff() reduxes (the unrolled tree).
 template <int R, int K, int C, bool TA, bool TB, int ORD>
 __device__ __forceinline__ void mm(const float* __restrict__ A, const float* __restrict__ B,
                                    float* __restrict__ out) {
@@ -75,7 +77,8 @@ __device__ __forceinline__ void mm(const float* __restrict__ A, const float* __r
         const float b = TB ? B[j + C * k] : B[k + K * j];
         t[k] = a * b;
       }
-      out[i + R * j] = sum_terms<K, ORD>(t);
+      if constexpr (ORD == ORD_SLICE) out[i + R * j] = (i < (R / 4) * 4) ? sum_terms<K, ORD_ASC>(t) : sum_terms<K, ORD_TREE>(t);
+      else out[i + R * j] = sum_terms<K, ORD>(t);
     }
 }
 
@@ -89,23 +92,25 @@ __device__ __forceinline__ void inverse2(const float* m, float* r) {
 }
 
 // ---------- dense 5x5 ------------------------------------------------------------------------
-// Eigen order for 5-row shapes: every product falls on the coefficient path; the redux is vectorised (SSE4: one packet +
-// the fifth term) where the left factor is a transposed view (A'*X, B'*X), the unrolled tree (TREE) elsewhere.
+// Eigen order for 5-row shapes (oracle/eigen_order.h): a transposed left factor (A'*X, B'*X) puts the product on the coefficient
+// path with a vectorised redux (SSE4: one packet + the fifth term); a column-major 5-row left factor is assigned by slices —
+// rows 0-3 of each column by packets (ascending), row 4 by the unrolled-tree redux (SLICE); a 2-row left factor stays on the
+// coefficient path (TREE).  Inner size 2 has one order.
 __device__ __forceinline__ void dare5_dense_iter(const float* A, const float* B, const float* Q,
                                                  const float* R, const float* X, float* Xn) {
   float AtX[25], P1[25], BtX[10], G[4], Sg[4], Si[4], c1[10], c2[10], c3[25], c4[25], P2[25];
   mm<5, 5, 5, true, false, ORD_SSE4>(A, X, AtX);
-  mm<5, 5, 5, false, false, ORD_TREE>(AtX, A, P1);
+  mm<5, 5, 5, false, false, ORD_SLICE>(AtX, A, P1);
   mm<2, 5, 5, true, false, ORD_SSE4>(B, X, BtX);
   mm<2, 5, 2, false, false, ORD_TREE>(BtX, B, G);
 #pragma unroll
   for (int i = 0; i < 4; ++i) Sg[i] = R[i] + G[i];
   inverse2(Sg, Si);
-  mm<5, 5, 2, false, false, ORD_TREE>(AtX, B, c1);
+  mm<5, 5, 2, false, false, ORD_SLICE>(AtX, B, c1);
   mm<5, 2, 2, false, false, ORD_TREE>(c1, Si, c2);
   mm<5, 2, 5, false, true, ORD_TREE>(c2, B, c3);
-  mm<5, 5, 5, false, false, ORD_TREE>(c3, X, c4);
-  mm<5, 5, 5, false, false, ORD_TREE>(c4, A, P2);
+  mm<5, 5, 5, false, false, ORD_SLICE>(c3, X, c4);
+  mm<5, 5, 5, false, false, ORD_SLICE>(c4, A, P2);
 #pragma unroll
   for (int i = 0; i < 25; ++i) Xn[i] = (P1[i] - P2[i]) + Q[i];
 }

@@ -18,10 +18,27 @@
 // (product_order() below states the decision generically; r, c, k = rows, cols, inner size;
 // a factor is "row-major" if it is a .transpose() of a column-major object or a plain row vector):
 //
-//   CanVectorizeLhs = lhs column-major && r % 4 == 0        CanVectorizeRhs = rhs row-major && c % 4 == 0
+//   CanVectorizeLhs = lhs column-major && r != 1            CanVectorizeRhs = rhs row-major && c != 1
+//     (ProductEvaluators.h: `(!LhsRowMajor) && (LhsFlags & PacketAccessBit) && (RowsAtCompileTime!=1)` — there is no `% 4`
+//      term: with EIGEN_UNALIGNED_VECTORIZE = 1, the SSE default, every float matrix or transposed view has PacketAccessBit;
+//      rounds 1-2 of this file wrongly required r % 4 == 0, corrected in round 3)
 //   EvalToRowMajor  = (r == 1 && c != 1) ? 1 : (c == 1 && r != 1) ? 0 : (rhs row-major && !CanVectorizeLhs)
-//   the assignment into the temporary uses packets iff the product has PacketAccessBit (either CanVectorize*),
-//   its storage order agrees with the temporary's, and the temporary's inner size is a multiple of 4.
+//   The assignment into the plain temporary (column-major unless it is a row vector) is chosen by
+//   copy_using_evaluator_traits (AssignEvaluator.h).  With `inner` = the temporary's size along its storage order
+//   (the whole size for a vector), InnerPacketSize = LinearPacketSize = 4 (find_best_packet<float, n> falls back to Packet4f
+//   for every n), and MightVectorize = the product has PacketAccessBit (either CanVectorize*) && storage orders agree:
+//     inner % 4 == 0                   -> InnerVectorizedTraversal: every coefficient by packets           (4x4 products)
+//     else, a vector                   -> LinearVectorizedTraversal, CompleteUnrolling: the first (inner/4)*4 coefficients
+//                                         by packets, the rest by coeff()
+//     else, inner >= 4                 -> SliceVectorizedTraversal (MaySliceVectorize: InnerMaxSize >= InnerPacketSize under
+//                                         EIGEN_UNALIGNED_VECTORIZE) with InnerUnrolling (inner * (1 + CoeffReadCost) <= 400
+//                                         for every size below 8): per column the first (inner/4)*4 rows by packets
+//                                         (copy_using_evaluator_innervec_InnerUnrolling), the rest by coeff()
+//                                         (copy_using_evaluator_DefaultTraversal_InnerUnrolling)        (5-row products)
+//     else                             -> DefaultTraversal: every coefficient by coeff()                 (2- and 3-row products)
+//   So for a 5x5 temporary with a column-major left factor, rows 0-3 of every column are packet sums and row 4 is a
+//   coeff() redux.  On the reference's own matrices (A, B with at most two non-zeros per row / column) all orders coincide;
+//   the distinction matters for dense inputs to crx_dare_batch only.
 //
 //  (P) packet assignment: etor_product_packet_impl walks k upward,
 //      res = A(:,0)*B(0,j); res = A(:,k)*B(k,j) + res    (pmul, then pmul+padd)
@@ -69,14 +86,21 @@ Mat<C, R> transpose(const Mat<R, C>& a) {
 
 enum ProductOrder { PO_ASC = 0, PO_VEC = 1, PO_TREE = 2 };
 
-// The decision described in the header, for fixed sizes.
-inline ProductOrder product_order(int r, int c, int k, bool lhs_rm, bool rhs_rm) {
-  const bool can_vec_lhs = !lhs_rm && (r % 4 == 0);
-  const bool can_vec_rhs = rhs_rm && (c % 4 == 0);
+// The decision described in the header, for fixed sizes: how coefficient (i, j) of an r x c product of inner size k is summed.
+inline ProductOrder product_order(int r, int c, int k, bool lhs_rm, bool rhs_rm, int i, int j) {
+  const bool can_vec_lhs = !lhs_rm && r != 1;
+  const bool can_vec_rhs = rhs_rm && c != 1;
   const bool eval_rm = (r == 1 && c != 1) ? true : (c == 1 && r != 1) ? false : (rhs_rm && !can_vec_lhs);
   const bool dst_rm = (r == 1 && c != 1);
-  const int inner = dst_rm ? c : r;
-  if ((can_vec_lhs || can_vec_rhs) && eval_rm == dst_rm && inner % 4 == 0) return PO_ASC;
+  const bool is_vector = (r == 1 || c == 1);
+  const int inner = is_vector ? r * c : (dst_rm ? c : r);
+  const int pos = dst_rm ? j : i;                                         // position along the temporary's storage order
+  int by_packets = 0;                                                     // leading positions evaluated by packets
+  if ((can_vec_lhs || can_vec_rhs) && eval_rm == dst_rm) {
+    if (inner % 4 == 0) by_packets = inner;                               // InnerVectorizedTraversal
+    else if (is_vector || inner >= 4) by_packets = (inner / 4) * 4;       // Linear- / SliceVectorizedTraversal, unrolled
+  }
+  if (pos < by_packets) return PO_ASC;
   // Coefficient path.  ORACLE_CPATH_ORDER (a build flag of the test infrastructure only) forces one order for EVERY sum of this
   // path — 1: ascending, 2: the unrolled tree — so that tests can show that on the reference's own call sites the choice
   // made here does not matter (every such sum has at most two non-zero terms): tests/test_oracle_vs_ref.py.
@@ -128,12 +152,11 @@ template <int R, int K, int C>
 Mat<R, C> mul(const Mat<R, K>& A, const Mat<K, C>& B, bool lhs_transposed, bool rhs_transposed,
               SumOrder order) {
   Mat<R, C> out;
-  const ProductOrder po = (order == ORDER_ASC) ? PO_ASC : product_order(R, C, K, lhs_transposed, rhs_transposed);
   for (int j = 0; j < C; ++j)
     for (int i = 0; i < R; ++i) {
       float t[K];
       for (int k = 0; k < K; ++k) t[k] = A(i, k) * B(k, j);
-      out(i, j) = accumulate(t, K, po);
+      out(i, j) = accumulate(t, K, (order == ORDER_ASC) ? PO_ASC : product_order(R, C, K, lhs_transposed, rhs_transposed, i, j));
     }
   return out;
 }

@@ -48,16 +48,23 @@ def mul(A, B, lhs_t=False, rhs_t=False, order="eigen"):
     """A (R x K) times B (K x C), float32, one rounding per operation, Eigen's summation order."""
     R, K = A.shape
     C = B.shape[1]
-    can_l, can_r = (not lhs_t) and R % 4 == 0, rhs_t and C % 4 == 0
+    can_l, can_r = (not lhs_t) and R != 1, rhs_t and C != 1       # CanVectorizeLhs / Rhs (no `% 4` term: eigen_order.h)
     eval_rm = True if (R == 1 and C != 1) else False if (C == 1 and R != 1) else (rhs_t and not can_l)
     dst_rm = R == 1 and C != 1
-    packet = (can_l or can_r) and eval_rm == dst_rm and (C if dst_rm else R) % 4 == 0
+    is_vec = R == 1 or C == 1
+    inner = R * C if is_vec else (C if dst_rm else R)
+    by_packets = 0        # leading positions (along the temporary's storage order) that the assignment evaluates by packets
+    if (can_l or can_r) and eval_rm == dst_rm:
+        if inner % 4 == 0:
+            by_packets = inner                     # InnerVectorizedTraversal
+        elif is_vec or inner >= 4:
+            by_packets = (inner // 4) * 4          # Linear- / SliceVectorizedTraversal, unrolled: the rest by coeff()
     sse = lhs_t and (not rhs_t) and K >= 4
     out = np.zeros((R, C), dtype=f32)
     for j in range(C):
         for i in range(R):
             t = [f32(A[i, k] * B[k, j]) for k in range(K)]
-            if order == "asc" or packet:
+            if order == "asc" or (j if dst_rm else i) < by_packets:
                 s = t[0]
                 for k in range(1, K):
                     s = f32(s + t[k])

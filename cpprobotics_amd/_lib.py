@@ -101,6 +101,7 @@ _SIGNATURES = {
                                        C.POINTER(LoopParams), _P, _P]),
     "crx_lqr_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _P, _P, _P, C.POINTER(LqrParams), C.POINTER(VehicleParams),
                                            C.POINTER(LoopParams), _P, _P, _P]),
+    "crx_calc_nearest_index_window_batch": (_I, [_I, _P, _CP, _P, _I, _P]),
     "crx_calc_nearest_index_window_batch_dev": (_I, [_I, _P, _CP, _P, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P]),
     "crx_calc_ref_trajectory_batch_dev": (_I, [_I, _I, _P, _CP, _F, _D, _I, _P, _P, _P]),
@@ -119,6 +120,7 @@ _SIGNATURES = {
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),
     "crx_mpc_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
                                            _P, _P]),
+    "crx_mpc_closed_loop_batch": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

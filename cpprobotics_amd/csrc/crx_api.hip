@@ -100,7 +100,7 @@ struct DevBuf {
 
 extern "C" {
 
-int crx_version(void) { return 201; }  // 0.2.1 (0.2.0 + crx_smooth_yaw)
+int crx_version(void) { return 300; }  // 0.3.0 (0.2.1 + host-pointer window search and MPC closed loop, quad Riccati kernel)
 
 // The engine keeps no global state: crx_init only checks that a device is there and forces the HIP runtime + code object to
 // load now rather than in the first timed call; crx_shutdown drains the device.  Both are optional.
@@ -767,6 +767,45 @@ int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* co
   if (pe) CRX_HIP(hipMemcpy(pe, dpe.p, 4 * nn, hipMemcpyDeviceToHost));
   if (pth_e) CRX_HIP(hipMemcpy(pth_e, dpt.p, 4 * nn, hipMemcpyDeviceToHost));
   if (ind) CRX_HIP(hipMemcpy(ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
+  if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));
+  if (ticks_done) CRX_HIP(hipMemcpy(ticks_done, dt.p, 4 * nn, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
+                                        int* ind_out) {
+  if (n < 0 || nsearch < 0 || !course_ok(course, false) || (n && (!state || !pind || !ind_out)))
+    return fail(CRX_ERR_INVALID, "calc_nearest_index(window): bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n;
+  DevCourse dc; DevBuf ds, dp, di;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(dp, 4 * nn); CRX_ALLOC(di, 4 * nn);
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  CRX_HIP(hipMemcpy(dp.p, pind, 4 * nn, hipMemcpyHostToDevice));
+  if (int rc = crx_calc_nearest_index_window_batch_dev(n, ds.as<float>(), &dc.c, dp.as<int>(), nsearch, di.as<int>(), nullptr)) return rc;
+  CRX_HIP(hipMemcpy(ind_out, di.p, 4 * nn, hipMemcpyDeviceToHost));
+  return CRX_OK;
+}
+
+int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
+                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done) {
+  if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
+    return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const size_t nn = (size_t)n, mt = (size_t)loop->max_ticks;
+  DevCourse dc; DevBuf ds, di, dh, dt;
+  if (int rc = dc.upload(course)) return fail(rc, "course upload");
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn);
+  if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
+  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
+  if (target_ind) CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
+  if (int rc = crx_mpc_closed_loop_batch_dev(n, T, ds.as<float>(), &dc.c, dl, nsearch, prm, loop, di.as<int>(),
+                                             traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), nullptr, nullptr)) return rc;
+  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
+  if (target_ind) CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
   if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));
   if (ticks_done) CRX_HIP(hipMemcpy(ticks_done, dt.p, 4 * nn, hipMemcpyDeviceToHost));
   return CRX_OK;

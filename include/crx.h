@@ -240,6 +240,8 @@ int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course
 /* MPC front-end: calc_nearest_index(state, cx, cy, cyaw, pind) src/model_predictive_control.cpp:107-127 (window of
  * nsearch = N_IND_SEARCH points from pind; the reference's unchecked read past the course end is clipped) and
  * calc_ref_trajectory :130-170 (xref: n x 4T, column-major 4 x T per agent; target_ind in/out). */
+int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
+                                        int* ind_out);
 int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
                                             int* ind_out, void* stream);
 int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_course* course, float dl, double dt, int nsearch,
@@ -255,6 +257,9 @@ size_t crx_mpc_closed_loop_work_bytes(int n, int T);
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
                                   int* ticks_done, void* work, void* stream);
+/* host pointers (target_ind may be NULL = start from 0 as mpc_simulation does, :357) */
+int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
+                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done);
 
 
 /* ---- particle-filter localisation (src/particle_filter.cpp) ---------------------------------

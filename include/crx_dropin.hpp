@@ -8,8 +8,8 @@
 //   src/lqr_speed_steer_control.cpp:85-106 solve_DARE (5x5), dlqr (5x5)
 //   src/lqr_steer_control.cpp:75-96        solve_DARE (4x4), dlqr (4x4)
 //   src/model_predictive_control.cpp:255-346 mpc_solve
-//   and the callers on either side of the solves — calc_nearest_index, lqr_steering_control, update,
-//   calc_ref_trajectory — in one namespace per reference translation unit (the three files reuse the names
+//   and the callers on either side of the solves — calc_nearest_index (both forms), lqr_steering_control, update,
+//   calc_ref_trajectory, closed_loop_prediction, mpc_simulation — in one namespace per reference translation unit (the three files reuse the names
 //   `update` / `calc_nearest_index` with different bodies): crx_dropin::lqr_speed_steer, ::lqr_steer, ::mpc.
 //   `using namespace crx_dropin::lqr_speed_steer;` after deleting src/lqr_speed_steer_control.cpp:65-164 etc.
 //
@@ -23,6 +23,7 @@
 // column-major stand-in with the members the reference code uses (operator(), data(), <<-free).
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <stdexcept>
 #include <string>
@@ -167,6 +168,17 @@ namespace crx_dropin {
 using cpprobotics::State;
 using cpprobotics::Vec_f;
 
+using cpprobotics::Poi_f;
+
+// What the reference's closed-loop functions draw (x_h / y_h and the final state) — they return void and show an OpenCV window; a
+// call site that ignores the result compiles unchanged.  One row per executed tick that did not reach the goal, as the reference
+// pushes them (src/lqr_speed_steer_control.cpp:207-208, src/model_predictive_control.cpp:387-388).
+struct Trajectory {
+  Vec_f x_h, y_h, yaw_h, v_h;
+  State final_state{0.0f, 0.0f, 0.0f, 0.0f};
+  int ticks = 0;            // passes of the loop executed
+  bool goal = false;        // the goal test fired (otherwise max_ticks ran out: the reference's own loops have no other exit)
+};
 inline crx_course course_of(const Vec_f& cx, const Vec_f& cy, const Vec_f& cyaw, const Vec_f* ck, const Vec_f* sp) {
   if (cy.size() != cx.size() || cyaw.size() != cx.size()) throw std::invalid_argument("course arrays differ in length");
   return crx_course{(int)cx.size(), cx.data(), cy.data(), cyaw.data(), ck ? ck->data() : nullptr, sp ? sp->data() : nullptr};
@@ -197,6 +209,22 @@ inline void update(State& state, float a, float delta) {                        
   crx::dropin_check(crx_update_batch(1, s, &a, &delta, nullptr), "update");
   state.x = s[0]; state.y = s[1]; state.yaw = s[2]; state.v = s[3];
 }
+// closed_loop_prediction(cx, cy, cyaw, ck, speed_profile, goal) :166 — the loop :194-205 for the reference's start State(-0,-0,0,0),
+// e = e_th = 0, goal_dis 0.3.  The reference's clock never advances (`time_` :173), its loop ends at the goal only: max_ticks bounds it.
+inline Trajectory closed_loop_prediction(Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f speed_profile, Poi_f goal, int max_ticks = 5000) {
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &speed_profile);
+  float s[4] = {-0.0f, -0.0f, 0.0f, 0.0f};
+  crx_loop_params lp{goal[0], goal[1], 0.3f, 1.0, 0.05f, max_ticks};
+  std::vector<float> hist((size_t)max_ticks * 4);
+  int ticks = 0;
+  crx::dropin_check(crx_lqr_closed_loop_batch(1, 5, s, &c, nullptr, nullptr, nullptr, nullptr, nullptr, &lp, hist.data(), &ticks), "closed_loop_prediction");
+  Trajectory t;
+  t.ticks = ticks; t.final_state = State(s[0], s[1], s[2], s[3]);
+  { const float dx = s[0] - goal[0], dy = s[1] - goal[1]; t.goal = std::sqrt(dx * dx + dy * dy) <= lp.goal_dis; }
+  const int kept = t.goal ? ticks - 1 : ticks;                  // the tick that reaches the goal breaks before the push_back
+  for (int k = 0; k < kept; ++k) { t.x_h.push_back(hist[4 * k]); t.y_h.push_back(hist[4 * k + 1]); t.yaw_h.push_back(hist[4 * k + 2]); t.v_h.push_back(hist[4 * k + 3]); }
+  return t;
+}
 }  // namespace lqr_speed_steer
 
 namespace lqr_steer {         // src/lqr_steer_control.cpp
@@ -214,6 +242,22 @@ inline float lqr_steering_control(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, V
   float delta = 0.0f;
   crx::dropin_check(crx_lqr_steering_control_batch(1, 4, s, &c, &ind, &pe, &pth_e, nullptr, &delta), "lqr_steering_control");
   return delta;
+}
+// closed_loop_prediction(cx, cy, cyaw, ck, speed_profile, goal) :148 — the loop :186-197: steering from the 4-state LQR, ai = KP *
+// (speed_profile[ind] - v), ind advanced while the vehicle stands still; goal_dis 0.5.
+inline Trajectory closed_loop_prediction(Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f speed_profile, Poi_f goal, int max_ticks = 5000) {
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &speed_profile);
+  float s[4] = {-0.0f, -0.0f, 0.0f, 0.0f};
+  crx_loop_params lp{goal[0], goal[1], 0.5f, 1.0, 0.05f, max_ticks};
+  std::vector<float> hist((size_t)max_ticks * 4);
+  int ticks = 0;
+  crx::dropin_check(crx_lqr_closed_loop_batch(1, 4, s, &c, nullptr, nullptr, nullptr, nullptr, nullptr, &lp, hist.data(), &ticks), "closed_loop_prediction");
+  Trajectory t;
+  t.ticks = ticks; t.final_state = State(s[0], s[1], s[2], s[3]);
+  { const float dx = s[0] - goal[0], dy = s[1] - goal[1]; t.goal = std::sqrt(dx * dx + dy * dy) <= lp.goal_dis; }
+  const int kept = t.goal ? ticks - 1 : ticks;
+  for (int k = 0; k < kept; ++k) { t.x_h.push_back(hist[4 * k]); t.y_h.push_back(hist[4 * k + 1]); t.yaw_h.push_back(hist[4 * k + 2]); t.v_h.push_back(hist[4 * k + 3]); }
+  return t;
 }
 }  // namespace lqr_steer
 
@@ -240,6 +284,37 @@ inline void calc_ref_trajectory(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, Vec
   const crx_course c = course_of(cx, cy, cyaw, &ck, &sp);
   const float s[4] = {state.x, state.y, state.yaw, state.v};
   crx::dropin_check(crx_calc_ref_trajectory_batch(1, T_, s, &c, dl, 0.2, 10, &target_ind, xref.data()), "calc_ref_trajectory");
+}
+// calc_nearest_index(state, cx, cy, cyaw, pind) :107 — the window of N_IND_SEARCH = 10 points from pind (the reference reads
+// cx[pind .. pind+9] unchecked, :110; the engine clips the window at the end of the course)
+inline int calc_nearest_index(State state, Vec_f cx, Vec_f cy, Vec_f cyaw, int pind) {
+  const crx_course c = course_of(cx, cy, cyaw, nullptr, nullptr);
+  const float s[4] = {state.x, state.y, state.yaw, state.v};
+  int ind = 0;
+  crx::dropin_check(crx_calc_nearest_index_window_batch(1, s, &c, &pind, 10, &ind), "calc_nearest_index");
+  return ind;
+}
+// mpc_simulation(cx, cy, cyaw, ck, speed_profile, goal) :348 — set-up :349-360 (start state from the first course point, the yaw
+// wrap, target_ind = 0, smooth_yaw on the by-value copy of cyaw) and the loop :371-385 (calc_ref_trajectory -> mpc_solve -> update
+// -> goal test, goal_dis 0.5) as ONE persistent kernel.  The reference's `iter_count` never advances (MAX_TIME is no exit): max_ticks.
+template <int T_>
+inline Trajectory mpc_simulation(Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f speed_profile, Poi_f goal, int max_ticks = 5000) {
+  float s[4] = {cx[0], cy[0], cyaw[0], speed_profile[0]};
+  const double pi = 3.14159265358979323846;
+  if ((double)(s[2] - cyaw[0]) >= pi) s[2] = (float)((double)s[2] - pi * 2.0);
+  else if ((double)(s[2] - cyaw[0]) <= -1.0 * pi) s[2] = (float)((double)s[2] + pi * 2.0);
+  smooth_yaw(cyaw);
+  const crx_course c = course_of(cx, cy, cyaw, &ck, &speed_profile);
+  crx_loop_params lp{goal[0], goal[1], 0.5f, 1.0, 0.05f, max_ticks};
+  std::vector<float> hist((size_t)max_ticks * 4);
+  int ticks = 0, target_ind = 0;
+  crx::dropin_check(crx_mpc_closed_loop_batch(1, T_, s, &c, 1.0f, 10, nullptr, &lp, &target_ind, hist.data(), &ticks), "mpc_simulation");
+  Trajectory t;
+  t.ticks = ticks; t.final_state = State(s[0], s[1], s[2], s[3]);
+  { const float dx = s[0] - goal[0], dy = s[1] - goal[1]; t.goal = std::sqrt(dx * dx + dy * dy) <= lp.goal_dis; }
+  const int kept = t.goal ? ticks - 1 : ticks;
+  for (int k = 0; k < kept; ++k) { t.x_h.push_back(hist[4 * k]); t.y_h.push_back(hist[4 * k + 1]); t.yaw_h.push_back(hist[4 * k + 2]); t.v_h.push_back(hist[4 * k + 3]); }
+  return t;
 }
 }  // namespace mpc
 

@@ -2,9 +2,13 @@
 // Mirrors: the EKF loop body (src/extended_kalman_filter.cpp:171-183) with fixed inputs instead of the
 // random_device draws; lqr_steering_control()'s dlqr call (src/lqr_speed_steer_control.cpp:116-132,
 // src/lqr_steer_control.cpp:104-118); mpc_simulation()'s mpc_solve call (src/model_predictive_control.cpp:374).
+// The closed loops under the reference's own signatures — closed_loop_prediction (src/lqr_speed_steer_control.cpp:166,
+// src/lqr_steer_control.cpp:148), mpc_simulation (src/model_predictive_control.cpp:348) — and the MPC file's windowed
+// calc_nearest_index (:107) run on the arc course below.
 // Prints every result as hex floats so the GPU test can compare bit-for-bit with the oracle.
 #include <cmath>
 #include <cstdio>
+#include <string>
 #include "crx_dropin.hpp"
 
 using crx::Mat;
@@ -100,6 +104,26 @@ int main() {
     crx_dropin::mpc::update(st, 0.5f, 0.9f);
     const float row[4] = {st.x, st.y, st.yaw, st.v};
     dump("mpc_update", row, 4);
+  }
+  // ---- the closed loops under the reference's signatures, and the MPC file's windowed nearest-index search
+  {
+    cpprobotics::Poi_f goal{{cx.back(), cy.back()}};
+    crx_dropin::Trajectory t5 = crx_dropin::lqr_speed_steer::closed_loop_prediction(cx, cy, cyaw, ck, sp, goal, 400);
+    crx_dropin::Trajectory t4 = crx_dropin::lqr_steer::closed_loop_prediction(cx, cy, cyaw, ck, sp, goal, 400);
+    crx_dropin::Trajectory tm = crx_dropin::mpc::mpc_simulation<6>(cx, cy, cyaw, ck, sp, goal, 60);
+    const crx_dropin::Trajectory* ts[3] = {&t5, &t4, &tm};
+    const char* names[3] = {"loop5", "loop4", "loopm"};
+    for (int k = 0; k < 3; ++k) {
+      const crx_dropin::Trajectory& t = *ts[k];
+      const float head[6] = {(float)t.ticks, t.goal ? 1.0f : 0.0f, t.final_state.x, t.final_state.y, t.final_state.yaw, t.final_state.v};
+      dump((std::string(names[k]) + "_end").c_str(), head, 6);
+      dump((std::string(names[k]) + "_x").c_str(), t.x_h.data(), (int)t.x_h.size());
+      dump((std::string(names[k]) + "_y").c_str(), t.y_h.data(), (int)t.y_h.size());
+    }
+    cpprobotics::State st(3.0f, 0.6f, 0.3f, 2.0f);
+    float idx[3];
+    for (int k = 0; k < 3; ++k) idx[k] = (float)crx_dropin::mpc::calc_nearest_index(st, cx, cy, cyaw, 5 + 20 * k);   // 45 + 10 runs to the course end
+    dump("window_ind", idx, 3);
   }
   return 0;
 }

@@ -104,3 +104,33 @@ def test_dropin_matches_oracle(demo, oracle_mod):
     st2 = oracle_mod.update(st, np.array([0.5], f32), np.array([0.9], f32), dt=0.2, wheelbase=2.5, clamp_speed=True)
     assert np.array_equal(got["mpc_update"][0], st2[0])
 
+    # the closed loops under the reference's signatures: same ticks, same fate, the drawn trajectory tick by tick
+    goal = (float(cx[-1]), float(cy[-1]))
+    for dim, tag, cap in ((5, "loop5", 400), (4, "loop4", 400)):
+        st0 = np.array([[-0.0, -0.0, 0.0, 0.0]], f32)
+        so, tio, ho = oracle_mod.lqr_closed_loop(st0, course, goal, dim=dim, max_ticks=cap, want_hist=True)[:3]
+        end = got[tag + "_end"][0]
+        reached = bool(np.hypot(so[0, 0] - goal[0], so[0, 1] - goal[1]) <= (0.3 if dim == 5 else 0.5))
+        assert int(end[0]) == tio[0] and bool(end[1]) == reached and np.array_equal(end[2:], so[0])
+        kept = tio[0] - 1 if reached else tio[0]
+        assert np.array_equal(got[tag + "_x"][0], ho[:kept, 0, 0]) and np.array_equal(got[tag + "_y"][0], ho[:kept, 0, 1])
+    # mpc_simulation: the reference's set-up (:349-360) replayed, then the loop through the oracle's solver (tolerance parity)
+    st0 = np.array([[cx[0], cy[0], th[0], course[4][0]]], f32)
+    cyaw_s = crx_smooth(th)
+    ms, mt, mh, _ = oracle_mod.mpc_closed_loop(st0, (cx, cy, cyaw_s, course[3], course[4]), goal, 6, 60, want_hist=True)
+    end = got["loopm_end"][0]
+    assert int(end[0]) == mt[0]
+    assert np.max(np.abs(end[2:] - ms[0]) / np.maximum(np.abs(ms[0]), 1.0)) <= 1e-5
+    reached = bool(np.hypot(ms[0, 0] - goal[0], ms[0, 1] - goal[1]) <= 0.5)
+    kept = mt[0] - 1 if reached else mt[0]
+    assert bool(end[1]) == reached and len(got["loopm_x"][0]) == kept
+    assert np.max(np.abs(got["loopm_x"][0] - mh[:kept, 0, 0])) <= 1e-5 * max(1.0, np.abs(mh[:kept, 0, 0]).max())
+    # the MPC file's windowed search
+    stw = np.array([[3.0, 0.6, 0.3, 2.0]], f32)
+    want = [oracle_mod.calc_nearest_index_window(stw, course, np.array([p], np.int32))[0] for p in (5, 25, 45)]
+    assert np.array_equal(got["window_ind"][0], np.array(want, f32))
+
+
+def crx_smooth(yaw):
+    import cpprobotics_amd as crx
+    return crx.smooth_yaw(np.asarray(yaw, np.float32))

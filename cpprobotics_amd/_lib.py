@@ -82,7 +82,6 @@ _SIGNATURES = {
     "crx_ekf_run_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams), _P]),
     "crx_ekf_simulate_inputs_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                          C.POINTER(EkfParams), _P]),
-    "crx_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(EkfParams), _P, _P]),
     "crx_normal_draws_dev": (_I, [_I, _I, C.c_longlong, C.c_ulonglong, C.c_uint, _P, _P]),
     "crx_dare_batch": (_I, [_I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P]),
     "crx_dare_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P]),
@@ -120,7 +119,7 @@ _SIGNATURES = {
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),
     "crx_mpc_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
                                            _P, _P]),
-    "crx_mpc_closed_loop_batch": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P]),
+    "crx_mpc_closed_loop_batch": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 

@@ -53,26 +53,10 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
 
-// Threads per workgroup of the iterative kernels (DARE, MPC, tracking): full 64-lane waves.  Narrower waves
-// (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized
-// batches) were measured and are 1.0x-5x SLOWER: with single-wave workgroups the dispatcher stacks the extra waves
-// on a subset of the CUs instead of spreading them (scripts/gpu_lanes_sweep.sh; CRX_LANES overrides for experiments).
-inline unsigned iter_block() {
-  static const int forced = [] { const char* e = std::getenv("CRX_LANES"); return e ? std::atoi(e) : 0; }();
-  if (forced >= 1 && forced <= 64) return (unsigned)forced;
-  return 64;
-}
-
-// CRX_MPC_LIVE=<agents per wave>, CRX_MPC_WG=<waves per workgroup>: launch-geometry experiments (scripts/gpu_mpc_ab.py).
-inline int mpc_forced_live() {
-  static const int forced = [] { const char* e = std::getenv("CRX_MPC_LIVE"); return e ? std::atoi(e) : 64; }();
-  return forced;
-}
-
-inline int mpc_forced_wg() {
-  static const int forced = [] { const char* e = std::getenv("CRX_MPC_WG"); return e ? std::atoi(e) : 1; }();
-  return forced;
-}
+// Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
+// waves (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized batches)
+// were measured in round 1 and are 1.0x-5x SLOWER: the dispatcher stacks the extra waves on a subset of the CUs.
+inline unsigned iter_block() { return 64; }
 
 crx::EkfConsts make_consts(const float* Q, const float* R, const crx_ekf_params* prm) {
   crx::EkfConsts k;
@@ -197,9 +181,9 @@ int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const floa
   return CRX_OK;
 }
 
-int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u,
+static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, const float* u,
                           float* x_hist, float* P_hist, const float* Q, const float* R,
-                          const crx_ekf_params* prm, void* stream) {
+                          const crx_ekf_params* prm, void* stream, bool force_addr64) {
   if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
     return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
   if (int rc = check_device()) return rc;
@@ -214,10 +198,9 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
 #ifndef CRX_EKF_BUFFER_ADDRESSING
 #define CRX_EKF_BUFFER_ADDRESSING 1
 #endif
-  // 32-bit buffer offsets (ekf_kernels.hip.h); CRX_EKF_BUFFER=0 forces the 64-bit-address kernels that large
-  // batches get (tests exercise both with small inputs)
-  const char* env_buf = std::getenv("CRX_EKF_BUFFER");
-  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !(env_buf && env_buf[0] == '0');
+  // 32-bit buffer offsets (ekf_kernels.hip.h) up to kEkfBufMaxN vehicles, the 64-bit-address kernels above (tests force the
+  // latter on small inputs through crx_x_ekf_run_addr64_dev)
+  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !force_addr64;
 #define CRX_LAUNCH_RUN(XH, PH)                                                                          \
   do {                                                                                                  \
     if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
@@ -230,6 +213,15 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
 #undef CRX_LAUNCH_RUN
   CRX_HIP(hipGetLastError());
   return CRX_OK;
+}
+
+int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                          const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, false);
+}
+int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                             const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, true);
 }
 
 #ifdef CRX_EKF_TIMING
@@ -260,8 +252,10 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
   return CRX_OK;
 }
 
-// The two-lanes-per-vehicle A/B variant of the fused launch (ekf_wave2_kernels.hip.h).  Not the production path.
-int crx_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
+// The two-lanes-per-vehicle A/B variant of the fused launch (ekf_wave2_kernels.hip.h): measured 0.61-0.73x of the production
+// kernel (profiles/r02/ekf_wave_ab.txt).  Measurement only (include/crx_experimental.h); it has no general-step fallback: when
+// *left_domain comes back non-zero, xEst / PEst / x_hist of this call are not valid.
+int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
                                const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream) {
   if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
     return fail(CRX_ERR_INVALID, "ekf_run_pair: bad argument");
@@ -474,16 +468,28 @@ int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* 
 // ---------------------------------------------------------------------------------------------
 // MPC
 // ---------------------------------------------------------------------------------------------
-int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
-                            float* sol, int* status, double* cost, void* stream) {
+// agents_per_wave (1..64) and waves_per_workgroup (1..4): the launch geometry; the product entry point uses full waves in
+// single-wave workgroups (every emptier or stacked geometry measured slower: profiles/r02/mpc_tail.txt).
+static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
+  if (agents_per_wave < 1 || agents_per_wave > 64 || waves_per_workgroup < 1 || waves_per_workgroup > 4)
+    return fail(CRX_ERR_INVALID, "mpc_solve: launch geometry out of range (1..64 agents per wave, 1..4 waves per workgroup)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, mpc_forced_live(), mpc_forced_wg());
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
+}
+int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                            float* sol, int* status, double* cost, void* stream) {
+  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
+}
+int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                 double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
+  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, waves_per_workgroup);
 }
 
 int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
@@ -650,8 +656,8 @@ int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const cr
   return CRX_OK;
 }
 
-// The persistent kernel keeps everything in registers / private memory: no work buffer is needed any more (kept for ABI
-// compatibility with 0.1: returns 0, and crx_mpc_closed_loop_batch_dev ignores `work`).
+// The persistent kernel keeps everything in registers / private memory: no work buffer is needed (kept for source compatibility
+// with 0.1: returns 0).
 size_t crx_mpc_closed_loop_work_bytes(int n, int T) {
   (void)n; (void)T;
   return 0;
@@ -659,7 +665,7 @@ size_t crx_mpc_closed_loop_work_bytes(int n, int T) {
 
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
-                                  int* ticks_done, void* work, void* stream) {
+                                  int* ticks_done, int* solve_flags, void* stream) {
   if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 ||
       (n && (!state || !target_ind || !ticks_done)))
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
@@ -669,7 +675,7 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   if (prm) p = *prm; else crx_mpc_default_params(&p);
   const crx::VehicleParams vp{p.dt, p.wb, p.max_steer, p.max_speed, p.min_speed, 1};
   const size_t nn = (size_t)n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
-  (void)nn; (void)nv; (void)work;              // `work` is no longer used (kept in the signature; may be NULL)
+  (void)nn; (void)nv;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(blocks_for(n, 64)), block(64);
   const crx::CourseView cv = view(course);
@@ -680,13 +686,13 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
   // ONE persistent kernel for the whole episode (round 1 enqueued three kernels per tick from the host)
   if (T <= 8)
     hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<8>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp, loop->goal_x,
-                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
+                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done, solve_flags);
   else if (T <= 24)
     hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<24>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp, loop->goal_x,
-                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
+                       loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done, solve_flags);
   else
     hipLaunchKernelGGL((crx::mpc_closed_loop_kernel<CRX_MPC_MAX_T>), grid, block, 0, s, n, T, loop->max_ticks, state, cv, dl, nsearch, q, vp,
-                       loop->goal_x, loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done);
+                       loop->goal_x, loop->goal_y, loop->goal_dis, target_ind, traj_hist, ticks_done, solve_flags);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }
@@ -790,20 +796,21 @@ int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_cou
 }
 
 int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
-                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done) {
+                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done, int* solve_flags) {
   if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   const size_t nn = (size_t)n, mt = (size_t)loop->max_ticks;
-  DevCourse dc; DevBuf ds, di, dh, dt;
+  DevCourse dc; DevBuf ds, di, dh, dt, df;
   if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn);
+  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn); CRX_ALLOC(df, 4 * nn);
   if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
   CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
   if (target_ind) CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
   if (int rc = crx_mpc_closed_loop_batch_dev(n, T, ds.as<float>(), &dc.c, dl, nsearch, prm, loop, di.as<int>(),
-                                             traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), nullptr, nullptr)) return rc;
+                                             traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), df.as<int>(), nullptr)) return rc;
+  if (solve_flags) CRX_HIP(hipMemcpy(solve_flags, df.p, 4 * nn, hipMemcpyDeviceToHost));
   CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
   if (target_ind) CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
   if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));

@@ -174,15 +174,18 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   if (__all(c00 && c11)) {
     // Both diagonal curvatures positive in every lane (always so in a Gauss-Newton sweep): the problem along each of the four
     // edges is a convex parabola, whose minimiser over the edge is the stationary point clamped to it — four candidates
-    // cover the whole boundary, corners included, and the one kept is the same point the full enumeration below keeps.
+    // cover the whole boundary, corners included.  A control counts as free under the rule of the full enumeration below (its
+    // unclamped stationary value lies in the closed interval), so the two paths agree on the point and on the flags except for
+    // exact ties between two DIFFERENT boundary points of equal objective, which the two candidate orders may break differently
+    // (a measure-zero coincidence; which path runs is a wave-level decision, the CPU twin mirrors the enumeration below).
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const double c0 = b ? hi0 : lo0;
-      const double t1 = clampd(-(g1 + hod * c0) * ih11, lo1, hi1);
-      consider(c0, t1, (t1 > lo1 && t1 < hi1) ? 2 : 0, true);
+      const double u1 = -(g1 + hod * c0) * ih11;
+      consider(c0, clampd(u1, lo1, hi1), (u1 >= lo1 && u1 <= hi1) ? 2 : 0, true);
       const double c1 = b ? hi1 : lo1;
-      const double t0 = clampd(-(g0 + hod * c1) * ih00, lo0, hi0);
-      consider(t0, c1, (t0 > lo0 && t0 < hi0) ? 1 : 0, true);
+      const double u0 = -(g0 + hod * c1) * ih00;
+      consider(clampd(u0, lo0, hi0), c1, (u0 >= lo0 && u0 <= hi0) ? 1 : 0, true);
     }
     const lanemask_t in = lanes_where(interior);
     k0 = sel64(in, ia, b0); k1 = sel64(in, ib, b1);

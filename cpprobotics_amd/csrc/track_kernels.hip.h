@@ -359,13 +359,14 @@ template <int MAXT>
 __global__ void __launch_bounds__(64)
 mpc_closed_loop_kernel(int n, int T, int max_ticks, float* __restrict__ state, CourseView c, float dl, int nsearch, MpcP p, VehicleParams vp,
                        float goal_x, float goal_y, float goal_dis, int* __restrict__ target_ind, float* __restrict__ traj_hist,
-                       int* __restrict__ ticks_done) {
+                       int* __restrict__ ticks_done, int* __restrict__ solve_flags) {
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = a < (size_t)n;
   const size_t ag = live ? a : 0;
   float4 s = reinterpret_cast<const float4*>(state)[ag];
   int tind = target_ind[ag];
-  int ticks = 0;
+  int ticks = 0, flags = 0;      // flags: bit 0 = some tick's solve did not converge (its first control was applied all the same, as
+                                 // the reference applies whatever IPOPT returns, :338-339), bit 1 = some tick's speed bound infeasible
   bool active = live;
   float4 xr[MAXT];
   const int last = c.n - 1;
@@ -387,6 +388,7 @@ mpc_closed_loop_kernel(int n, int T, int max_ticks, float* __restrict__ state, C
     int st; double J; float a0, d0;
     mpc_solve_lane<MAXT>(active, T, s, xr, p, nullptr, st, J, a0, d0);
     if (active) {
+      flags |= ((st & 1) ? 0 : 1) | (st & 2);
       update_dev(s.x, s.y, s.z, s.w, a0, d0, vp);
       ticks = tick + 1;
       if (traj_hist) reinterpret_cast<float4*>(traj_hist)[(size_t)tick * n + a] = s;
@@ -398,6 +400,7 @@ mpc_closed_loop_kernel(int n, int T, int max_ticks, float* __restrict__ state, C
   reinterpret_cast<float4*>(state)[a] = s;
   target_ind[a] = tind;
   ticks_done[a] = ticks;
+  if (solve_flags) solve_flags[a] = flags;
 }
 
 }  // namespace crx

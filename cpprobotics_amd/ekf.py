@@ -126,23 +126,6 @@ def normal_draws(n, T, agent0=0, seed=0xC0FFEE, stream_id=0, device=None, out=No
     return out
 
 
-def ekf_run_pair(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):
-    """EXPERIMENT (A/B only): ekf_run with two lanes per vehicle, see include/crx.h.  Returns True if every vehicle stayed on
-    the fast domain (the results are then equal to ekf_run's as IEEE values)."""
-    import torch
-    L.require_cuda(xEst, PEst, z, u, x_hist)
-    T, n = z.shape[0], xEst.shape[0]
-    L.expect("xEst", xEst, "f", n, 4); L.expect("PEst", PEst, "f", n, 16); L.expect("z", z, "f", T, n, 2); L.expect("u", u, "f", T, n, 2)
-    L.expect("x_hist", x_hist, "f", T, n, 4, optional=True)
-    q, r = _qr(Q, R)
-    p = _params(dt)
-    flag = torch.zeros((4,), dtype=torch.int32, device=xEst.device)
-    L.check(L.lib().crx_ekf_run_pair_batch_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist),
-                                               q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.ptr(flag),
-                                               L.stream_ptr()), "crx_ekf_run_pair_batch_dev")
-    return flag
-
-
 QSIM = (1.0, (30.0 / 180 * math.pi) * (30.0 / 180 * math.pi))   # Qsim diag (:154-156)
 RSIM = (0.5 * 0.5, 0.5 * 0.5)                                    # Rsim diag (:159-161)
 

@@ -8,6 +8,9 @@ from . import _lib as L
 _P, _I = C.c_void_p, C.c_int
 _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
+    "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
+    "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
 EXPERIMENTAL_SYMBOLS = tuple(sorted(_X_SIGNATURES))
 _bound = False
@@ -42,3 +45,50 @@ def dlqr_from_v_lanes(v, dim=5, lanes_per_agent=0, dt=0.1, L_wheelbase=0.5, eps=
     L.check(xlib().crx_x_dare_from_v_lanes_dev(n, dim, L.ptr(v), C.byref(p), L.ptr(X), L.ptr(K), L.ptr(iters),
                                                L.stream_ptr(), int(lanes_per_agent)), "crx_x_dare_from_v_lanes_dev")
     return K, X, iters
+
+
+def mpc_solve_geometry(x0, xref, T, agents_per_wave=64, waves_per_workgroup=1, params=None):
+    """mpc_solve with the launch geometry forced (the product uses full waves in single-wave workgroups).  -> sol, status, cost."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+    status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+    cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    L.check(xlib().crx_x_mpc_solve_geometry_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                L.stream_ptr(), int(agents_per_wave), int(waves_per_workgroup)), "crx_x_mpc_solve_geometry_dev")
+    return sol, status, cost
+
+
+def _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist, P_hist=None):
+    from .ekf import _params, _qr
+    L.require_cuda(xEst, PEst, z, u, x_hist, P_hist)
+    T, n = z.shape[0], xEst.shape[0]
+    L.expect("xEst", xEst, "f", n, 4); L.expect("PEst", PEst, "f", n, 16); L.expect("z", z, "f", T, n, 2); L.expect("u", u, "f", T, n, 2)
+    L.expect("x_hist", x_hist, "f", T, n, 4, optional=True); L.expect("P_hist", P_hist, "f", T, n, 16, optional=True)
+    q, r = _qr(Q, R)
+    return n, T, q, r, _params(dt)
+
+
+def ekf_run_addr64(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None, P_hist=None):
+    """ekf_run through the 64-bit-address instantiations of the fused kernel (what batches above 4 M vehicles get)."""
+    n, T, q, r, p = _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist, P_hist)
+    L.check(xlib().crx_x_ekf_run_addr64_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist), L.ptr(P_hist),
+                                            q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.stream_ptr()),
+            "crx_x_ekf_run_addr64_dev")
+
+
+def ekf_run_pair(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):
+    """Round 2's A/B variant: ekf_run with two lanes per vehicle.  Returns True if every vehicle stayed on the kernel's fast
+    domain (the results then equal ekf_run's as IEEE values); False means xEst / PEst / x_hist of this call are NOT valid — the
+    variant has no general-step fallback."""
+    import torch
+    n, T, q, r, p = _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist)
+    flag = torch.zeros((4,), dtype=torch.int32, device=xEst.device)
+    L.check(xlib().crx_x_ekf_run_pair_batch_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist),
+                                                q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.ptr(flag),
+                                                L.stream_ptr()), "crx_x_ekf_run_pair_batch_dev")
+    return bool(flag[0].item() == 0)

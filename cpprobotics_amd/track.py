@@ -183,9 +183,10 @@ def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10
 
 
 def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, nsearch=10, goal_dis=0.5, params=None,
-                   want_hist=False):
+                   want_hist=False, want_flags=False):
     """mpc_simulation's loop (:371-385, maths only) for n vehicles at once: state and target_ind are updated in place.
-    -> (ticks_done int32 [n], traj_hist or None).
+    -> (ticks_done int32 [n], traj_hist or None[, solve_flags int32 [n]: bit 0 = a tick's solve did not converge, bit 1 = a tick
+    started outside the speed bounds]).
     The set-up of the reference (:349-360) is the caller's, from the pieces of this module: the course arrays from
     course_from_waypoints(wx, wy, 1.0, variant=0), the start state (cx[0], cy[0], cyaw[0], sp[0]) taken BEFORE the headings are
     passed through smooth_yaw (:360), target_ind = 0."""
@@ -200,7 +201,8 @@ def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, n
     ticks = torch.zeros((n,), dtype=torch.int32, device=state.device)
     hist = torch.zeros((max_ticks, n, 4), dtype=torch.float32, device=state.device) if want_hist else None
     lp = loop_params(goal, goal_dis, max_ticks)
+    flags = torch.zeros((n,), dtype=torch.int32, device=state.device) if want_flags else None
     L.check(L.lib().crx_mpc_closed_loop_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), int(nsearch), C.byref(p),
-                                                  C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), None,
+                                                  C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), L.ptr(flags),
                                                   L.stream_ptr()), "crx_mpc_closed_loop_batch_dev")
-    return ticks, hist
+    return (ticks, hist, flags) if want_flags else (ticks, hist)

@@ -94,13 +94,6 @@ int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, cons
  * u_true: n x 2.  xTrue, xDR: n x 4, updated in place.  Outputs z, ud: [T][n][2].
  * xTrue_hist / xDR_hist ([T][n][4]) may be NULL.  qsim[2], rsim[2] are the diagonal entries
  * Qsim(0,0),Qsim(1,1),Rsim(0,0),Rsim(1,1) (:154-161) as floats. */
-/* EXPERIMENT, not the production path: the fused launch with TWO LANES PER VEHICLE (rows (0,1) / (2,3) of the covariance on the
- * even / odd lane of a pair, DPP moves across the pair) — the per-wavefront layout north_star sketches, kept so that the A/B
- * in profiles/r02/ekf_wave_ab.txt can be re-run.  Same results as crx_ekf_run_batch_dev as IEEE values on that kernel's
- * fast domain (0 < |yaw| < 120, 2^-60 <= |det S| <= 2^60); *left_domain (device int, may be NULL) is OR-ed with 1 if a
- * vehicle left it, in which case the results are not to be used.  No P history. */
-int crx_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
-                               const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream);
 /* Standard-normal draws for synthetic inputs, keyed by (seed, stream_id, GLOBAL agent id, step) with Philox4x32-10 + Box-Muller
  * (csrc/crx_philox.h): w[t][a][0..3] = the four draws pass t of the reference's loop consumes for agent agent0 + a
  * (src/extended_kalman_filter.cpp:174-181; the reference's own generator is random_device-seeded, :162-164).  The bytes do not
@@ -252,14 +245,17 @@ int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const cr
 /* mpc_simulation's loop (src/model_predictive_control.cpp:371-385), maths only: per tick calc_ref_trajectory -> mpc_solve -> update
  * (first control of the solution) -> goal test, for n agents, the WHOLE episode in one persistent kernel enqueued on `stream`
  * (state, target_ind and the reference trajectory of an agent never leave the lane between ticks).  Agents that reached the
- * goal stop being updated.  target_ind: in/out.  work: unused since 0.2 (may be NULL; crx_mpc_closed_loop_work_bytes returns 0). */
-size_t crx_mpc_closed_loop_work_bytes(int n, int T);
+ * goal stop being updated.  target_ind: in/out.
+ * solve_flags (may be NULL; n ints, since 0.3.0 in the place of the `work` pointer that 0.2 ignored): per agent, bit 0 = at least
+ * one tick's solve did not converge within max_iter (its first control was applied all the same — the reference applies whatever
+ * IPOPT returns, :338-339), bit 1 = at least one tick started from a speed outside the speed bounds (crx_mpc_solve status bit 1). */
+size_t crx_mpc_closed_loop_work_bytes(int n, int T);   /* 0 since 0.2: no work buffer */
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
-                                  int* ticks_done, void* work, void* stream);
+                                  int* ticks_done, int* solve_flags, void* stream);
 /* host pointers (target_ind may be NULL = start from 0 as mpc_simulation does, :357) */
 int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
-                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done);
+                              const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done, int* solve_flags);
 
 
 /* ---- particle-filter localisation (src/particle_filter.cpp) ---------------------------------

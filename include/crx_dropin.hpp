@@ -308,7 +308,7 @@ inline Trajectory mpc_simulation(Vec_f cx, Vec_f cy, Vec_f cyaw, Vec_f ck, Vec_f
   crx_loop_params lp{goal[0], goal[1], 0.5f, 1.0, 0.05f, max_ticks};
   std::vector<float> hist((size_t)max_ticks * 4);
   int ticks = 0, target_ind = 0;
-  crx::dropin_check(crx_mpc_closed_loop_batch(1, T_, s, &c, 1.0f, 10, nullptr, &lp, &target_ind, hist.data(), &ticks), "mpc_simulation");
+  crx::dropin_check(crx_mpc_closed_loop_batch(1, T_, s, &c, 1.0f, 10, nullptr, &lp, &target_ind, hist.data(), &ticks, nullptr), "mpc_simulation");
   Trajectory t;
   t.ticks = ticks; t.final_state = State(s[0], s[1], s[2], s[3]);
   { const float dx = s[0] - goal[0], dy = s[1] - goal[1]; t.goal = std::sqrt(dx * dx + dy * dy) <= lp.goal_dis; }

@@ -15,6 +15,22 @@ extern "C" {
 int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
                                 int* iters, void* stream, int lanes_per_agent);
 
+/* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
+ * workgroup.  The product entry point uses 64 and 1. */
+int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                 double* cost, void* stream, int agents_per_wave, int waves_per_workgroup);
+
+/* crx_ekf_run_batch_dev through the 64-bit-address instantiations of the fused kernel whatever n is (the product entry point
+ * switches to them above 4 M vehicles). */
+int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                             const float* Q, const float* R, const crx_ekf_params* prm, void* stream);
+
+/* Round 2's measured-and-rejected A/B variant of the fused EKF launch: two lanes per vehicle with DPP moves (0.61-0.73x of the
+ * production kernel, profiles/r02/ekf_wave_ab.txt).  No general-step fallback: left_domain[0] != 0 afterwards means a vehicle left
+ * the fast domain (|yaw| >= 120, extreme determinant) and xEst / PEst / x_hist of this call are NOT valid. */
+int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
+                                 const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import cpprobotics_amd as crx  # noqa: E402
-from cpprobotics_amd.ekf import ekf_run_pair  # noqa: E402
+from cpprobotics_amd.experimental import ekf_run_pair  # noqa: E402
 from common import ekf_QR, ekf_agents  # noqa: E402
 
 Q, R = ekf_QR()
@@ -45,7 +45,7 @@ def run(n, T, reps):
                      "hbm_frac": (32.0 * n * T + 160.0 * n) / (ms[len(ms) // 2] * 1e-3) / 8e12,
                      "waves": (n + 63) // 64 if name == "lane_per_vehicle" else (2 * n + 63) // 64}
         if name != "lane_per_vehicle":
-            out[name]["left_fast_domain"] = int(flag.cpu().numpy()[0])
+            out[name]["left_fast_domain"] = int(not flag)
         del xh
     a, b = res["lane_per_vehicle"], res["two_lanes_per_vehicle"]
     out["results_equal_as_ieee_values"] = bool(all(np.array_equal(p, q) for p, q in zip(a, b)))

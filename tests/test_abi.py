@@ -1,4 +1,4 @@
-"""The C-ABI shared library loads and exports every symbol include/crx.h declares (CPU-only checks)."""
+"""The C-ABI shared library loads and exports every symbol include/crx.h and include/crx_experimental.h declare (CPU-only checks)."""
 import ctypes as C
 import os
 import re
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "crx.h")).read()
+def _declared_functions(header="crx.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(crx_[a-zA-Z0-9_]+)\s*\(", src)))
 
@@ -23,8 +23,21 @@ def test_header_and_loader_agree(crx):
 
 def test_library_exports_every_declared_symbol(crx):
     raw = C.CDLL(crx.lib_path())
-    for name in _declared_functions():
+    for name in _declared_functions() + _declared_functions("crx_experimental.h"):
         assert hasattr(raw, name), f"libcrx.so does not export {name}"
+
+
+def test_experimental_entry_points_are_separate(crx):
+    """Measurement-only entry points: prefix crx_x_, declared in include/crx_experimental.h only, bound in
+    cpprobotics_amd/experimental.py only; the product header and loader name none of them and no experiment is steered by an
+    environment variable any more."""
+    from cpprobotics_amd import experimental as X
+    xs = _declared_functions("crx_experimental.h")
+    assert xs and all(n.startswith("crx_x_") for n in xs) and sorted(X.EXPERIMENTAL_SYMBOLS) == xs
+    assert not [n for n in _declared_functions() if n.startswith("crx_x_")]
+    X.xlib()
+    api = open(os.path.join(ROOT, "cpprobotics_amd", "csrc", "crx_api.hip")).read()
+    assert "getenv" not in api
 
 
 def test_version_and_defaults(crx):

@@ -162,6 +162,26 @@ def test_mpc_closed_loop_matches_oracle(crx, oracle_mod, T, n):
     assert np.array_equal(td.cpu().numpy(), tindo)
 
 
+def test_mpc_closed_loop_long_horizon_and_flags(crx, oracle_mod):
+    """The MAXT = 64 instantiation of the persistent kernel (T = 30) against the oracle's loop, and the per-agent solve flags:
+    clear on the course; bit 1 set for an agent that starts faster than MAX_SPEED (crx_mpc_solve's status bit 1)."""
+    course, goal = mpc_course_f32()
+    dc = crx.Course.from_numpy(course)
+    n, T, max_ticks = 40, 30, 6
+    st = tracking_agents(n, tuple(c[:150] for c in course), 19, spread=0.4)
+    st[:, 3] = np.random.default_rng(20).uniform(0.5, 4.0, n).astype(np.float32)
+    st[3, 3] = 25.0                                                            # above MAX_SPEED = 55 km/h
+    tind0 = oracle_mod.calc_nearest_index(st, course)[0].astype(np.int32)
+    so, tio, histo, tindo = oracle_mod.mpc_closed_loop(st, course, goal, T=T, max_ticks=max_ticks, target_ind=tind0, want_hist=True)
+    sd, td = _t(st), _t(tind0)
+    ticks, hist, flags = crx.mpc_simulation(sd, dc, goal, T, max_ticks, target_ind=td, want_hist=True, want_flags=True)
+    flags = flags.cpu().numpy()
+    assert np.array_equal(ticks.cpu().numpy(), tio) and np.array_equal(td.cpu().numpy(), tindo)
+    assert floored_rel_err(sd.cpu().numpy(), so, 1.0) <= 1e-5
+    assert flags[3] & 2 and not (np.delete(flags, 3) & 2).any()
+    assert (flags & 1).mean() < 0.1
+
+
 def test_tracking_fuzz_wide_ranges(crx, oracle_mod, lqr_setup):
     """Control evaluation and update with states spread over many decades (vehicles far off the course, huge/tiny speeds,
     NaN positions): wherever the oracle's result is finite the engine's is bit-identical; NaN positions keep the incoming

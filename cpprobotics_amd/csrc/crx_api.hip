@@ -15,6 +15,7 @@
 #include "ekf_kernels.hip.h"
 #include "ekf_wave2_kernels.hip.h"
 #include "mpc_kernels.hip.h"
+#include "mpc_quad_kernels.hip.h"
 #include "track_kernels.hip.h"
 #include "pf_kernels.hip.h"
 #include "dwa_kernels.hip.h"
@@ -52,6 +53,8 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
+// Largest batch the four-lanes-per-agent MPC kernel is selected for (profiles/r03/mpc_lanes_ab.txt); 0 = never.
+constexpr int kMpcQuadMaxAgents = 0;
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
 // waves (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized batches)
@@ -483,9 +486,30 @@ static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, co
   const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
+// lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24),
+// 0 = chosen by batch size.
+static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                           double* cost, void* stream, int lanes_per_agent) {
+  if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
+    return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
+  if (lanes_per_agent == 0) lanes_per_agent = (T <= 24 && n <= kMpcQuadMaxAgents) ? 4 : 1;
+  if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
+  if (n < 0 || T < 2 || T > 24 || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): bad argument (2 <= T <= 24)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_quad_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
+}
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
-  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
+  return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, 0);
+}
+int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                              double* cost, void* stream, int lanes_per_agent) {
+  return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, lanes_per_agent);
 }
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {

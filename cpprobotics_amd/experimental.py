@@ -9,6 +9,7 @@ _P, _I = C.c_void_p, C.c_int
 _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
@@ -45,6 +46,23 @@ def dlqr_from_v_lanes(v, dim=5, lanes_per_agent=0, dt=0.1, L_wheelbase=0.5, eps=
     L.check(xlib().crx_x_dare_from_v_lanes_dev(n, dim, L.ptr(v), C.byref(p), L.ptr(X), L.ptr(K), L.ptr(iters),
                                                L.stream_ptr(), int(lanes_per_agent)), "crx_x_dare_from_v_lanes_dev")
     return K, X, iters
+
+
+def mpc_solve_lanes(x0, xref, T, lanes_per_agent=0, params=None):
+    """mpc_solve with the register layout forced: 1 = one agent per lane, 4 = one agent per DPP quad (parallel line search),
+    0 = automatic.  -> sol, status, cost."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+    status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+    cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    L.check(xlib().crx_x_mpc_solve_lanes_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                             L.stream_ptr(), int(lanes_per_agent)), "crx_x_mpc_solve_lanes_dev")
+    return sol, status, cost
 
 
 def mpc_solve_geometry(x0, xref, T, agents_per_wave=64, waves_per_workgroup=1, params=None):

@@ -15,6 +15,11 @@ extern "C" {
 int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
                                 int* iters, void* stream, int lanes_per_agent);
 
+/* crx_mpc_solve_batch_dev with the register layout forced: lanes_per_agent = 1 (one agent per lane), 4 (one agent per DPP quad,
+ * the line search's step lengths rolled out side by side; T <= 24) or 0 (what the product entry point would pick). */
+int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                              double* cost, void* stream, int lanes_per_agent);
+
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,

@@ -137,6 +137,34 @@ def test_mpc_other_parameters(crx, oracle_mod, over):
         assert np.abs(sd[:, 4 * T:4 * T + N]).max() > 0.8          # the wider limit is actually used
 
 
+@pytest.mark.parametrize("T,n", [(6, 1), (6, 17), (21, 16), (21, 500), (9, 130), (24, 33)])
+def test_mpc_four_lanes_per_agent_variant(crx, oracle_mod, T, n):
+    """mpc_quad_kernel (a DPP quad per agent, the step lengths of the line search rolled out side by side; forced through the
+    experimental entry point): the sequential search's decisions, so the same sweep counts, status bits and solutions as the CPU
+    twin — and the one-lane kernel."""
+    from cpprobotics_amd.experimental import mpc_solve_lanes
+    x0, xref = mpc_problem(n, T, seed=200 + n + T)
+    so, sto, co = mpc_solve_threads(oracle_mod, x0, xref, T)
+    sd, std, cd = (a.cpu().numpy() for a in mpc_solve_lanes(_t(x0), _t(xref), T, 4))
+    _check(x0, T, so, sto, co, sd, std, cd, 0.95 if n > 16 else 0.9)
+    s1, st1, c1 = (a.cpu().numpy() for a in mpc_solve_lanes(_t(x0), _t(xref), T, 1))
+    assert np.array_equal(st1, std) and floored_rel_err(sd, s1, 1.0) <= 1e-9
+
+
+def test_mpc_four_lanes_speed_bounds_and_full_size(crx, oracle_mod):
+    from cpprobotics_amd.experimental import mpc_solve_lanes
+    for fast in (True, False):
+        x0, xref = speed_bound_problems(300, 21, 91, fast)
+        so, sto, co = mpc_solve_threads(oracle_mod, x0, xref, 21)
+        sd, std, cd = (a.cpu().numpy() for a in mpc_solve_lanes(_t(x0), _t(xref), 21, 4))
+        _check(x0, 21, so, sto, co, sd, std, cd, 0.99)
+    n, T = 8192, 21                                     # BASELINE configs[3], every agent
+    x0, xref = mpc_problem(n, T, 4)
+    so, sto, co = mpc_solve_threads(oracle_mod, x0, xref, T)
+    sd, std, cd = (a.cpu().numpy() for a in mpc_solve_lanes(_t(x0), _t(xref), T, 4))
+    _check(x0, T, so, sto, co, sd, std, cd, 0.999)
+
+
 def test_mpc_edge_cases(crx):
     import torch
     sol = crx.mpc_solve(torch.empty((0, 4), device="cuda"), torch.empty((0, 24), device="cuda"), 6)

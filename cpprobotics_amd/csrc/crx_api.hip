@@ -13,15 +13,23 @@
 #include "../../include/crx_experimental.h"
 #include "dare_kernels.hip.h"
 #include "ekf_kernels.hip.h"
-#include "ekf_wave2_kernels.hip.h"
 #include "mpc_kernels.hip.h"
-#include "mpc_quad_kernels.hip.h"
 #include "track_kernels.hip.h"
 #include "pf_kernels.hip.h"
 #include "dwa_kernels.hip.h"
 #include "frenet_kernels.hip.h"
 #include "crx_philox.h"
 #include "crx_qr.h"
+// Measured-and-rejected kernel variants (A/B evidence: profiles/r02/ekf_wave_ab.txt, profiles/r03/mpc_lanes_ab.txt): compiled in only
+// with -DCRX_EXPERIMENTAL_KERNELS=1 (the Makefile's default, so that the A/B scripts and their parity tests can run); reachable
+// through include/crx_experimental.h only, never selected by a product entry point.
+#ifndef CRX_EXPERIMENTAL_KERNELS
+#define CRX_EXPERIMENTAL_KERNELS 0
+#endif
+#if CRX_EXPERIMENTAL_KERNELS
+#include "ekf_wave2_kernels.hip.h"
+#include "mpc_quad_kernels.hip.h"
+#endif
 
 namespace {
 
@@ -53,8 +61,6 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
-// Largest batch the four-lanes-per-agent MPC kernel is selected for (profiles/r03/mpc_lanes_ab.txt); 0 = never.
-constexpr int kMpcQuadMaxAgents = 0;
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
 // waves (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized batches)
@@ -260,6 +266,10 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
 // *left_domain comes back non-zero, xEst / PEst / x_hist of this call are not valid.
 int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
                                const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream) {
+#if !CRX_EXPERIMENTAL_KERNELS
+  (void)x_hist; (void)prm; (void)left_domain; (void)stream;
+  return fail(CRX_ERR_INVALID, "ekf_run_pair: this libcrx.so was built without the experimental kernels (CRX_EXPERIMENTAL_KERNELS=0)");
+#else
   if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
     return fail(CRX_ERR_INVALID, "ekf_run_pair: bad argument");
   if (int rc = check_device()) return rc;
@@ -269,6 +279,7 @@ int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* 
                      x_hist, k, left_domain);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
+#endif
 }
 
 // w[t][a][0..3] = the four N(0,1) draws of (seed, stream, global agent id agent0 + a, step t): see crx_philox.h
@@ -486,14 +497,17 @@ static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, co
   const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
-// lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24),
-// 0 = chosen by batch size.
+// lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
+// measured 0.95x at BASELINE configs[3] and less beyond, never selected), 0 = what the product entry point uses (= 1).
 static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                            double* cost, void* stream, int lanes_per_agent) {
   if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
     return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
-  if (lanes_per_agent == 0) lanes_per_agent = (T <= 24 && n <= kMpcQuadMaxAgents) ? 4 : 1;
+  if (lanes_per_agent == 0) lanes_per_agent = 1;     // the quad variant lost its A/B at every batch size (profiles/r03/mpc_lanes_ab.txt)
   if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
+#if !CRX_EXPERIMENTAL_KERNELS
+  return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): this libcrx.so was built without the experimental kernels");
+#else
   if (n < 0 || T < 2 || T > 24 || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): bad argument (2 <= T <= 24)");
   if (int rc = check_device()) return rc;
@@ -502,6 +516,7 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   if (prm) p = *prm; else crx_mpc_default_params(&p);
   const hipError_t e = crx::mpc_quad_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
+#endif
 }
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {

@@ -12,9 +12,11 @@
 // (DESIGN.md 6).  All four lanes run it redundantly; nothing is lost, the SIMDs they occupy had no wave at this batch.
 //
 // Memory: the agent's accepted trajectory (knots, controls, the rollout's trig) lives in an LDS block shared by its quad;
-// each lane keeps its candidate and its copy of the gains in private memory; the owner of the accepted candidate publishes
-// it to the block (184 doubles at T = 21, ~2 % of a sweep).  16 agents per wave, one wave per workgroup, 27.9 KB of LDS
-// (block stride = 2 mod 32 doubles: the 16 quads' broadcast reads fall on distinct banks).
+// so do the gains of a sweep (computed by all four lanes, stored by lane 0); each lane keeps only its candidate in private memory,
+// and the owner of the accepted candidate publishes it to the block (184 doubles at T = 21, ~2 % of a sweep).  16 agents per wave,
+// one wave per workgroup, 74 KB of LDS at T <= 24 — two workgroups per CU (block stride = 2 mod 32 doubles: the 16 quads'
+// broadcast reads fall on distinct banks).  With the gains in private memory as well (first version) the kernel was 0.885x of the
+// one-lane kernel at configs[3]: four times the waves stream four times the scratch through L2 (profiles/r03/mpc_lanes_ab.txt).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mpc_kernels.hip.h"
@@ -28,7 +30,7 @@ __device__ __forceinline__ void mpc_solve_quad(const bool live, const int T, con
                                                double* __restrict__ cur, const int r, const int qbase,
                                                float* __restrict__ so, int& status_out, double& cost_out, float& a0_out, float& d0_out) {
   const int N = T - 1;
-  constexpr int UO = 4 * MAXT, TO = 6 * MAXT;      // offsets of U[i][2] and TR[i][3] behind S[i][4] in the agent's LDS block
+  constexpr int UO = 4 * MAXT, TO = 6 * MAXT, GO = 9 * MAXT;   // offsets of U[i][2], TR[i][3] and the gains (k[2], K[12]) behind S[i][4]
 
   // The agent's ACCEPTED trajectory lives in its LDS block `cur` (knots S[i][4] at 4i, controls U[i][2] at UO + 2i, the trig of
   // the rollout TR[i][3] at TO + 3i), shared by the four lanes.  Each lane keeps its own CANDIDATE of the line search and its
@@ -36,8 +38,8 @@ __device__ __forceinline__ void mpc_solve_quad(const bool live, const int T, con
   double Sc[MAXT][4];     // candidate knots: x, y, yaw, v
   double Uc[MAXT][2];     // candidate stages: delta, a
   double TRc[MAXT][3];    // sin(yaw_i), cos(yaw_i), tan(delta_i) of the candidate rollout: the next backward sweep reuses them
-  double kf[MAXT][2];     // feed-forward
-  double Kf[MAXT][12];    // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev)
+  // The gains of a sweep (feed-forward k[2], feedback K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev)) go to the block too, at
+  // GO + 14 i: all four lanes compute them, lane 0 stores them, every lane's rollout reads them.
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
@@ -73,9 +75,9 @@ __device__ __forceinline__ void mpc_solve_quad(const bool live, const int T, con
     RollIn q;
 #pragma unroll
     for (int a = 0; a < 4; ++a) q.s[a] = cur[4 * i + a];
-    q.u0 = cur[UO + 2 * i]; q.u1 = cur[UO + 2 * i + 1]; q.k0 = kf[i][0]; q.k1 = kf[i][1];
+    q.u0 = cur[UO + 2 * i]; q.u1 = cur[UO + 2 * i + 1]; q.k0 = cur[GO + 14 * i]; q.k1 = cur[GO + 14 * i + 1];
 #pragma unroll
-    for (int a = 0; a < 12; ++a) q.K[a] = Kf[i][a];
+    for (int a = 0; a < 12; ++a) q.K[a] = cur[GO + 14 * i + 2 + a];
     q.r = xr4[i];
     return q;
   };
@@ -303,9 +305,9 @@ __device__ __forceinline__ void mpc_solve_quad(const bool live, const int T, con
           }
         }
       }
-      kf[i][0] = k0; kf[i][1] = k1;
+      if (r == 0) { cur[GO + 14 * i] = k0; cur[GO + 14 * i + 1] = k1; }
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = K[0][b]; Kf[i][2 * b + 1] = K[1][b]; }
+      for (int b = 0; b < 6; ++b) { if (r == 0) { cur[GO + 14 * i + 2 + 2 * b] = K[0][b]; cur[GO + 14 * i + 3 + 2 * b] = K[1][b]; } }
       gnorm = fmax(gnorm, fmax(fabs(k0), fabs(k1)));
       // expected change and value function (unregularised, symmetrised Quu)
       const double Quuk0 = Quu00 * k0 + hod * k1, Quuk1 = hod * k0 + Quu11 * k1;
@@ -477,14 +479,14 @@ __device__ __forceinline__ void mpc_solve_quad(const bool live, const int T, con
 }
 
 
-constexpr int mpc_quad_stride(int maxt) { return ((9 * maxt + 31 - 2) / 32) * 32 + 2; }   // doubles per agent block, = 2 (mod 32)
+constexpr int mpc_quad_stride(int maxt) { return ((23 * maxt + 31 - 2) / 32) * 32 + 2; }   // doubles per agent block, = 2 (mod 32)
 
 template <int MAXT>
 __global__ void __launch_bounds__(64)
 mpc_quad_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
                 float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
   constexpr int STRIDE = mpc_quad_stride(MAXT);
-  __shared__ __attribute__((aligned(16))) double s_traj[16 * STRIDE];
+  extern __shared__ __attribute__((aligned(16))) double s_traj[];      // 16 * STRIDE doubles (74 KB at MAXT = 24: dynamic)
   const int lane = threadIdx.x & 63, r = lane & 3, qbase = lane & ~3;
   const size_t agent = (size_t)blockIdx.x * 16 + (lane >> 2);
   const bool live = agent < (size_t)n;
@@ -508,11 +510,14 @@ inline hipError_t mpc_quad_launch(int n, int T, const float* x0, const float* xr
   p.r_a = q.r_a; p.r_d = q.r_delta; p.rd_a = q.rd_a; p.rd_d = q.rd_delta;
   p.qx = q.q_x; p.qy = q.q_y; p.qyaw = q.q_yaw; p.qv = q.q_v; p.tol = q.tol; p.max_iter = q.max_iter;
   const dim3 grid((unsigned)(((size_t)n + 15) / 16)), block(64);
-  if (T <= 8)
-    hipLaunchKernelGGL((mpc_quad_kernel<8>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
-  else if (T <= 24)
-    hipLaunchKernelGGL((mpc_quad_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
-  else
+  if (T <= 8) {
+    hipLaunchKernelGGL((mpc_quad_kernel<8>), grid, block, 16 * mpc_quad_stride(8) * sizeof(double), stream, n, T, x0, xref, p, sol, status, cost);
+  } else if (T <= 24) {
+    constexpr size_t lds = 16 * mpc_quad_stride(24) * sizeof(double);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mpc_quad_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL((mpc_quad_kernel<24>), grid, block, lds, stream, n, T, x0, xref, p, sol, status, cost);
+  } else
     return hipErrorInvalidValue;       // longer horizons: the one-lane kernel (the blocks would not fit two waves per CU)
   return hipGetLastError();
 }

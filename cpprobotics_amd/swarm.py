@@ -123,3 +123,71 @@ class ChunkedTrajectoryGather:
     def time_major(self):
         self.wait()
         return self.gathered.permute(0, 2, 1, 3, 4).reshape(self.T, self.world * self.nl, self.C).contiguous()
+
+
+class MixedSwarmRound:
+    """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (scripts/swarm_bench.py runs it on the
+    GPUs, tests/test_dist_cpu.py with gloo and the CPU oracle standing in for the launches):
+
+      1. the shard's vehicles run T fused EKF steps — cut into `chunks` launches whose histories are all-gathered one by one while
+         the next chunk computes (ChunkedTrajectoryGather; `gather="final"` gathers the final estimates only, "none" nothing);
+      2. every `plan_every`-th vehicle plans from its final estimate: plan_launch(est) — on a second stream on GPUs, so that the
+         planners of round r overlap the EKF launches of round r + 1 (they only read `est`, which the next round refills after
+         waiting for them).
+
+    ekf_launch(c, t0, t1, hist): enqueue EKF steps [t0, t1) of this shard, history into hist [t1 - t0, n_local, C]; it owns the
+    filter state and must reset it when c == 0.  final_state(): the shard's [n_local, C] estimate after the last chunk.
+    plan_launch(est): enqueue the planners on est [n_plan, C] (a buffer owned by this object); its return value is `plans`."""
+
+    def __init__(self, n_local, T, C, chunks, plan_every, device, ekf_launch, final_state, plan_launch, gather="traj", n_total=None, group=None):
+        self.nl, self.T, self.C, self.every, self.gather_kind, self.group = n_local, T, C, int(plan_every), gather, group
+        self.ekf_launch, self.final_state, self.plan_launch = ekf_launch, final_state, plan_launch
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.n_total = n_total if n_total is not None else n_local * self.world
+        self.cuda = torch.device(device).type == "cuda"
+        self.chunks = chunks
+        self.cg = ChunkedTrajectoryGather(T, n_local, C, chunks, device, group=group) if (gather == "traj" and dist.is_initialized()) else None
+        self.local_hist = None if self.cg is not None else torch.empty((chunks, T // chunks, n_local, C), dtype=torch.float32, device=device)
+        self.est = torch.empty(((n_local + self.every - 1) // self.every, C), dtype=torch.float32, device=device)
+        self.plan_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.ekf_done = torch.cuda.Event() if self.cuda else None
+        self.plans = None
+        self.final = None
+
+    def run(self):
+        main = torch.cuda.current_stream() if self.cuda else None
+        if self.cg is not None:
+            self.cg.run(self.ekf_launch)
+        else:
+            Tc = self.T // self.chunks
+            for c in range(self.chunks):
+                self.ekf_launch(c, c * Tc, (c + 1) * Tc, self.local_hist[c])
+        if self.cuda:
+            main.wait_stream(self.plan_stream)            # the planners of the previous round still read self.est
+        x = self.final_state()
+        self.est.copy_(x[:: self.every])
+        if self.cuda:
+            self.ekf_done.record(main)
+            with torch.cuda.stream(self.plan_stream):
+                self.plan_stream.wait_event(self.ekf_done)
+                self.plans = self.plan_launch(self.est)
+        else:
+            self.plans = self.plan_launch(self.est)
+        if self.gather_kind == "final" and dist.is_initialized():
+            self.final = gather_agents(x, self.n_total, self.group)
+        return self
+
+    def wait(self):
+        if self.cg is not None:
+            self.cg.wait()
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.plan_stream)
+
+    def gathered_bytes_per_rank(self):
+        if not dist.is_initialized() or self.world == 1:
+            return 0
+        return {"traj": 4 * self.C * self.T * self.n_total, "final": 4 * self.C * self.n_total, "none": 0}[self.gather_kind]
+
+    def trajectory_time_major(self):
+        """[T, n_total, C] in global agent order (a copy), from the chunked gather."""
+        return self.cg.time_major()

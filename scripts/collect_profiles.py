@@ -40,11 +40,11 @@ shutil.copy(os.path.join(src, "swarm_1gpu.json"), os.path.join(dst, "swarm_shard
 shutil.copy(os.path.join(src, "host.txt"), os.path.join(dst, "host.txt"))
 p = os.path.join(src, "prof")
 stats(os.path.join(p, "prof_stats", "ekf_kernel_stats.csv"), os.path.join(dst, "ekf_kernel_stats.csv"), ["ekf_run_kernel", "ekf_simulate_inputs"])
-stats(os.path.join(p, "side_stats", "side_kernel_stats.csv"), os.path.join(dst, "side_kernel_stats.csv"), ["mpc_kernel", "dare_from_v_kernel"])
+stats(os.path.join(p, "side_stats", "side_kernel_stats.csv"), os.path.join(dst, "side_kernel_stats.csv"), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel"])
 for name in ("fetch", "write", "sq"):
     counters(os.path.join(p, f"pmc_{name}", "ekf_counter_collection.csv"), os.path.join(dst, f"pmc_{name}_ekf_run_kernel.csv"), ["ekf_run_kernel"])
 for name, o in (("side_sq", "side_pmc_sq.csv"), ("side_flop", "side_pmc_flop.csv"), ("side_sq2", "side_pmc_sq2.csv")):
-    counters(os.path.join(p, name, "side_counter_collection.csv"), os.path.join(dst, o), ["mpc_kernel", "dare_from_v_kernel"])
+    counters(os.path.join(p, name, "side_counter_collection.csv"), os.path.join(dst, o), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel"])
 for f in ("summary.txt", "traffic.json", "side_counters.json"):
     shutil.copy(os.path.join(p, f), os.path.join(dst, f))
 shutil.copy(os.path.join(p, "traffic.json"), os.path.join(ROOT, "profiles", "traffic.json"))

@@ -30,7 +30,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--agents", type=int, default=131072, help="agents per GPU (1,048,576 / 8)")
     ap.add_argument("--T", type=int, default=100, help="EKF steps per round")
-    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--gpus", type=int, default=None, help="must equal WORLD_SIZE when given (bench.py's contract)")
+    ap.add_argument("--steps", "--rounds", dest="steps", type=int, default=5, help="timed rounds")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
     ap.add_argument("--chunks", type=int, default=4, help="launches per round of the chunked trajectory gather")
     args = ap.parse_args()
@@ -44,13 +46,14 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus is None or args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     n, T = args.agents, args.T
-    n_total, n_mpc, Tm = n * world, n // 8, 21
+    n_total, n_mpc, Tm = n * world, (n + 7) // 8, 21
     Q, R = ekf_QR()
     course, goal = mpc_course_f32()
     dc = crx.Course.from_numpy(course, device=dev)
@@ -64,60 +67,72 @@ def main():
     del w
     P0 = torch.eye(4, device=dev).reshape(1, 16).repeat(n, 1).contiguous()
     x, P = x0.clone(), P0.clone()
-    x_hist = torch.empty((T, n, 4), device=dev)
     tind = torch.zeros(n_mpc, dtype=torch.int32, device=dev)
-
-    plan_stream = torch.cuda.Stream(device=dev)
-    ekf_done = torch.cuda.Event()
-    cg = swarm.ChunkedTrajectoryGather(T, n, 4, args.chunks, dev) if (world > 1 and args.gather == "traj") else None
-    st = torch.empty((n_mpc, 4), device=dev)
     v_cmd = 2.5
+    ekf_evs = []
 
-    def one_round():
-        main = torch.cuda.current_stream()
-        x.copy_(x0); P.copy_(P0)
-        if cg is not None:
-            cg.run(lambda c, t0_, t1_, hist: crx.ekf_run(x, P, z[t0_:t1_], ud[t0_:t1_], Q, R, x_hist=hist))
-        else:
-            crx.ekf_run(x, P, z, ud, Q, R, x_hist=x_hist)
-        main.wait_stream(plan_stream)                                 # the planners of the previous round still read st
-        st[:, :3].copy_(x[::8, :3])                                   # every eighth agent plans from its estimated pose ...
-        st[:, 3] = v_cmd                                              # ... at the commanded speed: the filter's 4th state integrates
-                                                                      # the noisy velocity input every step (F(3,3) = 1 and B(3,0) = 1,
-                                                                      # src/extended_kalman_filter.cpp:27,34) — a random walk, not a speed
-        ekf_done.record(main)
-        with torch.cuda.stream(plan_stream):                          # planning overlaps the next round's EKF launches
-            plan_stream.wait_event(ekf_done)
-            crx.calc_nearest_index(st, dc, tind)
-            xref = crx.calc_ref_trajectory(st, dc, tind, Tm)
-            sol = crx.mpc_solve(st, xref, Tm)
-        out = None
-        if world > 1 and args.gather == "final":
-            out = swarm.gather_agents(x, n_total)
-        return sol, out
+    def ekf_launch(c, t0_, t1_, hist):
+        if c == 0:
+            x.copy_(x0); P.copy_(P0)
+        ev = ekf_evs[-1] if ekf_evs and len(ekf_evs[-1]) < 2 * args.chunks else None
+        if ev is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record(); ev.append(e0)
+        crx.ekf_run(x, P, z[t0_:t1_], ud[t0_:t1_], Q, R, x_hist=hist)
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev.append(e1)
+
+    def plan_launch(est):
+        est[:, 3] = v_cmd            # the planners take the estimated pose at the commanded speed: the filter's 4th state integrates the
+                                     # noisy velocity input every step (F(3,3) = 1 and B(3,0) = 1, src/extended_kalman_filter.cpp:27,34)
+        crx.calc_nearest_index(est, dc, tind)
+        xref = crx.calc_ref_trajectory(est, dc, tind, Tm)
+        return crx.mpc_solve(est, xref, Tm)
+
+    rnd = swarm.MixedSwarmRound(n, T, 4, args.chunks, 8, dev, ekf_launch, lambda: x, plan_launch, gather=args.gather, n_total=n_total)
 
     def sync():
-        if cg is not None:
-            cg.wait()
+        rnd.wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(3):
-        one_round()
+    for _ in range(args.warmup):
+        rnd.run()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.rounds):
-        one_round()
+    for _ in range(args.steps):
+        ekf_evs.append([])
+        rnd.run()
     sync()
-    dt = (time.perf_counter() - t0) / args.rounds
+    dt = (time.perf_counter() - t0) / args.steps
+    ekf_ms = sum(sum(a.elapsed_time(b) for a, b in zip(ev[0::2], ev[1::2])) for ev in ekf_evs) / max(1, len(ekf_evs))
+    rates = torch.tensor([n * T / dt], dtype=torch.float64, device=dev)
+    per_rank = [float(rates.item())]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        allr = [torch.zeros_like(rates) for _ in range(world)]
+        dist.all_gather(allr, rates)
+        per_rank = [float(r.item()) for r in allr]
     if rank == 0:
-        gb = {"traj": 16.0 * T * n_total, "final": 16.0 * n_total, "none": 0.0}[args.gather] if world > 1 else 0.0
-        print(json.dumps({"workload": f"mixed swarm: {n_total} agents over {world} GPU(s), {T} EKF steps + 1/8 of the agents one MPC solve (T=21) per round",
-                          "round_ms": dt * 1e3, "ekf_updates_per_s": n_total * T / dt, "mpc_solves_per_s": n_mpc * world / dt,
-                          "gather": args.gather if world > 1 else "n/a", "gathered_bytes_per_rank_per_round": gb}))
+        algo_bytes = 32.0 * n * T + 160.0 * n                       # the EKF launches of one round on one GPU
+        achieved = algo_bytes / (ekf_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "EKF updates/s of a mixed EKF + MPC swarm (BASELINE.json configs[4]); MPC solves/s beside it",
+            "value": n_total * T / dt, "unit": "updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (EKF), f64 (MPC)",
+            "data": "synthetic",
+            "config": {"workload": f"mixed swarm: {n_total} agents over {world} GPU(s), {T} EKF steps for every agent + one MPC solve (T = 21) "
+                                   f"for every eighth agent per round; gather = {args.gather if world > 1 else 'n/a'}",
+                       "agents_per_gpu": n, "ekf_steps_per_round": T, "mpc_agents_per_gpu": n_mpc, "chunks": args.chunks},
+            "secondary": {"metric": "MPC horizon solves/s (T = 21) of the same rounds", "value": n_mpc * world / dt, "unit": "solves/s"},
+            "roofline": {"bound": "valu", "kernel": "crx::ekf_run_kernel (the round's EKF launches)", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "kernel_ms_per_round": ekf_ms, "algorithmic_bytes_per_round": algo_bytes,
+                         "traffic": None},
+            "multi_gpu": {"ranks": world, "per_rank_ekf_updates_per_s": per_rank,
+                          "gather": args.gather if world > 1 else "n/a", "gathered_bytes_per_rank_per_round": rnd.gathered_bytes_per_rank(),
+                          "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                          "layout": "[chunk][rank][t][agent][4] (cpprobotics_amd/swarm.py: ChunkedTrajectoryGather)"},
+            "round_ms": dt * 1e3, "ekf_updates_per_s": n_total * T / dt, "mpc_solves_per_s": n_mpc * world / dt}))
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

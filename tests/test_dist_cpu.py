@@ -121,6 +121,84 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     assert np.array_equal(fg, fr["state"])
 
 
+def _swarm_worker(rank, world, port, n, T, q):
+    """One round of the mixed EKF + MPC swarm (cpprobotics_amd/swarm.py: MixedSwarmRound, what scripts/swarm_bench.py runs on the
+    GPUs) with the CPU oracle standing in for the launches: chunked trajectory gather + planners on every eighth vehicle."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from common import ekf_QR, ekf_agents, mpc_course_f32
+    from cpprobotics_amd import swarm
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    u, x0, P0 = ekf_agents(n, 17)
+    x0[:, :3] = np.stack([course[0][:n], course[1][:n], course[2][:n]], axis=1)        # vehicles start along the course
+    lo, hi = swarm.shard_range(n, rank, world)
+    w = oracle.normal_draws(hi - lo, T, agent0=lo, seed=18)
+    z, ud, *_ = oracle.ekf_simulate_inputs(u[lo:hi], x0[lo:hi], x0[lo:hi], w)
+    st = dict(x=x0[lo:hi].copy(), P=P0[lo:hi].copy())
+
+    def ekf_launch(c, t0, t1, hist):
+        if c == 0:
+            st["x"], st["P"] = x0[lo:hi].copy(), P0[lo:hi].copy()
+        st["x"], st["P"], h, _ = oracle.ekf_run(st["x"], st["P"], z[t0:t1], ud[t0:t1], Q, R)
+        hist.copy_(torch.from_numpy(h))
+
+    def plan_launch(est):
+        e = est.numpy().copy(); e[:, 3] = 2.5
+        tind = oracle.calc_nearest_index(e, course)[0].astype(np.int32)
+        xref, _ = oracle.calc_ref_trajectory(e, course, tind, 6)
+        return oracle.mpc_solve(e, xref, 6)[0]
+
+    outs = []
+    for kind in ("traj", "final"):
+        rnd = swarm.MixedSwarmRound(hi - lo, T, 4, 4, 8, "cpu", ekf_launch, lambda: torch.from_numpy(st["x"]), plan_launch, gather=kind, n_total=n)
+        for _ in range(2):                       # two rounds: the second one reuses every buffer of the first
+            rnd.run()
+        rnd.wait()
+        full = rnd.trajectory_time_major() if kind == "traj" else rnd.final
+        plans = swarm.gather_agents(torch.from_numpy(np.ascontiguousarray(rnd.plans)), n // 8)
+        outs.append((full.numpy(), plans.numpy(), rnd.gathered_bytes_per_rank()))
+    if rank == 0:
+        q.put(outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mixed_swarm_round_sharded_equals_unsharded(oracle_mod):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import ekf_QR, ekf_agents, mpc_course_f32
+    world, n, T = 2, 64, 20
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_swarm_worker, args=(r, world, port, n, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    (traj, plans_t, bytes_t), (final, plans_f, bytes_f) = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    o = oracle_mod
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    u, x0, P0 = ekf_agents(n, 17)
+    x0[:, :3] = np.stack([course[0][:n], course[1][:n], course[2][:n]], axis=1)
+    w = o.normal_draws(n, T, agent0=0, seed=18)
+    z, ud, *_ = o.ekf_simulate_inputs(u, x0, x0, w)
+    x, P, xh, _ = o.ekf_run(x0, P0, z, ud, Q, R)
+    assert np.array_equal(traj, xh) and np.array_equal(final, x)
+    e = x[::8].copy(); e[:, 3] = 2.5
+    tind = o.calc_nearest_index(e, course)[0].astype(np.int32)
+    xref, _ = o.calc_ref_trajectory(e, course, tind, 6)
+    sol = o.mpc_solve(e, xref, 6)[0]
+    assert np.array_equal(plans_t, sol) and np.array_equal(plans_f, sol)
+    assert bytes_t == 16 * T * n and bytes_f == 16 * n
+
+
 def test_shard_range_partitions():
     from cpprobotics_amd import swarm
     for n in (0, 1, 7, 64, 65536, 1048576):

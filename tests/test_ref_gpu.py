@@ -3,7 +3,8 @@
 oracle/_ref/libref.so (oracle/ref_build.sh: the cited line ranges of /root/reference compiled unmodified) is built in the
 development container and travels to the GPU box as a prebuilt file; nothing here reads /root/reference.  The other GPU tests
 compare the kernels with the oracle and tests/test_oracle_vs_ref.py the oracle with these lines — this file closes the triangle on
-the hot path itself: EKF, DARE / dlqr, the tracking closed loops, the dynamic-window and Frenet episodes (all bit for bit), and the
+the hot path itself: EKF, DARE / dlqr, the tracking closed loops, the dynamic-window and Frenet episodes (all bit for bit), a
+particle-filter tick (bit for bit up to its three reordered sums), and the
 MPC solution judged by the reference's FG_EVAL."""
 import numpy as np
 import pytest
@@ -113,6 +114,60 @@ def test_frenet_episode_equals_the_reference_lines(crx, oracle_mod):
             assert _eq(hist[: ticks[a], a], rr["hist"][: ticks[a], a]), a
         assert _eq(sd.cpu().numpy(), rr["state"])
     assert rr["status"][0] == 0 and rr["ticks"][0] == 98                          # the reference's scenario reaches its goal in 98 calls
+
+
+def test_pf_tick_equals_the_reference_lines(crx, oracle_mod):
+    """pf_localization + resampling (src/particle_filter.cpp:73-148) compiled from the reference's own lines, draws injected, against
+    the kernel.  The kernel takes the three 100-term sums of a tick as a tree over the wavefront, Eigen in its own vectorised order:
+    with at most two non-zero weights the order cannot matter and the tick must agree bit for bit (particles, weights, estimate,
+    ancestors; of the covariance the upper triangle — the kernel mirrors it, the reference rounds (w dx_r) dx_c and (w dx_c) dx_r
+    separately); with 100 live particles the motion of every particle bit for bit and the sums at 2e-6."""
+    NP = R.pf_np()
+    rng = np.random.default_rng(83)
+    rsim4 = (1.0, 0.0, 0.0, float(np.float32(oracle_mod.oracle_lib.PF_RSIM[1])))
+    RFID = np.array([[10.0, 0.0], [10.0, 10.0], [0.0, 15.0], [-5.0, 20.0]], np.float32)
+    u = np.array([1.0, 0.1], np.float32)
+    n = 48
+    px = np.stack([rng.normal(3, 1.0, (n, NP)), rng.normal(4, 1.0, (n, NP)), rng.uniform(-3.2, 3.2, (n, NP)), rng.normal(1, 0.3, (n, NP))], axis=2).astype(np.float32)
+    pw = np.zeros((n, NP), np.float32)
+    nrm = rng.standard_normal((n, NP, 2)).astype(np.float32)
+    uni = rng.uniform(1.0, 2.0, (n, NP)).astype(np.float32)
+    nobs = rng.integers(0, 5, n).astype(np.int32)
+    obs = np.zeros((n, 4, 3), np.float32)
+    for a in range(n):
+        k = nobs[a]
+        obs[a, :k] = np.concatenate([np.hypot(3 - RFID[:k, :1], 4 - RFID[:k, 1:]) + rng.normal(0, 0.2, (k, 1)), RFID[:k]], axis=1)
+        if a < n // 2:                           # two (or one) live particles, near the truth so that their weights do not underflow
+            live = rng.choice(NP, 2 if a % 4 else 1, replace=False)
+            pw[a, live] = rng.uniform(0.1, 1.0, len(live))
+            px[a, live, :2] = np.array([3.0, 4.0]) + rng.normal(0, 0.05, (len(live), 2))
+            nrm[a, live] *= 0.05
+        else:
+            w = rng.uniform(0.2, 1.0, NP); pw[a] = w / w.sum()
+    ref = []
+    for a in range(n):
+        pr, wr, xr, Pr = R.pf_localization(px[a], pw[a], obs[a, :nobs[a]], u, nrm[a], rsim=rsim4)
+        p2, w2 = R.pf_resampling(pr, wr, uni[a])
+        ref.append((pr, wr, xr, Pr, p2, w2))
+    pxd, pwd = _t(px), _t(pw)
+    xe, Pe, _, nres = crx.pf_run(pxd, pwd, _t(obs[None]), _t(nobs[None]), _t(np.repeat(u[None, None], n, 1)), _t(nrm[None]), _t(uni[None]))
+    pxk, pwk, xe, Pe = pxd.cpu().numpy(), pwd.cpu().numpy(), xe.cpu().numpy(), Pe.cpu().numpy().reshape(n, 4, 4)     # [c][r] column-major
+    close = lambda g, w: np.max(np.abs(g.astype(np.float64) - w)) <= 2e-6 * max(1.0, np.max(np.abs(w)))
+    for a in range(n):
+        pr, wr, xr, Pr, p2, w2 = ref[a]
+        Prm = Pr.reshape(4, 4)
+        if a < n // 2:
+            assert _eq(pxk[a], p2) and _eq(pwk[a], w2) and _eq(xe[a], xr), a                     # the whole tick, ancestors included
+            for c in range(4):
+                for r in range(c + 1):
+                    assert Pe[a, c, r] == Prm[c, r], (a, r, c)
+            assert close(Pe[a], Prm)
+        else:
+            resampled = not _eq(w2, wr)
+            if not resampled:
+                assert _eq(pxk[a], pr)                                                           # motion model of every particle: exact
+                assert close(pwk[a] * NP, wr * NP)
+            assert close(xe[a], xr) and close(Pe[a], Prm), a
 
 
 @pytest.mark.parametrize("T", [6, 21])

@@ -321,7 +321,10 @@ void crx_frenet_default_config(crx_frenet_config* c);
  * (<= 64 lateral offsets, horizons x target speeds <= 64, <= 64 time steps, horizons x speeds x time steps <= 2048) */
 int crx_frenet_num_paths(const crx_frenet_config* cfg);
 /* host: Spline2D(wx, wy) -> coef[9][nx] (include/cubic_spline.h:53-65, :95-116, :172-186).  The nx-by-nx float system is
- * solved as the reference solves it, A.colPivHouseholderQr().solve(B) in float (csrc/crx_qr.h), bit for bit. */
+ * solved as the reference solves it, A.colPivHouseholderQr().solve(B) in float: csrc/crx_qr.h restates Eigen 3.3.9's
+ * ColPivHouseholderQR with ascending loops.  That is Eigen's own order for the 2x2 / 3x3 polynomial systems (every reduction is
+ * shorter than a SIMD packet) and bit-identical to the Eigen STAND-IN of the reference-line build for any nx; against real Eigen,
+ * whose GEMV kernels may associate the nx x nx products differently, last-ulp differences are possible for nx >= 4 (unpinned). */
 int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef);
 /* host: the course sampled as main :205-213 does (float i += 0.1); returns the sample count, fills up to cap of them */
 int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap);

@@ -53,7 +53,7 @@ def test_structured_iteration_other_parameters(host, oracle_mod, kind, dim):
     """Other dt / L / eps / iteration caps (the block structure does not depend on them), wide speed range."""
     rng = np.random.default_rng(5)
     v = np.concatenate([rng.uniform(-30, 30, 500), 10.0 ** rng.uniform(-6, 2.5, 300) * rng.choice([-1, 1], 300)]).astype(np.float32)
-    for dt, L, eps, maxiter in ((0.1, 0.5, 1e-3, 40), (0.05, 2.9, 0.01, 150), (0.2, 0.5, 1e-4, 7), (0.1, 0.5, 0.01, 1)):
+    for dt, L, eps, maxiter in ((0.1, 0.5, 1e-3, 40), (0.05, 2.9, 0.01, 150), (0.2, 0.5, 1e-4, 7), (0.1, 0.5, 0.01, 1), (0.1, 0.5, 0.01, 0), (0.1, 0.5, 1e9, 9)):
         A, B, Q, R = oracle_mod.lqr_build(v, dim, dt=dt, L=L)
         Xo, _, ito = oracle_mod.dare(A, B, Q, R, eps=eps, maxiter=maxiter)
         X, it = host(kind, v, dim, dt=dt, L=L, eps=eps, maxiter=maxiter)

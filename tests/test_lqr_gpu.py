@@ -35,7 +35,8 @@ def test_dare_from_v_both_register_layouts_bit_exact(crx, oracle_mod, dim, n, la
     from cpprobotics_amd.experimental import dlqr_from_v_lanes
     v = lqr_speeds(n, seed=7 * n + dim)
     v[0] = 0.0
-    for dt, L, eps, maxiter in ((0.1, 0.5, 0.01, 150), (0.05, 2.9, 1e-3, 40), (0.1, 0.5, 0.01, 1)):
+    for dt, L, eps, maxiter in ((0.1, 0.5, 0.01, 150), (0.05, 2.9, 1e-3, 40), (0.1, 0.5, 0.01, 1), (0.1, 0.5, 0.01, 0), (0.1, 0.5, 0.01, 2),
+                                (0.1, 0.5, 0.01, 3), (0.1, 0.5, 1e9, 9), (0.2, 0.5, 1e-4, 77)):      # caps 0 / odd / even, a test that passes at once
         A, B, Q, R = oracle_mod.lqr_build(v, dim, dt=dt, L=L)
         Xo, Ko, ito = oracle_mod.dare(A, B, Q, R, eps=eps, maxiter=maxiter)
         K, X, it = dlqr_from_v_lanes(_t(v), dim, lanes, dt=dt, L_wheelbase=L, eps=eps, maxiter=maxiter)

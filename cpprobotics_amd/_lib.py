@@ -163,7 +163,7 @@ def check(rc, what):
         raise CrxError(f"{what} failed with status {rc}: {msg}")
 
 
-def require_cuda(*tensors):
+def require_cuda(*tensors, dtypes=None):
     """Every tensor handed to a *_dev entry point: on the device, contiguous, float32 or int32 (the kernels reinterpret the
     bytes as float4/float2/int — any other dtype would be silently misread) and 16-byte aligned (vector loads)."""
     import torch
@@ -176,20 +176,20 @@ def require_cuda(*tensors):
             raise CrxError("crx *_dev entry points need device tensors")
         if not t.is_contiguous():
             raise CrxError("crx needs contiguous tensors")
-        if t.dtype not in (torch.float32, torch.int32):
+        if t.dtype not in (dtypes or (torch.float32, torch.int32)):
             raise CrxError(f"crx needs float32 (or int32 index) tensors, got {t.dtype}")
         if t.numel() and t.data_ptr() % 16:
             raise CrxError("crx needs 16-byte aligned tensors (got an offset view; .clone() it)")
 
 
 def expect(name, t, kind, *shape, optional=False):
-    """Shape/dtype contract of one argument: kind 'f' = float32, 'i' = int32; shape entries may be None (any)."""
+    """Shape/dtype contract of one argument: kind 'f' = float32, 'd' = float64, 'i' = int32; shape entries may be None (any)."""
     import torch
     if t is None:
         if optional:
             return
         raise CrxError(f"{name}: missing")
-    want = torch.float32 if kind == "f" else torch.int32
+    want = {"f": torch.float32, "d": torch.float64, "i": torch.int32}[kind]
     if t.dtype != want:
         raise CrxError(f"{name}: expected {want}, got {t.dtype}")
     if len(shape) != t.dim() or any(s is not None and int(s) != int(d) for s, d in zip(shape, t.shape)):

@@ -1162,6 +1162,28 @@ int crx_smooth_yaw(float* cyaw, int n) {   // src/model_predictive_control.cpp:1
   return CRX_OK;
 }
 
+// Probe of the device's double sin / cos (crx_dsincos.h, the table staged in LDS as the Frenet kernel does): c[i] = cos(x[i]),
+// s[i] = sin(x[i]).  tests/test_dsincos.py compares the bits with the host libm's.
+namespace crx {
+__global__ void __launch_bounds__(256) dsincos_probe_kernel(int n, const double* __restrict__ x, double* __restrict__ s, double* __restrict__ c) {
+  __shared__ uint64_t s_sc[kDsincosTabLen];
+  for (int i = threadIdx.x; i < kDsincosTabLen; i += blockDim.x) s_sc[i] = kDsincosTab[i];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  c[i] = dcos_(v, s_sc);
+  s[i] = dsin_(v, s_sc);
+}
+}  // namespace crx
+int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream) {
+  if (n < 0 || (n > 0 && (!x || !s || !c))) return fail(CRX_ERR_INVALID, "dsincos: bad arguments");
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::dsincos_probe_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, x, s, c);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,

@@ -16,11 +16,11 @@
 //
 // Arithmetic contract: every expression keeps the reference's C++ types (float members, double macros,
 // std::pow(float,int) and std::cos(float + double) in double, atan2/sqrt of floats in float); atan2f is glibc-exact
-// (crx_fdlibm.h); std::pow comes from the host's libm (FrPowArg below) or is an exact product; the 3x3 / 2x2 coefficient solves
-// are Eigen's ColPivHouseholderQR restated in float (crx_qr.h).  ONE operation is not the reference's bit for bit: the double
-// cos / sin of :111-112 is the engine's own (<= 1 ulp of a double; glibc's is 0.55 ulp), which can move the float it is rounded
-// into by one ulp only when `poi + di*cos` lands within 2^-29 of a float rounding boundary.  The parity tests demand equal
-// bits on every committed seed (costs, verdicts, winners, whole episodes) with an enumerated exception list — empty so far.
+// (crx_fdlibm.h); the double cos / sin of :111-112 are glibc's sin() / cos() restated (crx_dsincos.h: bit-identical on every
+// argument float + M_PI/2 can form, two separate evaluations as in the reference's unoptimised build); std::pow comes from the
+// host's libm (FrPowArg below) or is an exact product; the 3x3 / 2x2 coefficient solves are Eigen's ColPivHouseholderQR restated
+// in float (crx_qr.h).  No operation is left to a device library: the parity tests demand equal bits (costs, verdicts, winners,
+// whole episodes) against the oracle and against the reference's own lines, without exceptions.
 // Reference quirks that decide the numbers are kept (the missing factor 5 in the quintic's first derivative,
 // quintic_polynomial.h:53; maxima starting at FLT_MIN); where the reference is undefined (a path with < 2 points on the course) the path is dropped, where it would
 // throw (s before the course) the path is dropped and status bit 2 is set.
@@ -31,7 +31,7 @@
 #include <float.h>
 #include "crx_fdlibm.h"
 #include "crx_qr.h"
-#include "mpc_kernels.hip.h"   // mpc_sincos (double)
+#include "crx_dsincos.h"
 
 namespace crx {
 
@@ -119,7 +119,7 @@ __device__ __forceinline__ int fr_bisect(const float* __restrict__ x, float t, i
 // What depends only on the (horizon, target speed) pair — 12 "longitudinal combos" with the reference's constants — is
 // computed once per planning call instead of once per candidate: phase A, one lane per combo: the quartic, its samples'
 // maxima and jerk sum, the hand-over samples and how many points lie on the course; phase B, one lane per (combo, time
-// step): the course position and the unit normal's (cos, sin) there (spline lookup, atan2f, double sincos), stored in an
+// step): the course position and the unit normal's (cos, sin) there (spline lookup, atan2f, double cos and sin), stored in an
 // LDS table; phase C, one lane per candidate: the lateral quintic and the walk along the table.
 struct FrTab { float px, py; double cs, sn; };   // poi[0], poi[1], cos(iyaw + pi/2), sin(iyaw + pi/2)   :108-112
 
@@ -140,9 +140,11 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
   __shared__ float s_di[kFrMaxDi], s_Ti[kFrMaxTi], s_tv[kFrMaxTv], s_t[kFrMaxT];
   __shared__ FrPow s_pw[kFrMaxT], s_pT[kFrMaxTi];
   __shared__ int s_nt[kFrMaxTi], s_cnt[4];
+  __shared__ uint64_t s_sc[kDsincosTabLen];      // glibc's sin/cos table (crx_dsincos.h): gathered per lane in phase B
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   for (int i = threadIdx.x; i < 9 * nx; i += blockDim.x) s_coef[i] = coef[i];
   for (int i = threadIdx.x; i < 2 * nob; i += blockDim.x) s_ob[i] = ob[i];
+  for (int i = threadIdx.x; i < kDsincosTabLen; i += blockDim.x) s_sc[i] = kDsincosTab[i];
   if (threadIdx.x == 0) {     // the sample grids, by the reference's own float accumulation (:55-56,:58,:66-68); caps checked by the host
     int ndi = 0, nTi = 0, ntv = 0, ntt = 0;
     for (float di = (float)(-1 * g.max_road_width); di < g.max_road_width && ndi < kFrMaxDi; di += g.d_road_w) s_di[ndi++] = di;
@@ -215,7 +217,9 @@ frenet_run_kernel(int n, int max_ticks, float* __restrict__ state, const float* 
       const float ddx = cbx[segd] + 2.0f * ccx[segd] * dxd + 3.0f * cdx[segd] * dxd * dxd;
       const float ddy = cby[segd] + 2.0f * ccy[segd] * dxd + 3.0f * cdy[segd] * dxd * dxd;
       const float iyaw = atan2f_(ddy, ddx);
-      mpc_sincos((double)iyaw + half_pi, &r.sn, &r.cs);
+      const double nyaw = (double)iyaw + half_pi;
+      r.cs = dcos_(nyaw, s_sc);                      // :111
+      r.sn = dsin_(nyaw, s_sc);                      // :112
       tab[e] = r;
     }
     __builtin_amdgcn_wave_barrier();

@@ -10,6 +10,7 @@ _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
+    "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
@@ -110,3 +111,14 @@ def ekf_run_pair(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):
                                                 q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.ptr(flag),
                                                 L.stream_ptr()), "crx_x_ekf_run_pair_batch_dev")
     return bool(flag[0].item() == 0)
+
+
+def dsincos(x):
+    """(sin(x), cos(x)) of a float64 tensor as the Frenet kernel evaluates them on the device (csrc/crx_dsincos.h)."""
+    import torch
+    L.require_cuda(x, dtypes=(torch.float64,))
+    n = x.numel()
+    L.expect("x", x, "d", n)
+    s, c = torch.empty_like(x), torch.empty_like(x)
+    L.check(xlib().crx_x_dsincos_dev(n, L.ptr(x), L.ptr(s), L.ptr(c), L.stream_ptr()), "crx_x_dsincos_dev")
+    return s, c

@@ -25,6 +25,10 @@ int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, 
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup);
 
+/* Probe of the device's double-precision sin / cos (csrc/crx_dsincos.h: glibc 2.35's sin() / cos() restated for the Frenet
+ * planner's frenet_optimal_trajectory.cpp:111-112): s[i] = sin(x[i]), c[i] = cos(x[i]) for |x[i]| < 105414336 (NaN beyond). */
+int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream);
+
 /* crx_ekf_run_batch_dev through the 64-bit-address instantiations of the fused kernel whatever n is (the product entry point
  * switches to them above 4 M vehicles). */
 int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,

@@ -15,7 +15,9 @@
 #     oracle/ref_shim/Eigen/Eigen, which restates Eigen 3.3.9's evaluation order (see its header).  `ref_eigen_kind()` in the
 #     library says which one was used; tests report it.
 #   * CppAD / IPOPT: oracle/ref_shim/cppad_standin.h — AD<double> = double, ipopt::solve captures the problem it is handed.
-# Flags: -std=gnu++11 as the reference's CMakeLists.txt:4 (no -march: SSE2, no FMA); -O1 -ffp-contract=off changes no result.
+# Flags: -std=gnu++11 as the reference's CMakeLists.txt:4 (no -march: SSE2, no FMA); -O1 -ffp-contract=off changes no result
+# PROVIDED sin/cos stay the separate libm calls of the reference's unoptimised build: -fdisable-tree-sincos keeps GCC from
+# merging `cos(x) ... sin(x)` into one sincos(), which in glibc rounds differently from sin()/cos() (double: ~1 call in 1000).
 set -euo pipefail
 REF=${1:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -71,7 +73,7 @@ if echo '#include <Eigen/Eigen>' | g++ -x c++ -fsyntax-only - 2>/dev/null; then 
 elif [ -f /usr/include/eigen3/Eigen/Eigen ]; then EIGEN_INC="-I/usr/include/eigen3"; KIND=1
 else EIGEN_INC="-I$HERE/ref_shim"; KIND=0; fi
 build_flavour() {      # $1 = library name, $2 = extra flags
-  local CXXFLAGS="-std=gnu++11 -O1 -ffp-contract=off -fPIC -w -I$GEN -I$REF/include $EIGEN_INC -DREF_EIGEN_KIND=$KIND $2"
+  local CXXFLAGS="-std=gnu++11 -O1 -ffp-contract=off -fdisable-tree-sincos -fPIC -w -I$GEN -I$REF/include $EIGEN_INC -DREF_EIGEN_KIND=$KIND $2"
   local OBJS=() tag="$1"
   for f in "$HERE"/ref_shim/ref_*.cpp; do
     o="$OUT/$(basename "${f%.cpp}").$tag.o"

@@ -2,10 +2,9 @@
 
 Every cost, every check_paths verdict, every winner, every tick of every episode must equal the oracle's (itself equal to the
 reference's own lines bit for bit, tests/test_oracle_vs_ref.py).  The kernel's std::pow values are libm's (evaluated by the C ABI
-entry point on the time grid), atan2f / sqrtf are glibc-exact; the one operation that is not the reference's own is the double
-cos / sin of frenet_optimal_trajectory.cpp:111-112 (<= 1 ulp of a double), which can move the float it is rounded into only
-when the double lands within 2^-29 of a float rounding boundary.  If that ever happens on a committed seed the case is listed
-in KNOWN_EXCEPTIONS by (test, agent, path) with the reason — the list is empty: no committed seed hits it."""
+entry point on the time grid), atan2f / sqrtf and the double cos / sin of frenet_optimal_trajectory.cpp:111-112 are glibc's
+bit for bit (crx_fdlibm.h, crx_dsincos.h; tests/test_fdlibm.py, tests/test_dsincos.py): no operation is left that could differ.
+KNOWN_EXCEPTIONS — (test, agent, path) -> reason — stays as the place where a deviation would have to be written down; it is empty."""
 import numpy as np
 import pytest
 

@@ -646,20 +646,36 @@ int crx_update_batch_dev(int n, float* state, const float* a, const float* delta
   return CRX_OK;
 }
 
-int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+// lanes_per_agent: 0 = by batch size (a DPP quad per agent while the batch would leave SIMDs idle with one agent per lane, and the
+// course fits in LDS), 1 / 4 = forced (crx_x_lqr_closed_loop_lanes_dev)
+static int lqr_closed_loop_launch(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
                                   const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
-                                  float* traj_hist, int* ticks_done, void* stream) {
-  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
+                                  float* traj_hist, int* ticks_done, void* stream, int lanes_per_agent) {
+  if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state) ||
+      (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4))
     return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
+  if (lanes_per_agent == 4 && !use_lds(course)) return fail(CRX_ERR_INVALID, "lqr_closed_loop: the four-lane layout needs a course that fits in LDS");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
   const crx::VehicleParams vp = vparams(veh, 0);
   const unsigned bs = iter_block();
-  const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
+  const bool quad = lanes_per_agent == 4 || (lanes_per_agent == 0 && n <= kDareQuadMaxAgents && use_lds(course));
+  if (quad) {
+    const dim3 grid(blocks_for((size_t)n * 4, crx::kTrackBlock)), block(crx::kTrackBlock);
+#define CRX_LAUNCH_LOOPQ(DIM) \
+    hipLaunchKernelGGL((crx::lqr_closed_loop_quad_kernel<DIM>), grid, block, lds_bytes(course), s, n, loop->max_ticks, state, cv, \
+                       pe, pth_e, ind, p.dt, p.L, p.eps, p.maxiter, vp, loop->goal_x, loop->goal_y, loop->goal_dis, loop->kp,     \
+                       loop->stop_speed, traj_hist, ticks_done)
+    if (dim == 5) CRX_LAUNCH_LOOPQ(5); else CRX_LAUNCH_LOOPQ(4);
+#undef CRX_LAUNCH_LOOPQ
+    CRX_HIP(hipGetLastError());
+    return CRX_OK;
+  }
+  const dim3 grid(blocks_for(n, bs)), block(bs);
 #define CRX_LAUNCH_LOOP(DIM, LDS) \
   hipLaunchKernelGGL((crx::lqr_closed_loop_kernel<DIM, LDS>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, loop->max_ticks, state, cv, \
                      pe, pth_e, ind, p.dt, p.L, p.eps, p.maxiter, vp, loop->goal_x, loop->goal_y, loop->goal_dis, loop->kp,        \
@@ -669,6 +685,16 @@ int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course
 #undef CRX_LAUNCH_LOOP
   CRX_HIP(hipGetLastError());
   return CRX_OK;
+}
+int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                                  const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                                  float* traj_hist, int* ticks_done, void* stream) {
+  return lqr_closed_loop_launch(n, dim, state, course, pe, pth_e, ind, prm, veh, loop, traj_hist, ticks_done, stream, 0);
+}
+int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                                    const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                                    float* traj_hist, int* ticks_done, void* stream, int lanes_per_agent) {
+  return lqr_closed_loop_launch(n, dim, state, course, pe, pth_e, ind, prm, veh, loop, traj_hist, ticks_done, stream, lanes_per_agent);
 }
 
 int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx_course* course, const int* pind, int nsearch,

@@ -362,24 +362,11 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
 // (~14 scalar instructions, which cost a lone wave as much as vector ones) and no live-out registers but the iterate itself.
 typedef unsigned long long dare_mask_t;
 
-template <int DIM>
-__global__ void __launch_bounds__(256)
-dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
-                        float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
-  constexpr int NN = DIM * DIM;
-  constexpr int M = (DIM == 5) ? 2 : 1;
-  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t a = t >> 2;
-  const int r = (int)(threadIdx.x & 3);
-  const bool live = a < (size_t)n;
-  const float v = live ? vg[a] : 1.0f;
-  QuadLane<float, uint32_t> c;
-  c.dt = dt; c.v = v; c.bd = dt;
-  c.bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
-  c.a = (r == 0) ? 1.0f : ((r == 2) ? v : dt);
-  c.m2 = (r == 2) ? 0xffffffffu : 0u;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c.q[j] = (r == j) ? 1.0f : 0.0f;
+// The quad's loop: iterate from X = Q = I until the test passes or the cap is reached, for the agents of `todo` (a lane mask, whole
+// quads).  emit(who, W, w44, it): the agents of `who` return iterate (W = this lane's row of the 4x4 block, w44) after `it`
+// evaluations — called from the pass in which their test succeeds (or after the cap), so nothing but the iterate is carried.
+template <int DIM, class Emit>
+__device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32_t>& c, float eps, int maxiter, dare_mask_t todo, Emit&& emit) {
   float X[4], Y[4], x44 = 1.0f, y44 = 1.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) X[j] = c.q[j];
@@ -387,32 +374,6 @@ dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L,
     if constexpr (DIM == 5) return dare5_quad_iter(c, Xi, xi44, Xo, xo44);
     else return dare4_quad_iter(c, Xi, Xo);
   };
-  // the agents of `who` hand back iterate (W, w44) after `it` evaluations
-  auto emit = [&](dare_mask_t who, const float* W, float w44, int it) {
-    if (!((who >> (threadIdx.x & 63)) & 1)) return;
-    if (Xg) {
-      float* Xa = Xg + a * NN;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Xa[r + DIM * j] = W[j];
-      if constexpr (DIM == 5) {
-        Xa[r + DIM * 4] = 0.0f; Xa[4 + DIM * r] = 0.0f;
-        if (r == 3) Xa[24] = w44;
-      }
-    }
-    if (Kg && r == 3) {       // the gain needs rows 3 (this lane's) and 4 of X only
-      float Xf[NN], K[M * DIM];
-#pragma unroll
-      for (int j = 0; j < NN; ++j) Xf[j] = 0.0f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) Xf[3 + DIM * j] = W[j];
-      if constexpr (DIM == 5) { Xf[24] = w44; dlqr5_v_gain(dt, v, c.bv, dt, Xf, K); }
-      else dlqr4_v_gain(dt, v, c.bv, Xf, K);
-#pragma unroll
-      for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
-    }
-    if (iters && r == 0) iters[a] = it;
-  };
-  dare_mask_t todo = __builtin_amdgcn_ballot_w64(live);     // agents whose test has not passed yet
   if (maxiter <= 0) { emit(todo, X, x44, 0); return; }
   // Two evaluations per trip (X -> Y -> X); an odd cap is made even by one evaluation ahead of the loop.
   int i = 0;
@@ -438,6 +399,66 @@ dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L,
     }
   }
   if (todo) emit(todo, X, x44, maxiter);                    // agents that ran into the cap return the last evaluation
+}
+
+// the constants of quad lane r (row r of the 4x4 block) for speed v
+__device__ __forceinline__ QuadLane<float, uint32_t> dare_quad_lane(int r, float v, float dt, double L) {
+  QuadLane<float, uint32_t> c;
+  c.dt = dt; c.v = v; c.bd = dt;
+  c.bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
+  c.a = (r == 0) ? 1.0f : ((r == 2) ? v : dt);
+  c.m2 = (r == 2) ? 0xffffffffu : 0u;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c.q[j] = (r == j) ? 1.0f : 0.0f;
+  return c;
+}
+
+// the gain from the lane that holds row 3 of the 4x4 block (rows 3 and 4 of X are all dlqr needs)
+template <int DIM>
+__device__ __forceinline__ void dlqr_quad_gain_row3(const QuadLane<float, uint32_t>& c, const float* W, float w44, float* K) {
+  constexpr int NN = DIM * DIM;
+  float Xf[NN];
+#pragma unroll
+  for (int j = 0; j < NN; ++j) Xf[j] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) Xf[3 + DIM * j] = W[j];
+  if constexpr (DIM == 5) { Xf[24] = w44; dlqr5_v_gain(c.dt, c.v, c.bv, c.dt, Xf, K); }
+  else dlqr4_v_gain(c.dt, c.v, c.bv, Xf, K);
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256)
+dare_from_v_quad_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
+                        float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
+  constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t a = t >> 2;
+  const int r = (int)(threadIdx.x & 3);
+  const bool live = a < (size_t)n;
+  const float v = live ? vg[a] : 1.0f;
+  const QuadLane<float, uint32_t> c = dare_quad_lane(r, v, dt, L);
+  // the agents of `who` hand back iterate (W, w44) after `it` evaluations
+  auto emit = [&](dare_mask_t who, const float* W, float w44, int it) {
+    if (!((who >> (threadIdx.x & 63)) & 1)) return;
+    if (Xg) {
+      float* Xa = Xg + a * NN;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Xa[r + DIM * j] = W[j];
+      if constexpr (DIM == 5) {
+        Xa[r + DIM * 4] = 0.0f; Xa[4 + DIM * r] = 0.0f;
+        if (r == 3) Xa[24] = w44;
+      }
+    }
+    if (Kg && r == 3) {       // the gain needs rows 3 (this lane's) and 4 of X only
+      float K[M * DIM];
+      dlqr_quad_gain_row3<DIM>(c, W, w44, K);
+#pragma unroll
+      for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
+    }
+    if (iters && r == 0) iters[a] = it;
+  };
+  riccati_from_v_quad<DIM>(c, eps, maxiter, __builtin_amdgcn_ballot_w64(live), emit);
 }
 
 }  // namespace crx

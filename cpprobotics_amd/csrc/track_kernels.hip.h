@@ -260,6 +260,154 @@ lqr_closed_loop_kernel(int n, int max_ticks, float* __restrict__ state, CourseVi
   if (ticks_done) ticks_done[a] = ticks;
 }
 
+// ---- the closed LQR loop, four lanes per agent -----------------------------------------------------------------------------------
+// BASELINE-sized batches (configs[2]: 16,384 agents) are 256 waves of the kernel above on 1,024 SIMDs, each a latency chain of
+// ~11 k instructions per tick.  Here an agent is a DPP quad (dare_kernels.hip.h): the Riccati iteration runs one row of X per
+// lane (~0.6x the instructions per evaluation, and a wave waits for the slowest of 16 agents, not of 64), the course scan is
+// split four ways (lane r scores the pairs j = r mod 4; the quad keeps the lexicographic minimum of (distance, index), which
+// is the sequential scan's first strict minimum), and everything else of a tick — error state, -K x, update, goal test — is
+// evaluated redundantly by the four lanes on identical registers.  The same batch then fills every SIMD.  Same arithmetic per
+// coefficient as the one-lane kernel: same bits (tests/test_track_gpu.py runs both layouts against the oracle).
+// The gain of the pass in which an agent's test succeeds travels through a per-wave LDS slot (written by the lane that holds row 3).
+template <int CTRL>
+__device__ __forceinline__ float quad_perm_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_perm_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
+
+// calc_nearest_index for a quad: lane r scans the LDS pairs r, r+4, ...; every lane returns the agent's result.
+__device__ __forceinline__ float calc_nearest_index_quad(float sx, float sy, const CourseView& c, const float2* __restrict__ pts, int& ind, int r) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  float mind = FLT_MAX;
+  int best = 0x7fffffff;                            // "no point compared smaller" (NaN position)
+  const float4* __restrict__ pairs = reinterpret_cast<const float4*>(pts);
+  const v2f s2x = {sx, sx}, s2y = {sy, sy};
+  const int np = (c.n + 1) >> 1;
+  for (int j = r; j < np; j += 4) {
+    const float4 q = pairs[j];
+    const v2f px = {q.x, q.y}, py = {q.z, q.w};
+    const v2f idx = px - s2x, idy = py - s2y;
+    const v2f d_e = idx * idx + idy * idy;
+    if (d_e.x < mind) { mind = d_e.x; best = 2 * j; }
+    if (d_e.y < mind) { mind = d_e.y; best = 2 * j + 1; }
+  }
+  {                                                 // lanes (0,1) <-> (1,0), (2,3) <-> (3,2); then pairs <-> pairs
+    const float om = quad_perm_f<0xb1>(mind); const int ob = quad_perm_i<0xb1>(best);      // quad_perm [1,0,3,2]
+    if (om < mind || (om == mind && ob < best)) { mind = om; best = ob; }
+  }
+  {
+    const float om = quad_perm_f<0x4e>(mind); const int ob = quad_perm_i<0x4e>(best);      // quad_perm [2,3,0,1]
+    if (om < mind || (om == mind && ob < best)) { mind = om; best = ob; }
+  }
+  if (best != 0x7fffffff) ind = best;
+  best = ind;
+  const int j = best < 0 ? 0 : (best >= c.n ? c.n - 1 : best);
+  const float dxl = c.cx[j] - sx, dyl = c.cy[j] - sy;
+  const float angle = (float)yaw_p2p(c.cyaw[j] - atan2f_(dyl, dxl));
+  if (angle < 0) mind = -mind;
+  return mind;
+}
+
+// -K x, feed-forward, feedback: the tail of lqr_steering_control from the error state on (:134-150 / :121-132)
+template <int DIM>
+__device__ __forceinline__ LqrCtl lqr_control_from_gain(const float* K, float e, float th_e, float pe, float pth_e, float sv, float spj, float k,
+                                                        double dt, double L) {
+  const float x0 = e;
+  const float x1 = (float)((double)(e - pe) / dt);
+  const float x2 = th_e;
+  const float x3 = (float)((double)(th_e - pth_e) / dt);
+  LqrCtl out;
+  float u0;
+  if (DIM == 5) {
+    const float x4 = sv - spj;
+    float t[5], s[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) { t[j] = (-K[0 + 2 * j]); s[j] = (-K[1 + 2 * j]); }
+    t[0] *= x0; t[1] *= x1; t[2] *= x2; t[3] *= x3; t[4] *= x4;
+    s[0] *= x0; s[1] *= x1; s[2] *= x2; s[3] *= x3; s[4] *= x4;
+    u0 = (t[0] + t[1]) + (t[2] + (t[3] + t[4]));
+    out.ai = (s[0] + s[1]) + (s[2] + (s[3] + s[4]));
+  } else {
+    const float t0 = (-K[0]) * x0, t1 = (-K[1]) * x1, t2 = (-K[2]) * x2, t3 = (-K[3]) * x3;
+    u0 = (t0 + t2) + (t1 + t3);
+    out.ai = 0.0f;
+  }
+  const float ff = (float)atan(L * (double)k);
+  const float fb = (float)yaw_p2p(u0);
+  out.delta = ff + fb;
+  return out;
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(kTrackBlock)
+lqr_closed_loop_quad_kernel(int n, int max_ticks, float* __restrict__ state, CourseView c, float* __restrict__ pe_io,
+                            float* __restrict__ pth_io, int* __restrict__ ind_io, double dt, double L, float eps, int maxiter,
+                            VehicleParams vp, float goal_x, float goal_y, float goal_dis, double kp, float stop_speed,
+                            float* __restrict__ traj_hist, int* __restrict__ ticks_done) {
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  constexpr int APB = kTrackBlock / 4;               // agents per workgroup (one wave)
+  extern __shared__ __attribute__((aligned(16))) float2 pts[];
+  __shared__ float s_K[APB][M * DIM + (DIM == 5 ? 1 : 0)];     // odd row stride: the four readers of a quad hit one bank row each
+  stage_course(c, pts);
+  const size_t a = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int r = (int)(threadIdx.x & 3), q = (int)(threadIdx.x >> 2);
+  const bool live = a < (size_t)n;
+  const size_t aa = live ? a : 0;
+  float4 s = reinterpret_cast<const float4*>(state)[aa];
+  float pe = pe_io ? pe_io[aa] : 0.0f, pth = pth_io ? pth_io[aa] : 0.0f;
+  int ind = ind_io ? ind_io[aa] : 0;
+  bool done = !live;
+  int ticks = 0;
+  const float dtf = (float)dt;
+  for (int t = 0; t < max_ticks; ++t) {
+    if (__all(done)) break;
+    float4 sn = s;
+    int ind_n = (DIM == 5) ? 0 : ind;
+    const float e = calc_nearest_index_quad(sn.x, sn.y, c, pts, ind_n, r);
+    const int j = ind_n < 0 ? 0 : (ind_n >= c.n ? c.n - 1 : ind_n);
+    const float k = c.ck[j];
+    const float th_e = (float)yaw_p2p(sn.z - c.cyaw[j]);
+    const QuadLane<float, uint32_t> ql = dare_quad_lane(r, sn.w, dtf, L);
+    auto emit = [&](dare_mask_t who, const float* W, float w44, int) {
+      if (r != 3 || !((who >> (threadIdx.x & 63)) & 1)) return;
+      float K[M * DIM];
+      dlqr_quad_gain_row3<DIM>(ql, W, w44, K);
+#pragma unroll
+      for (int i = 0; i < M * DIM; ++i) s_K[q][i] = K[i];
+    };
+    riccati_from_v_quad<DIM>(ql, eps, maxiter, __builtin_amdgcn_ballot_w64(!done), emit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float K[M * DIM];
+#pragma unroll
+    for (int i = 0; i < M * DIM; ++i) K[i] = s_K[q][i];
+    __builtin_amdgcn_wave_barrier();                 // the next tick's writes come after these reads
+    const LqrCtl u = lqr_control_from_gain<DIM>(K, e, th_e, pe, pth, sn.w, c.sp[j], k, dt, L);
+    float ai = u.ai;
+    if (DIM == 4) {
+      const int js = ind_n < 0 ? 0 : (ind_n >= c.n ? c.n - 1 : ind_n);
+      ai = (float)(kp * (double)(c.sp[js] - sn.w));
+    }
+    update_dev(sn.x, sn.y, sn.z, sn.w, ai, u.delta, vp);
+    if (DIM == 4 && fabsf(sn.w) <= stop_speed) ind_n += 1;
+    if (!done) {
+      s = sn; pe = e; pth = th_e; ind = ind_n;
+      ticks = t + 1;
+      if (traj_hist && r == 0) reinterpret_cast<float4*>(traj_hist)[(size_t)t * n + a] = s;
+      const float dx = s.x - goal_x, dy = s.y - goal_y;
+      if (sqrtf(dx * dx + dy * dy) <= goal_dis) done = true;
+    }
+  }
+  if (!live || r != 0) return;
+  reinterpret_cast<float4*>(state)[a] = s;
+  if (pe_io) pe_io[a] = pe;
+  if (pth_io) pth_io[a] = pth;
+  if (ind_io) ind_io[a] = ind;
+  if (ticks_done) ticks_done[a] = ticks;
+}
+
 // ---- MPC front-end --------------------------------------------------------------------------------------
 // calc_nearest_index(state, cx, cy, cyaw, pind) of model_predictive_control.cpp: window [pind, pind+N_IND_SEARCH).
 // The reference reads cx[i] without a bounds check (:110); the window is clipped to the course here.

@@ -10,6 +10,8 @@ _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
+    "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
+                                             C.POINTER(L.LoopParams), _P, _P, _P, _I]),
     "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
@@ -122,3 +124,24 @@ def dsincos(x):
     s, c = torch.empty_like(x), torch.empty_like(x)
     L.check(xlib().crx_x_dsincos_dev(n, L.ptr(x), L.ptr(s), L.ptr(c), L.stream_ptr()), "crx_x_dsincos_dev")
     return s, c
+
+
+def closed_loop_prediction_lanes(state, course, goal, lanes_per_agent, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L_wheelbase=0.5, eps=0.01,
+                                 maxiter=150, kp=1.0, stop_speed=0.05, want_hist=False, pe=None, pth_e=None, ind=None):
+    """track.closed_loop_prediction with the register layout forced: 1 = one agent per lane, 4 = one agent per DPP quad."""
+    import torch
+    from .track import _lqr_params, vehicle_params, loop_params
+    L.require_cuda(state, pe, pth_e, ind)
+    n = state.shape[0]
+    L.expect("state", state, "f", n, 4)
+    if goal_dis is None:
+        goal_dis = 0.3 if dim == 5 else 0.5
+    ticks = torch.zeros((n,), dtype=torch.int32, device=state.device)
+    hist = torch.zeros((max_ticks, n, 4), dtype=torch.float32, device=state.device) if want_hist else None
+    p = _lqr_params(dt, L_wheelbase, eps, maxiter)
+    vp = vehicle_params(False, dt=float(dt), wheelbase=float(L_wheelbase))
+    lp = loop_params(goal, goal_dis, max_ticks, kp, stop_speed)
+    L.check(xlib().crx_x_lqr_closed_loop_lanes_dev(n, dim, L.ptr(state), course.ref(), L.ptr(pe), L.ptr(pth_e), L.ptr(ind), C.byref(p), C.byref(vp),
+                                                   C.byref(lp), L.ptr(hist), L.ptr(ticks), L.stream_ptr(), int(lanes_per_agent)),
+            "crx_x_lqr_closed_loop_lanes_dev")
+    return ticks, hist

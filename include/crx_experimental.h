@@ -25,6 +25,13 @@ int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, 
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup);
 
+/* crx_lqr_closed_loop_batch_dev with the register layout forced: lanes_per_agent = 1 (one agent per lane), 4 (one agent per DPP
+ * quad: the Riccati iteration one row per lane, the course scan split four ways; needs a course that fits in LDS) or 0 (what the
+ * product entry point would pick for this n). */
+int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
+                                    const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
+                                    float* traj_hist, int* ticks_done, void* stream, int lanes_per_agent);
+
 /* Probe of the device's double-precision sin / cos (csrc/crx_dsincos.h: glibc 2.35's sin() / cos() restated for the Frenet
  * planner's frenet_optimal_trajectory.cpp:111-112): s[i] = sin(x[i]), c[i] = cos(x[i]) for |x[i]| < 105414336 (NaN beyond). */
 int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream);

@@ -252,15 +252,16 @@ def update(state, a, delta, dt=0.1, wheelbase=0.5, max_steer=45.0 / 180 * _math.
 
 
 def lqr_closed_loop(state, course, goal, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L=0.5, eps=0.01, maxiter=150,
-                    max_steer=45.0 / 180 * _math.pi, kp=1.0, stop_speed=0.05, want_hist=False, agents=None):
-    """Returns (state, ticks_done, traj_hist or None, pe, pth_e, ind)."""
+                    max_steer=45.0 / 180 * _math.pi, kp=1.0, stop_speed=0.05, want_hist=False, agents=None, pe=None, pth_e=None, ind=None):
+    """Returns (state, ticks_done, traj_hist or None, pe, pth_e, ind); pe / pth_e / ind: the values carried into the first tick (default 0)."""
     state = _f32(state).copy()
     n = state.shape[0]
     cx, cy, cyaw, ck, sp = _course(course)
     if goal_dis is None:
         goal_dis = 0.3 if dim == 5 else 0.5
-    pe, pth = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
-    ind = np.zeros(n, dtype=np.int32)
+    pe = np.zeros(n, dtype=np.float32) if pe is None else _f32(pe).copy()
+    pth = np.zeros(n, dtype=np.float32) if pth_e is None else _f32(pth_e).copy()
+    ind = np.zeros(n, dtype=np.int32) if ind is None else np.ascontiguousarray(ind, dtype=np.int32).copy()
     ticks = np.zeros(n, dtype=np.int32)
     hist = np.zeros((max_ticks, n, 4), dtype=np.float32) if want_hist else None
     a0, a1 = (0, n) if agents is None else agents

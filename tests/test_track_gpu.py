@@ -106,6 +106,49 @@ def test_lqr_closed_loop_bit_exact(crx, oracle_mod, lqr_setup, dim):
         assert bit_equal(h[: tio[a], a], histo[: tio[a], a])
 
 
+@pytest.mark.parametrize("lanes", [1, 4])
+@pytest.mark.parametrize("dim", [5, 4])
+def test_lqr_closed_loop_both_layouts(crx, oracle_mod, lqr_setup, dim, lanes):
+    """One agent per lane and one agent per DPP quad, forced through the experimental entry point: every tick equals the oracle's.
+    Batch sizes that leave part of the last wave / the last quad-wave empty; carried pe / pth_e / ind; near-zero speeds (DARE cap)."""
+    from cpprobotics_amd.experimental import closed_loop_prediction_lanes
+    course, goal, dc = lqr_setup
+    for n, seed in ((1, 3), (17, 5), (203, 9)):
+        rng = np.random.default_rng(seed + dim)
+        st = tracking_agents(n, tuple(c[:200] for c in course), seed + dim, spread=0.4)
+        st[: max(1, n // 8), 3] = rng.uniform(-0.08, 0.08, max(1, n // 8))
+        pe = rng.normal(0, 0.3, n).astype(np.float32); pth = rng.normal(0, 0.2, n).astype(np.float32)
+        ind0 = rng.integers(0, len(course[0]), n).astype(np.int32)
+        max_ticks = 120
+        so, tio, histo, peo, ptho, indo = oracle_mod.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=max_ticks, want_hist=True, pe=pe, pth_e=pth, ind=ind0)
+        sd, ped, pthd, indd = _t(st), _t(pe), _t(pth), _t(ind0)
+        ticks, hist = closed_loop_prediction_lanes(sd, dc, goal, lanes, dim=dim, max_ticks=max_ticks, want_hist=True, pe=ped, pth_e=pthd, ind=indd)
+        assert np.array_equal(ticks.cpu().numpy(), tio)
+        assert bit_equal(sd.cpu().numpy(), so)
+        assert bit_equal(ped.cpu().numpy(), peo) and bit_equal(pthd.cpu().numpy(), ptho) and np.array_equal(indd.cpu().numpy(), indo)
+        h = hist.cpu().numpy()
+        for a in range(n):
+            assert bit_equal(h[: tio[a], a], histo[: tio[a], a])
+
+
+def test_lqr_closed_loop_nan_position_both_layouts(crx, oracle_mod, lqr_setup):
+    """A NaN position never compares smaller in the course scan: the index keeps its incoming value (0 in the 5-state file, the caller's in the
+    4-state file) in both layouts."""
+    from cpprobotics_amd.experimental import closed_loop_prediction_lanes
+    course, goal, dc = lqr_setup
+    st = tracking_agents(9, tuple(c[:200] for c in course), 77, spread=0.4)
+    st[2, 0] = np.nan; st[5, 1] = np.nan
+    ind0 = np.arange(9, dtype=np.int32) * 11
+    for dim in (5, 4):
+        so, tio, histo, peo, ptho, indo = oracle_mod.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=5, want_hist=True, ind=ind0)
+        for lanes in (1, 4):
+            sd, indd = _t(st), _t(ind0)
+            ticks, hist = closed_loop_prediction_lanes(sd, dc, goal, lanes, dim=dim, max_ticks=5, want_hist=True, ind=indd)
+            assert np.array_equal(ticks.cpu().numpy(), tio) and np.array_equal(indd.cpu().numpy(), indo)
+            assert np.array_equal(sd.cpu().numpy(), so, equal_nan=True) and np.array_equal(hist.cpu().numpy(), histo, equal_nan=True)
+            assert np.isnan(so[2]).any() and np.isnan(so[5]).any() and not np.isnan(np.delete(so, [2, 5], axis=0)).any()
+
+
 def test_lqr_closed_loop_host_pointer_abi(crx, oracle_mod, lqr_setup):
     from cpprobotics_amd import _lib as L
     course, goal, _ = lqr_setup

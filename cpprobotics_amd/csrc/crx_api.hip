@@ -624,9 +624,18 @@ int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const
   crx_lqr_params p;
   if (prm) p = *prm; else crx_lqr_default_params(&p);
   const unsigned bs = iter_block();
-  const dim3 grid(blocks_for(n, bs)), block(bs);
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
+  if (n <= kDareQuadMaxAgents && use_lds(course)) {      // a DPP quad per agent while one agent per lane would leave SIMDs idle
+    const dim3 qgrid(blocks_for((size_t)n * 4, crx::kTrackBlock)), qblock(crx::kTrackBlock);
+    if (dim == 5)
+      hipLaunchKernelGGL((crx::lqr_steering_control_quad_kernel<5>), qgrid, qblock, lds_bytes(course), s, n, state, cv, ind, pe, pth_e, p.dt, p.L, p.eps, p.maxiter, control);
+    else
+      hipLaunchKernelGGL((crx::lqr_steering_control_quad_kernel<4>), qgrid, qblock, lds_bytes(course), s, n, state, cv, ind, pe, pth_e, p.dt, p.L, p.eps, p.maxiter, control);
+    CRX_HIP(hipGetLastError());
+    return CRX_OK;
+  }
+  const dim3 grid(blocks_for(n, bs)), block(bs);
 #define CRX_LAUNCH_CTL(DIM, LDS) \
   hipLaunchKernelGGL((crx::lqr_steering_control_kernel<DIM, LDS>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, state, cv, ind, pe, pth_e, p.dt, p.L, p.eps, p.maxiter, control)
   if (dim == 5) { if (use_lds(course)) CRX_LAUNCH_CTL(5, true); else CRX_LAUNCH_CTL(5, false); }

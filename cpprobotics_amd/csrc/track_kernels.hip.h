@@ -408,6 +408,51 @@ lqr_closed_loop_quad_kernel(int n, int max_ticks, float* __restrict__ state, Cou
   if (ticks_done) ticks_done[a] = ticks;
 }
 
+// one control evaluation per agent, four lanes per agent (the tick of the loop above as its own launch)
+template <int DIM>
+__global__ void __launch_bounds__(kTrackBlock)
+lqr_steering_control_quad_kernel(int n, const float* __restrict__ state, CourseView c, int* __restrict__ ind_io,
+                                 float* __restrict__ pe_io, float* __restrict__ pth_io, double dt, double L, float eps,
+                                 int maxiter, float* __restrict__ control) {
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  constexpr int APB = kTrackBlock / 4;
+  extern __shared__ __attribute__((aligned(16))) float2 pts[];
+  __shared__ float s_K[APB][M * DIM + (DIM == 5 ? 1 : 0)];
+  stage_course(c, pts);
+  const size_t a = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const int r = (int)(threadIdx.x & 3), q = (int)(threadIdx.x >> 2);
+  const bool live = a < (size_t)n;
+  const size_t aa = live ? a : 0;
+  const float4 s = reinterpret_cast<const float4*>(state)[aa];
+  int ind = (DIM == 4 && ind_io) ? ind_io[aa] : 0;
+  const float pe = pe_io[aa], pth = pth_io[aa];
+  const float e = calc_nearest_index_quad(s.x, s.y, c, pts, ind, r);
+  const int j = ind < 0 ? 0 : (ind >= c.n ? c.n - 1 : ind);
+  const float k = c.ck[j];
+  const float th_e = (float)yaw_p2p(s.z - c.cyaw[j]);
+  const QuadLane<float, uint32_t> ql = dare_quad_lane(r, s.w, (float)dt, L);
+  auto emit = [&](dare_mask_t who, const float* W, float w44, int) {
+    if (r != 3 || !((who >> (threadIdx.x & 63)) & 1)) return;
+    float K[M * DIM];
+    dlqr_quad_gain_row3<DIM>(ql, W, w44, K);
+#pragma unroll
+    for (int i = 0; i < M * DIM; ++i) s_K[q][i] = K[i];
+  };
+  riccati_from_v_quad<DIM>(ql, eps, maxiter, __builtin_amdgcn_ballot_w64(live), emit);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float K[M * DIM];
+#pragma unroll
+  for (int i = 0; i < M * DIM; ++i) K[i] = s_K[q][i];
+  const LqrCtl u = lqr_control_from_gain<DIM>(K, e, th_e, pe, pth, s.w, c.sp[j], k, dt, L);
+  if (!live || r != 0) return;
+  if (ind_io) ind_io[a] = ind;
+  pe_io[a] = e; pth_io[a] = th_e;
+  if (DIM == 5) reinterpret_cast<float2*>(control)[a] = make_float2(u.ai, u.delta);
+  else control[a] = u.delta;
+}
+
 // ---- MPC front-end --------------------------------------------------------------------------------------
 // calc_nearest_index(state, cx, cy, cyaw, pind) of model_predictive_control.cpp: window [pind, pind+N_IND_SEARCH).
 // The reference reads cx[i] without a bounds check (:110); the window is clipped to the course here.

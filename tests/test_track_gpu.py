@@ -54,7 +54,7 @@ def test_calc_nearest_index_course_lengths(crx, oracle_mod, nc):
 
 
 @pytest.mark.parametrize("dim", [5, 4])
-@pytest.mark.parametrize("n", [1, 100, 1025])
+@pytest.mark.parametrize("n", [1, 100, 1025, 33000])      # up to 32,768 agents: a DPP quad per agent; above: one agent per lane
 def test_lqr_steering_control_bit_exact(crx, oracle_mod, lqr_setup, dim, n):
     course, goal, dc = lqr_setup
     rng = np.random.default_rng(n + dim)

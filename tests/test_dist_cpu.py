@@ -82,6 +82,29 @@ def _frenet_states(n):
                      rng.uniform(-0.3, 0.3, n)], axis=1).astype(np.float32)
 
 
+def _collect(procs, q, budget=600.0):
+    """The rank-0 result of a group of spawned ranks.  Polls so that a rank that died is reported at once (with its exit code)
+    instead of after the whole budget; a slow first `import torch` in a fresh container alone can take minutes."""
+    import queue, time
+    t0 = time.time()
+    while True:
+        try:
+            out = q.get(timeout=2.0)
+            break
+        except queue.Empty:
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > budget:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError(f"ranks failed or timed out after {time.time() - t0:.0f} s: dead = {dead}")
+    for p in procs:
+        p.join(timeout=240)
+        assert p.exitcode == 0
+    return out
+
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -102,10 +125,7 @@ def test_sharded_equals_unsharded(world, n, oracle_mod):
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    xg, hg, sg, tg, fg = q.get(timeout=240)
-    for p in procs:
-        p.join(timeout=240)
-        assert p.exitcode == 0
+    xg, hg, sg, tg, fg = _collect(procs, q)
     Q, R = ekf_QR()
     u, x0, P0 = ekf_agents(n, 7)
     w = oracle_mod.normal_draws(n, T, agent0=0, seed=8)        # one "GPU" draws for everybody: the shards must have seen the same bytes
@@ -178,10 +198,7 @@ def test_mixed_swarm_round_sharded_equals_unsharded(oracle_mod):
     procs = [ctx.Process(target=_swarm_worker, args=(r, world, port, n, T, q)) for r in range(world)]
     for p in procs:
         p.start()
-    (traj, plans_t, bytes_t), (final, plans_f, bytes_f) = q.get(timeout=240)
-    for p in procs:
-        p.join(timeout=240)
-        assert p.exitcode == 0
+    (traj, plans_t, bytes_t), (final, plans_f, bytes_f) = _collect(procs, q)
     o = oracle_mod
     Q, R = ekf_QR()
     course, goal = mpc_course_f32()

@@ -37,14 +37,17 @@ first_json_line(os.path.join(src, "bench.json"), os.path.join(dst, "bench_n1.jso
 first_json_line(os.path.join(src, "bench_forcedist.json"), os.path.join(dst, "bench_forcedist_1rank.json"))
 shutil.copy(os.path.join(src, "side_bench.jsonl"), os.path.join(dst, "side_bench.jsonl"))
 shutil.copy(os.path.join(src, "swarm_1gpu.json"), os.path.join(dst, "swarm_shard_1gpu.json"))
+for f in ("dare_lanes_ab.jsonl", "mpc_lanes_ab.jsonl", "loop_lanes_ab.jsonl", "mpc_loop_err.jsonl", "tests.log"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 shutil.copy(os.path.join(src, "host.txt"), os.path.join(dst, "host.txt"))
 p = os.path.join(src, "prof")
 stats(os.path.join(p, "prof_stats", "ekf_kernel_stats.csv"), os.path.join(dst, "ekf_kernel_stats.csv"), ["ekf_run_kernel", "ekf_simulate_inputs"])
-stats(os.path.join(p, "side_stats", "side_kernel_stats.csv"), os.path.join(dst, "side_kernel_stats.csv"), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel"])
+stats(os.path.join(p, "side_stats", "side_kernel_stats.csv"), os.path.join(dst, "side_kernel_stats.csv"), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "lqr_closed_loop"])
 for name in ("fetch", "write", "sq"):
     counters(os.path.join(p, f"pmc_{name}", "ekf_counter_collection.csv"), os.path.join(dst, f"pmc_{name}_ekf_run_kernel.csv"), ["ekf_run_kernel"])
 for name, o in (("side_sq", "side_pmc_sq.csv"), ("side_flop", "side_pmc_flop.csv"), ("side_sq2", "side_pmc_sq2.csv")):
-    counters(os.path.join(p, name, "side_counter_collection.csv"), os.path.join(dst, o), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel"])
+    counters(os.path.join(p, name, "side_counter_collection.csv"), os.path.join(dst, o), ["mpc_kernel", "mpc_quad_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "lqr_closed_loop"])
 for f in ("summary.txt", "traffic.json", "side_counters.json"):
     shutil.copy(os.path.join(p, f), os.path.join(dst, f))
 shutil.copy(os.path.join(p, "traffic.json"), os.path.join(ROOT, "profiles", "traffic.json"))

@@ -1,5 +1,7 @@
 """Bit-exact kernels against the CPU oracle on seeds and sizes beyond the fixed ones of tests/: fused EKF, DARE / dlqr (structured and
-dense), lqr_steering_control, the LQR closed loops, the dynamic-window episode.  Prints the number of mismatching agents per family."""
+dense, both register layouts), the LQR closed loops (both layouts), the dynamic-window episode, the Frenet planner (single plans:
+every candidate cost, verdict and winner; episodes: every tick), the particle filter (against the oracle in the engine's summation
+order).  `python scripts/gpu_fuzz_bitexact.py [first_seed [seeds]]`; prints the number of mismatching agents per family."""
 import sys, numpy as np, torch
 sys.path.insert(0, 'tests'); sys.path.insert(0, '.')
 import cpprobotics_amd as crx
@@ -8,7 +10,13 @@ from common import ekf_QR, ekf_agents, ekf_noise, lqr_course, lqr_speeds, tracki
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 bad = {}
 Q, R = ekf_QR()
-for seed in range(200, 206):
+seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+from cpprobotics_amd.experimental import closed_loop_prediction_lanes, dlqr_from_v_lanes
+sys.path.insert(0, 'tests')
+from test_oracle_pf import _scenario
+count = {}
+for seed in range(seed0, seed0 + nseeds):
     rng = np.random.default_rng(seed)
     n, T = int(rng.integers(1, 3000)), int(rng.integers(1, 400))
     u, x0, P0 = ekf_agents(n, seed)
@@ -25,7 +33,10 @@ for seed in range(200, 206):
         K, X, it = crx.dlqr_from_v(t(v), dim=dim)
         Xd, itd = crx.solve_DARE(t(A), t(B), t(Qm), t(Rm))
         m = np.any(X.cpu().numpy() != Xo, axis=1) | np.any(K.cpu().numpy() != Ko, axis=1) | (it.cpu().numpy() != ito) | np.any(Xd.cpu().numpy() != Xo, axis=1) | (itd.cpu().numpy() != ito)
-        bad[f'dare{dim}'] = bad.get(f'dare{dim}', 0) + int(m.sum())
+        for lanes in (1, 4):
+            K2, X2, it2 = dlqr_from_v_lanes(t(v), dim, lanes)
+            m |= np.any(X2.cpu().numpy() != Xo, axis=1) | np.any(K2.cpu().numpy() != Ko, axis=1) | (it2.cpu().numpy() != ito)
+        bad[f'dare{dim}'] = bad.get(f'dare{dim}', 0) + int(m.sum()); count[f'dare{dim}'] = count.get(f'dare{dim}', 0) + len(v)
     course, goal = lqr_course()
     dc = crx.Course.from_numpy(course)
     for dim in (5, 4):
@@ -37,7 +48,11 @@ for seed in range(200, 206):
         m = (ticks != to) | np.any(sd.cpu().numpy() != so, axis=1)
         for a in np.flatnonzero(~m):
             if not np.array_equal(hist[: to[a], a], ho[: to[a], a]): m[a] = True
-        bad[f'loop{dim}'] = bad.get(f'loop{dim}', 0) + int(m.sum())
+        for lanes in (1, 4):
+            s2 = t(st)
+            tk2, h2 = closed_loop_prediction_lanes(s2, dc, goal, lanes, dim=dim, max_ticks=600, want_hist=True)
+            m |= (tk2.cpu().numpy() != to) | np.any(s2.cpu().numpy() != so, axis=1) | np.any(h2.cpu().numpy() != hist, axis=(0, 2))
+        bad[f'loop{dim}'] = bad.get(f'loop{dim}', 0) + int(m.sum()); count[f'loop{dim}'] = count.get(f'loop{dim}', 0) + len(st)
     O = oracle.oracle_lib
     n = 64
     st = np.stack([rng.uniform(-1, 9, n), rng.uniform(-1, 9, n), rng.uniform(-3.2, 3.2, n), rng.uniform(-0.5, 1.0, n), rng.uniform(-0.69, 0.69, n)], axis=1).astype(np.float32)
@@ -46,4 +61,35 @@ for seed in range(200, 206):
     sd, udv = t(st), t(uu)
     ticks, hist, *_ = crx.dwa_run(sd, udv, t(g), t(O.DWA_OBSTACLES), 60, want_hist=True)
     bad['dwa'] = bad.get('dwa', 0) + int(((ticks.cpu().numpy() != to) | np.any(sd.cpu().numpy() != so, axis=1)).sum())
-print("mismatching agents per family over 6 seeds:", bad)
+    count['dwa'] = count.get('dwa', 0) + n; count['ekf'] = count.get('ekf', 0) + x0.shape[0]
+    # Frenet: 300 single plans (168 candidate costs / verdicts each) and 24 episodes of up to 120 ticks
+    fc = crx.FrenetCourse(O.FRENET_WX, O.FRENET_WY); fob = t(O.FRENET_OBSTACLES)
+    nf = 300
+    fs = np.stack([rng.uniform(0.0, 70.0, nf), rng.uniform(1.0, 9.0, nf), rng.uniform(-3.0, 3.0, nf), rng.uniform(-0.8, 0.8, nf), rng.uniform(-0.5, 0.5, nf)], axis=1).astype(np.float32)
+    o = oracle.frenet_plan(fs, fc.coef, O.FRENET_OBSTACLES)
+    r = crx.frenet_optimal_planning(t(fs), fc, fob, want_paths=True)
+    eq = lambda a, b: np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+    m = np.array([not (eq(r["path_cf"][a].cpu().numpy(), o["path_cf"][a]) and eq(r["path_ok"][a].cpu().numpy(), o["path_ok"][a])) for a in range(nf)])
+    m |= (r["best_idx"].cpu().numpy() != o["best"]) | (r["n_valid"].cpu().numpy() != o["n_valid"]) | (r["status"].cpu().numpy() != o["status"])
+    bad['frenet_plan'] = bad.get('frenet_plan', 0) + int(m.sum()); count['frenet_plan'] = count.get('frenet_plan', 0) + nf
+    ne = 24
+    es = fs[:ne].copy(); es[:, 0] = rng.uniform(0.0, 40.0, ne)
+    oe = oracle.frenet_run(es, fc.coef, fc.goal, 120, O.FRENET_OBSTACLES, want_hist=True)
+    sd = t(es)
+    re = crx.frenet_run(sd, fc, fob, 120, want_hist=True)
+    m = (re["ticks"].cpu().numpy() != oe["ticks"]) | (re["status"].cpu().numpy() != oe["status"]) | np.array([not eq(sd.cpu().numpy()[a], oe["state"][a]) for a in range(ne)])
+    hh = re["hist"].cpu().numpy()
+    for a in range(ne):
+        if not eq(hh[: oe["ticks"][a], a], oe["hist"][: oe["ticks"][a], a]): m[a] = True
+    bad['frenet_episode'] = bad.get('frenet_episode', 0) + int(m.sum()); count['frenet_episode'] = count.get('frenet_episode', 0) + ne
+    # particle filter: 64 vehicles x 80 ticks against the oracle in the engine's summation order
+    npf, Tpf, NP = 64, 80, 100
+    ut, obs, nobs, nrm, uni, xth, _ = _scenario(oracle, npf, Tpf, NP, seed)
+    px, pw = np.zeros((npf, NP, 4), np.float32), np.full((npf, NP), 1.0 / NP, np.float32)
+    pxo, pwo, xeo, Peo, xho, nro = oracle.pf_run(px, pw, obs, nobs, ut, nrm, uni, wave_order=True)
+    pxd, pwd = t(px), t(pw)
+    xe, Pe, hist, nres = crx.pf_run(pxd, pwd, t(obs), t(nobs), t(ut), t(nrm), t(uni))
+    m = np.any(hist.cpu().numpy() != xho, axis=(0, 2)) | np.any(pxd.cpu().numpy() != pxo, axis=(1, 2)) | np.any(pwd.cpu().numpy() != pwo, axis=1) | (nres.cpu().numpy() != nro)
+    bad['pf'] = bad.get('pf', 0) + int(m.sum()); count['pf'] = count.get('pf', 0) + npf
+    print("seed", seed, bad, flush=True)
+print(f"mismatching agents per family over seeds {seed0}..{seed0 + nseeds - 1}:", bad, "of", count)

@@ -569,6 +569,8 @@ crx::VehicleParams vparams(const crx_vehicle_params* p, int mpc) {
 }
 inline bool use_lds(const crx_course* c) { return c->n <= crx::kCourseLdsMax; }
 inline size_t lds_bytes(const crx_course* c) { return use_lds(c) ? sizeof(float4) * (((size_t)c->n + 1) / 2) : 0; }   // two points per word
+// the four-lanes-per-agent tracking kernels keep a gain slot per agent in static LDS next to the staged course (64 KB per workgroup in all)
+inline bool use_quad(const crx_course* c, int n) { return n <= kDareQuadMaxAgents && use_lds(c) && lds_bytes(c) + 1024 <= 64 * 1024; }
 
 // host-side staging of a course for the host-pointer entry points
 struct DevCourse {
@@ -626,7 +628,7 @@ int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const
   const unsigned bs = iter_block();
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
-  if (n <= kDareQuadMaxAgents && use_lds(course)) {      // a DPP quad per agent while one agent per lane would leave SIMDs idle
+  if (use_quad(course, n)) {      // a DPP quad per agent while one agent per lane would leave SIMDs idle
     const dim3 qgrid(blocks_for((size_t)n * 4, crx::kTrackBlock)), qblock(crx::kTrackBlock);
     if (dim == 5)
       hipLaunchKernelGGL((crx::lqr_steering_control_quad_kernel<5>), qgrid, qblock, lds_bytes(course), s, n, state, cv, ind, pe, pth_e, p.dt, p.L, p.eps, p.maxiter, control);
@@ -663,7 +665,7 @@ static int lqr_closed_loop_launch(int n, int dim, float* state, const crx_course
   if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state) ||
       (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4))
     return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
-  if (lanes_per_agent == 4 && !use_lds(course)) return fail(CRX_ERR_INVALID, "lqr_closed_loop: the four-lane layout needs a course that fits in LDS");
+  if (lanes_per_agent == 4 && !use_quad(course, 0)) return fail(CRX_ERR_INVALID, "lqr_closed_loop: the four-lane layout needs a course that fits in LDS");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_lqr_params p;
@@ -672,7 +674,7 @@ static int lqr_closed_loop_launch(int n, int dim, float* state, const crx_course
   const unsigned bs = iter_block();
   const crx::CourseView cv = view(course);
   hipStream_t s = (hipStream_t)stream;
-  const bool quad = lanes_per_agent == 4 || (lanes_per_agent == 0 && n <= kDareQuadMaxAgents && use_lds(course));
+  const bool quad = lanes_per_agent == 4 || (lanes_per_agent == 0 && use_quad(course, n));
   if (quad) {
     const dim3 grid(blocks_for((size_t)n * 4, crx::kTrackBlock)), block(crx::kTrackBlock);
 #define CRX_LAUNCH_LOOPQ(DIM) \

@@ -53,6 +53,49 @@ def test_calc_nearest_index_course_lengths(crx, oracle_mod, nc):
         assert (io[:5] == nc // 2 - 7).all()
 
 
+@pytest.mark.parametrize("nc", [1, 2, 3, 5, 64, 425, 8063, 8064, 8065, 8192, 8193])
+def test_tracking_course_lengths_both_layouts(crx, oracle_mod, nc):
+    """lqr_steering_control and a short closed loop on odd, even, tiny and long courses, ties included: the four-lane layout splits the scan
+    over the lanes of a quad (pairs j = r mod 4, lexicographic minimum of (distance, index)); courses whose staging would not leave room
+    for its LDS gain slots (> 8,064 points) and courses beyond 8,192 points run one agent per lane."""
+    from cpprobotics_amd.experimental import closed_loop_prediction_lanes
+    rng = np.random.default_rng(nc + 1)
+    t = np.linspace(0.0, 6.0, nc)
+    cx = (20.0 * np.cos(t) + rng.normal(0, 0.05, nc)).astype(np.float32)
+    cy = (15.0 * np.sin(1.3 * t) + rng.normal(0, 0.05, nc)).astype(np.float32)
+    if nc >= 64:
+        for k in (nc // 2, nc // 3):
+            cx[k] = cx[k - 7]; cy[k] = cy[k - 7]                                 # exact duplicates: the earlier index must win
+    cyaw = rng.uniform(-3, 3, nc).astype(np.float32)
+    course = (cx, cy, cyaw, rng.uniform(-0.2, 0.2, nc).astype(np.float32), np.full(nc, 2.0, np.float32))
+    dc = crx.Course.from_numpy(course)
+    n = 133
+    st = np.stack([rng.uniform(-25, 25, n), rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(0.2, 3, n)], axis=1).astype(np.float32)
+    if nc >= 64:
+        st[:5, 0] = cx[nc // 2]; st[:5, 1] = cy[nc // 2]
+        st[5:9, 0] = cx[nc // 3]; st[5:9, 1] = cy[nc // 3]
+    pe = rng.normal(0, 0.3, n).astype(np.float32); pth = rng.normal(0, 0.2, n).astype(np.float32)
+    ind0 = rng.integers(0, nc, n).astype(np.int32)
+    goal = (1e6, 1e6)
+    for dim in (5, 4):
+        co, io, peo, ptho = oracle_mod.lqr_steering_control(st, course, pe, pth, dim=dim, ind=ind0)
+        ped, pthd, indd = _t(pe), _t(pth), _t(ind0)
+        ctl, ind = crx.lqr_steering_control(_t(st), dc, ped, pthd, dim=dim, ind=indd)
+        assert np.array_equal(ind.cpu().numpy(), io) and bit_equal(ctl.cpu().numpy(), co)
+        assert bit_equal(ped.cpu().numpy(), peo) and bit_equal(pthd.cpu().numpy(), ptho)
+        if nc >= 64:
+            assert (io[:5] == nc // 2 - 7).all() and (io[5:9] == nc // 3 - 7).all()
+        so, tio, histo, peo, ptho, indo = oracle_mod.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=6, want_hist=True, pe=pe, pth_e=pth, ind=ind0)
+        for lanes in ((1, 4) if nc <= 8064 else (1,)):
+            sd, ped, pthd, indd = _t(st), _t(pe), _t(pth), _t(ind0)
+            ticks, hist = closed_loop_prediction_lanes(sd, dc, goal, lanes, dim=dim, max_ticks=6, want_hist=True, pe=ped, pth_e=pthd, ind=indd)
+            assert np.array_equal(ticks.cpu().numpy(), tio) and bit_equal(sd.cpu().numpy(), so) and bit_equal(hist.cpu().numpy(), histo)
+            assert np.array_equal(indd.cpu().numpy(), indo)
+        if nc > 8064:
+            with pytest.raises(crx.CrxError):
+                closed_loop_prediction_lanes(_t(st), dc, goal, 4, dim=dim, max_ticks=1)
+
+
 @pytest.mark.parametrize("dim", [5, 4])
 @pytest.mark.parametrize("n", [1, 100, 1025, 33000])      # up to 32,768 agents: a DPP quad per agent; above: one agent per lane
 def test_lqr_steering_control_bit_exact(crx, oracle_mod, lqr_setup, dim, n):

@@ -66,17 +66,31 @@ for seed in range(seed0, seed0 + nseeds):
     fc = crx.FrenetCourse(O.FRENET_WX, O.FRENET_WY); fob = t(O.FRENET_OBSTACLES)
     nf = 300
     fs = np.stack([rng.uniform(0.0, 70.0, nf), rng.uniform(1.0, 9.0, nf), rng.uniform(-3.0, 3.0, nf), rng.uniform(-0.8, 0.8, nf), rng.uniform(-0.5, 0.5, nf)], axis=1).astype(np.float32)
-    o = oracle.frenet_plan(fs, fc.coef, O.FRENET_OBSTACLES)
-    r = crx.frenet_optimal_planning(t(fs), fc, fob, want_paths=True)
+    # odd seeds: another sample grid (time step, horizons, road width, target-speed fan) and a random obstacle set of random size
+    kw = {}
+    if seed & 1:
+        dt_, maxt_, mint_ = [(0.25, 5.0, 3.0), (0.3, 6.0, 4.0), (0.15, 4.0, 3.0), (0.1, 4.0, 3.5), (0.2, 5.0, 3.0)][int(rng.integers(0, 5))]   # within the kernel's grid caps
+        kw = dict(dt=dt_, maxt=maxt_, mint=mint_, max_road_width=float(rng.choice([5.0, 7.0, 9.0])), d_road_w=float(rng.choice([1.0, 1.5])),
+                  n_s_sample=int(rng.choice([1, 2])), robot_radius=float(rng.choice([1.0, 1.5, 2.0])))
+        nob = int(rng.integers(1, 12))
+        fobn = np.stack([rng.uniform(5.0, 65.0, nob), rng.uniform(-8.0, 10.0, nob)], axis=1).astype(np.float32)
+    else:
+        fobn = O.FRENET_OBSTACLES
+    ocfg = oracle.frenet_config(**kw)
+    gcfg = crx.frenet_default_config()
+    for k_, v_ in kw.items(): setattr(gcfg, k_, v_)
+    fob = t(fobn)
+    o = oracle.frenet_plan(fs, fc.coef, fobn, cfg=ocfg)
+    r = crx.frenet_optimal_planning(t(fs), fc, fob, gcfg, want_paths=True)
     eq = lambda a, b: np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
     m = np.array([not (eq(r["path_cf"][a].cpu().numpy(), o["path_cf"][a]) and eq(r["path_ok"][a].cpu().numpy(), o["path_ok"][a])) for a in range(nf)])
     m |= (r["best_idx"].cpu().numpy() != o["best"]) | (r["n_valid"].cpu().numpy() != o["n_valid"]) | (r["status"].cpu().numpy() != o["status"])
     bad['frenet_plan'] = bad.get('frenet_plan', 0) + int(m.sum()); count['frenet_plan'] = count.get('frenet_plan', 0) + nf
     ne = 24
     es = fs[:ne].copy(); es[:, 0] = rng.uniform(0.0, 40.0, ne)
-    oe = oracle.frenet_run(es, fc.coef, fc.goal, 120, O.FRENET_OBSTACLES, want_hist=True)
+    oe = oracle.frenet_run(es, fc.coef, fc.goal, 120, fobn, cfg=ocfg, want_hist=True)
     sd = t(es)
-    re = crx.frenet_run(sd, fc, fob, 120, want_hist=True)
+    re = crx.frenet_run(sd, fc, fob, 120, gcfg, want_hist=True)
     m = (re["ticks"].cpu().numpy() != oe["ticks"]) | (re["status"].cpu().numpy() != oe["status"]) | np.array([not eq(sd.cpu().numpy()[a], oe["state"][a]) for a in range(ne)])
     hh = re["hist"].cpu().numpy()
     for a in range(ne):

@@ -284,14 +284,19 @@ __device__ __forceinline__ float calc_nearest_index_quad(float sx, float sy, con
   const float4* __restrict__ pairs = reinterpret_cast<const float4*>(pts);
   const v2f s2x = {sx, sx}, s2y = {sy, sy};
   const int np = (c.n + 1) >> 1;
-  for (int j = r; j < np; j += 4) {
-    const float4 q = pairs[j];
+  auto score = [&](const float4& q, int j) {
     const v2f px = {q.x, q.y}, py = {q.z, q.w};
     const v2f idx = px - s2x, idy = py - s2y;
     const v2f d_e = idx * idx + idy * idy;
     if (d_e.x < mind) { mind = d_e.x; best = 2 * j; }
     if (d_e.y < mind) { mind = d_e.y; best = 2 * j + 1; }
+  };
+  int jp = r;
+  for (; jp + 12 < np; jp += 16) {                  // four LDS reads in flight: a lone wave would otherwise sit out every read's latency
+    const float4 q0 = pairs[jp], q1 = pairs[jp + 4], q2 = pairs[jp + 8], q3 = pairs[jp + 12];
+    score(q0, jp); score(q1, jp + 4); score(q2, jp + 8); score(q3, jp + 12);
   }
+  for (; jp < np; jp += 4) score(pairs[jp], jp);
   {                                                 // lanes (0,1) <-> (1,0), (2,3) <-> (3,2); then pairs <-> pairs
     const float om = quad_perm_f<0xb1>(mind); const int ob = quad_perm_i<0xb1>(best);      // quad_perm [1,0,3,2]
     if (om < mind || (om == mind && ob < best)) { mind = om; best = ob; }

@@ -371,8 +371,8 @@ __device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32
 #pragma unroll
   for (int j = 0; j < 4; ++j) X[j] = c.q[j];
   auto iter = [&](const float* Xi, const float& xi44, float* Xo, float& xo44) -> float {
-    if constexpr (DIM == 5) return dare5_quad_iter(c, Xi, xi44, Xo, xo44);
-    else return dare4_quad_iter(c, Xi, Xo);
+    if constexpr (DIM == 5) return dare5_quad_iter_dev(c, Xi, xi44, Xo, xo44);
+    else return dare4_quad_iter_dev(c, Xi, Xo);
   };
   if (maxiter <= 0) { emit(todo, X, x44, 0); return; }
   // Two evaluations per trip (X -> Y -> X); an odd cap is made even by one evaluation ahead of the loop.
@@ -387,15 +387,16 @@ __device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32
     i = 1;
   }
   for (; i < maxiter && todo; i += 2) {
-    {
-      const float m = iter(X, x44, Y, y44);
-      const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
-      if (hit) { emit(hit, Y, y44, i + 1); todo &= ~hit; }
-    }
-    {
-      const float m = iter(Y, y44, X, x44);
-      const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
-      if (hit) { emit(hit, X, x44, i + 2); todo &= ~hit; }
+    // both evaluations in one basic block (the first one's test — a chain of ten dependent instructions — overlaps the second one's
+    // start), one not-taken branch per trip; Y is still intact when the first evaluation's agents are handed back
+    const float m1 = iter(X, x44, Y, y44);
+    const float m2 = iter(Y, y44, X, x44);
+    const dare_mask_t hit1 = __builtin_amdgcn_ballot_w64(m1 < eps) & todo;
+    const dare_mask_t hit2 = __builtin_amdgcn_ballot_w64(m2 < eps) & todo & ~hit1;
+    if (hit1 | hit2) {
+      if (hit1) emit(hit1, Y, y44, i + 1);
+      if (hit2) emit(hit2, X, x44, i + 2);
+      todo &= ~(hit1 | hit2);
     }
   }
   if (todo) emit(todo, X, x44, maxiter);                    // agents that ran into the cap return the last evaluation

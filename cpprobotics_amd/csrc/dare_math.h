@@ -225,4 +225,102 @@ CRX_HD F dare5_quad_iter(const QuadLane<F, M>& c, const F* x, F x44, F* xn, F& x
   return qfmax(dare_quad_maxdiff(xn, x), qfabs(x44n - x44)) + dare_quad_first(xn, x);
 }
 
+// ---------- the same two evaluations as the kernels issue them ----------------------------------------------------------------------
+// Same operations on the same operands, entry by entry, as dare4_quad_iter / dare5_quad_iter above (the host build and the tests keep
+// using those); what differs is how they are handed to the machine:
+//   * lane 2's extra term of A'X is added under an exec mask of the lanes 2 (mod 4) (lanes 0, 1, 3 keep a * X[src] — the generic code adds +0.0f there,
+//     which can only turn a -0 into +0, and every zero's sign is gone after `(p1 - p2) + q`);
+//   * the two halves of independent scalar chains — (bv X33 bv, bd x44 bd), (m3, m0) / det, (R3 bv Si0 bv, x44 bd Si3 bd) — and the
+//     pairs of a row ride in packed fp32 instructions; products by the literal 1.0f are exact;
+//   * the quad maximum takes its partner lane as the DPP operand of v_max_f32 (fmaxf semantics: a NaN operand is dropped).
+// ~60 instead of ~77 VALU instructions per evaluation; tests/test_lqr_gpu.py and tests/test_track_gpu.py hold the kernels to the
+// oracle's bits (iteration counts included), tests/test_dare_host.py the generic code above.
+#if defined(__HIPCC__)
+typedef float dq_v2f __attribute__((ext_vector_type(2)));
+
+// acc[j] + src[j] on lane 2 of every quad, acc[j] elsewhere: the four adds under an exec mask of the lanes 2 (mod 4)
+__device__ __forceinline__ void dq_add_lane2(float& a0, float& a1, float& a2, float& a3, float s0, float s1, float s2, float s3) {
+  unsigned long long saved;
+  asm("s_and_saveexec_b64 %4, %9\n\t"
+      "v_add_f32_e32 %0, %0, %5\n\t"
+      "v_add_f32_e32 %1, %1, %6\n\t"
+      "v_add_f32_e32 %2, %2, %7\n\t"
+      "v_add_f32_e32 %3, %3, %8\n\t"
+      "s_mov_b64 exec, %4"
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "=&s"(saved)
+      : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "s"(0x4444444444444444ull)
+      : "scc");
+}
+// max(m, m of the lane CTRL names); m was written by the instruction before: two wait states ahead of the DPP read
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ float dq_max_perm(float m) {
+  float r;
+  if constexpr (P0 == 1) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(m));
+  else asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(m));
+  return r;
+}
+
+struct DqRows { float R0; dq_v2f R12; float R3; };
+__device__ __forceinline__ DqRows dq_AtX(const QuadLane<float, uint32_t>& c, const float* x) {
+  DqRows o;
+  float r0 = c.a * qperm<QP_0012>(x[0]), r1 = c.a * qperm<QP_0012>(x[1]), r2 = c.a * qperm<QP_0012>(x[2]), r3 = c.a * qperm<QP_0012>(x[3]);
+  dq_add_lane2(r0, r1, r2, r3, x[0], x[1], x[2], x[3]);
+  o.R0 = r0; o.R12[0] = r1; o.R12[1] = r2; o.R3 = r3;
+  return o;
+}
+// row r of (A'XA - (c33 X3)A) + Q, and max |xn - x| over the row
+__device__ __forceinline__ float dq_row(const QuadLane<float, uint32_t>& c, const DqRows& R, float c33, const float* x, float* xn) {
+  const float C0 = c33 * qperm<QP_3333>(x[0]);
+  dq_v2f C12;
+  C12[0] = c33 * qperm<QP_3333>(x[1]);
+  C12[1] = c33 * qperm<QP_3333>(x[2]);
+  const dq_v2f one_dt = {1.0f, c.dt}, v_dt = {c.v, c.dt};
+  const dq_v2f p1a = (dq_v2f){R.R0, R.R0} * one_dt;                    // (R0, R0 dt)
+  const dq_v2f p2a = (dq_v2f){C0, C0} * one_dt;
+  dq_v2f p1b = R.R12 * v_dt, p2b = C12 * v_dt;                         // (R1 v, R2 dt)
+  p1b[0] = p1b[0] + R.R12[1];                                          // R1 v + R2
+  p2b[0] = p2b[0] + C12[1];
+  const dq_v2f xa = (p1a - p2a) + (dq_v2f){c.q[0], c.q[1]};
+  const dq_v2f xb = (p1b - p2b) + (dq_v2f){c.q[2], c.q[3]};
+  const dq_v2f da = xa - (dq_v2f){x[0], x[1]}, db = xb - (dq_v2f){x[2], x[3]};
+  xn[0] = xa[0]; xn[1] = xa[1]; xn[2] = xb[0]; xn[3] = xb[1];
+  const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(da[0]), __builtin_fabsf(da[1])), __builtin_fmaxf(__builtin_fabsf(db[0]), __builtin_fabsf(db[1])));
+  return m;
+}
+__device__ __forceinline__ float dq_first(float d0) { return qperm<QP_0000>(d0 - d0); }
+
+__device__ __forceinline__ float dare4_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
+  const DqRows R = dq_AtX(c, x);
+  const float g = (c.bv * qperm<QP_3333>(x[3])) * c.bv;
+  const float s = 1.0f + g;
+  float m = dq_row(c, R, ((R.R3 * c.bv) / s) * c.bv, x, xn);
+  const float first = dq_first(xn[0] - x[0]);
+  m = dq_max_perm<1, 0, 3, 2>(m);
+  m = dq_max_perm<2, 3, 0, 1>(m);
+  return m + first;
+}
+__device__ __forceinline__ float dare5_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
+  const DqRows R = dq_AtX(c, x);
+  const dq_v2f bvd = {c.bv, c.bd};
+  dq_v2f t;
+  t[0] = c.bv * qperm<QP_3333>(x[3]);
+  t[1] = c.bd * x44;
+  const dq_v2f m03 = (dq_v2f){1.0f, 1.0f} + t * bvd;                   // (m0, m3)
+  const float det = m03[0] * m03[1];
+  const float invdet = 1.0f / det;
+  const dq_v2f Si = (dq_v2f){m03[1], m03[0]} * (dq_v2f){invdet, invdet};  // (Si0, Si3) = (m3, m0) / det
+  dq_v2f u;
+  u[0] = R.R3 * c.bv;
+  u[1] = x44 * c.bd;
+  u = (u * Si) * bvd;                                                  // (c33, ((x44 bd) Si3) bd)
+  float m = dq_row(c, R, u[0], x, xn);
+  x44n = (x44 - u[1] * x44) + 1.0f;
+  const float first = dq_first(xn[0] - x[0]);
+  m = __builtin_fmaxf(m, __builtin_fabsf(x44n - x44));
+  m = dq_max_perm<1, 0, 3, 2>(m);
+  m = dq_max_perm<2, 3, 0, 1>(m);
+  return m + first;
+}
+#endif
+
 }  // namespace crx

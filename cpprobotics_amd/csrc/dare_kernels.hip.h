@@ -375,28 +375,37 @@ __device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32
     else return dare4_quad_iter_dev(c, Xi, Xo);
   };
   if (maxiter <= 0) { emit(todo, X, x44, 0); return; }
-  // Two evaluations per trip (X -> Y -> X); an odd cap is made even by one evaluation ahead of the loop.
+  // Four evaluations per trip (X -> Y -> Z -> W -> X); a cap that is not a multiple of four is made one by single evaluations ahead
+  // of the loop.
   int i = 0;
-  if (maxiter & 1) {
+  for (const int peel = maxiter & 3; i < peel; ++i) {
     const float m = iter(X, x44, Y, y44);
     const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
-    if (hit) { emit(hit, Y, y44, 1); todo &= ~hit; }
+    if (hit) { emit(hit, Y, y44, i + 1); todo &= ~hit; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) X[j] = Y[j];
     x44 = y44;
-    i = 1;
   }
-  for (; i < maxiter && todo; i += 2) {
-    // both evaluations in one basic block (the first one's test — a chain of ten dependent instructions — overlaps the second one's
-    // start), one not-taken branch per trip; Y is still intact when the first evaluation's agents are handed back
+  float Z[4], W[4], z44 = 1.0f, w44 = 1.0f;
+  for (; i < maxiter && todo; i += 4) {
+    // all four evaluations in one basic block (an evaluation's test — a chain of ten dependent instructions ending in two DPP
+    // steps — overlaps the next evaluation's start), one not-taken branch per trip; every iterate of the trip is still intact when
+    // its agents are handed back
     const float m1 = iter(X, x44, Y, y44);
-    const float m2 = iter(Y, y44, X, x44);
+    const float m2 = iter(Y, y44, Z, z44);
+    const float m3 = iter(Z, z44, W, w44);
+    const float m4 = iter(W, w44, X, x44);
     const dare_mask_t hit1 = __builtin_amdgcn_ballot_w64(m1 < eps) & todo;
     const dare_mask_t hit2 = __builtin_amdgcn_ballot_w64(m2 < eps) & todo & ~hit1;
-    if (hit1 | hit2) {
+    const dare_mask_t hit3 = __builtin_amdgcn_ballot_w64(m3 < eps) & todo & ~(hit1 | hit2);
+    const dare_mask_t hit4 = __builtin_amdgcn_ballot_w64(m4 < eps) & todo & ~(hit1 | hit2 | hit3);
+    const dare_mask_t any = hit1 | hit2 | hit3 | hit4;
+    if (any) {
       if (hit1) emit(hit1, Y, y44, i + 1);
-      if (hit2) emit(hit2, X, x44, i + 2);
-      todo &= ~(hit1 | hit2);
+      if (hit2) emit(hit2, Z, z44, i + 2);
+      if (hit3) emit(hit3, W, w44, i + 3);
+      if (hit4) emit(hit4, X, x44, i + 4);
+      todo &= ~any;
     }
   }
   if (todo) emit(todo, X, x44, maxiter);                    // agents that ran into the cap return the last evaluation

@@ -391,10 +391,17 @@ __device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32
     // all four evaluations in one basic block (an evaluation's test — a chain of ten dependent instructions ending in two DPP
     // steps — overlaps the next evaluation's start), one not-taken branch per trip; every iterate of the trip is still intact when
     // its agents are handed back
-    const float m1 = iter(X, x44, Y, y44);
-    const float m2 = iter(Y, y44, Z, z44);
-    const float m3 = iter(Z, z44, W, w44);
-    const float m4 = iter(W, w44, X, x44);
+    auto eval = [&](const float* Xi, const float& xi44, float* Xo, float& xo44) -> DqTest {
+      if constexpr (DIM == 5) return dare5_quad_eval_dev(c, Xi, xi44, Xo, xo44);
+      else return dare4_quad_eval_dev(c, Xi, Xo);
+    };
+    const DqTest t1 = eval(X, x44, Y, y44);
+    const DqTest t2 = eval(Y, y44, Z, z44);
+    const DqTest t3 = eval(Z, z44, W, w44);
+    const DqTest t4 = eval(W, w44, X, x44);
+    float m1 = t1.m, m2 = t2.m, m3 = t3.m, m4 = t4.m;
+    dq_quad_max4(m1, m2, m3, m4);                   // the four tests' quad maxima, interleaved
+    m1 += t1.first; m2 += t2.first; m3 += t3.first; m4 += t4.first;
     const dare_mask_t hit1 = __builtin_amdgcn_ballot_w64(m1 < eps) & todo;
     const dare_mask_t hit2 = __builtin_amdgcn_ballot_w64(m2 < eps) & todo & ~hit1;
     const dare_mask_t hit3 = __builtin_amdgcn_ballot_w64(m3 < eps) & todo & ~(hit1 | hit2);

@@ -289,17 +289,37 @@ __device__ __forceinline__ float dq_row(const QuadLane<float, uint32_t>& c, cons
 }
 __device__ __forceinline__ float dq_first(float d0) { return qperm<QP_0000>(d0 - d0); }
 
-__device__ __forceinline__ float dare4_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
+// lane-local part of an evaluation: the row's maximum |xn - x| (before the quad reduction) and the first-element term
+struct DqTest { float m, first; };
+__device__ __forceinline__ DqTest dare4_quad_eval_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
   const DqRows R = dq_AtX(c, x);
   const float g = (c.bv * qperm<QP_3333>(x[3])) * c.bv;
   const float s = 1.0f + g;
-  float m = dq_row(c, R, ((R.R3 * c.bv) / s) * c.bv, x, xn);
-  const float first = dq_first(xn[0] - x[0]);
-  m = dq_max_perm<1, 0, 3, 2>(m);
-  m = dq_max_perm<2, 3, 0, 1>(m);
-  return m + first;
+  DqTest t;
+  t.m = dq_row(c, R, ((R.R3 * c.bv) / s) * c.bv, x, xn);
+  t.first = dq_first(xn[0] - x[0]);
+  return t;
 }
-__device__ __forceinline__ float dare5_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
+// the quad maximum of one evaluation's test, and of four at once (the four chains interleaved: no DPP read follows its source's
+// write by less than three instructions, so only the first one needs wait states)
+__device__ __forceinline__ float dq_quad_max(float m) { return dq_max_perm<2, 3, 0, 1>(dq_max_perm<1, 0, 3, 2>(m)); }
+__device__ __forceinline__ void dq_quad_max4(float& m1, float& m2, float& m3, float& m4) {
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4));
+}
+__device__ __forceinline__ float dare4_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
+  const DqTest t = dare4_quad_eval_dev(c, x, xn);
+  return dq_quad_max(t.m) + t.first;
+}
+__device__ __forceinline__ DqTest dare5_quad_eval_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
   const DqRows R = dq_AtX(c, x);
   const dq_v2f bvd = {c.bv, c.bd};
   dq_v2f t;
@@ -313,13 +333,16 @@ __device__ __forceinline__ float dare5_quad_iter_dev(const QuadLane<float, uint3
   u[0] = R.R3 * c.bv;
   u[1] = x44 * c.bd;
   u = (u * Si) * bvd;                                                  // (c33, ((x44 bd) Si3) bd)
-  float m = dq_row(c, R, u[0], x, xn);
+  DqTest o;
+  o.m = dq_row(c, R, u[0], x, xn);
   x44n = (x44 - u[1] * x44) + 1.0f;
-  const float first = dq_first(xn[0] - x[0]);
-  m = __builtin_fmaxf(m, __builtin_fabsf(x44n - x44));
-  m = dq_max_perm<1, 0, 3, 2>(m);
-  m = dq_max_perm<2, 3, 0, 1>(m);
-  return m + first;
+  o.first = dq_first(xn[0] - x[0]);
+  o.m = __builtin_fmaxf(o.m, __builtin_fabsf(x44n - x44));
+  return o;
+}
+__device__ __forceinline__ float dare5_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
+  const DqTest t = dare5_quad_eval_dev(c, x, x44, xn, x44n);
+  return dq_quad_max(t.m) + t.first;
 }
 #endif
 

@@ -400,8 +400,7 @@ __device__ __forceinline__ void riccati_from_v_quad(const QuadLane<float, uint32
     const DqTest t3 = eval(Z, z44, W, w44);
     const DqTest t4 = eval(W, w44, X, x44);
     float m1 = t1.m, m2 = t2.m, m3 = t3.m, m4 = t4.m;
-    dq_quad_max4(m1, m2, m3, m4);                   // the four tests' quad maxima, interleaved
-    m1 += t1.first; m2 += t2.first; m3 += t3.first; m4 += t4.first;
+    dq_quad_test4(m1, m2, m3, m4, t1.first, t2.first, t3.first, t4.first);     // the four tests' quad reductions, interleaved
     const dare_mask_t hit1 = __builtin_amdgcn_ballot_w64(m1 < eps) & todo;
     const dare_mask_t hit2 = __builtin_amdgcn_ballot_w64(m2 < eps) & todo & ~hit1;
     const dare_mask_t hit3 = __builtin_amdgcn_ballot_w64(m3 < eps) & todo & ~(hit1 | hit2);

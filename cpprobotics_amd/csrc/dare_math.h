@@ -290,20 +290,21 @@ __device__ __forceinline__ float dq_row(const QuadLane<float, uint32_t>& c, cons
 __device__ __forceinline__ float dq_first(float d0) { return qperm<QP_0000>(d0 - d0); }
 
 // lane-local part of an evaluation: the row's maximum |xn - x| (before the quad reduction) and the first-element term
-struct DqTest { float m, first; };
+struct DqTest { float m, first; };   // first: (d00 - d00) on every lane from its own row — lane 0's is the one that counts
 __device__ __forceinline__ DqTest dare4_quad_eval_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
   const DqRows R = dq_AtX(c, x);
   const float g = (c.bv * qperm<QP_3333>(x[3])) * c.bv;
   const float s = 1.0f + g;
   DqTest t;
   t.m = dq_row(c, R, ((R.R3 * c.bv) / s) * c.bv, x, xn);
-  t.first = dq_first(xn[0] - x[0]);
+  const float d0 = xn[0] - x[0];
+  t.first = d0 - d0;
   return t;
 }
-// the quad maximum of one evaluation's test, and of four at once (the four chains interleaved: no DPP read follows its source's
-// write by less than three instructions, so only the first one needs wait states)
+// the quad maximum of one evaluation's test; and four tests at once — maxima and first-element terms, the four chains interleaved: no DPP
+// read follows its source's write by less than three instructions, so only the first one needs wait states (f1..f4 are written before the block)
 __device__ __forceinline__ float dq_quad_max(float m) { return dq_max_perm<2, 3, 0, 1>(dq_max_perm<1, 0, 3, 2>(m)); }
-__device__ __forceinline__ void dq_quad_max4(float& m1, float& m2, float& m3, float& m4) {
+__device__ __forceinline__ void dq_quad_test4(float& m1, float& m2, float& m3, float& m4, float f1, float f2, float f3, float f4) {
   asm("s_nop 1\n\t"
       "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -312,12 +313,16 @@ __device__ __forceinline__ void dq_quad_max4(float& m1, float& m2, float& m3, fl
       "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
       "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-      : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4));
+      "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %4, %0 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"       // + lane 0's first-element term
+      "v_add_f32_dpp %1, %5, %1 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %6, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %7, %3 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
+      : "+v"(m1), "+v"(m2), "+v"(m3), "+v"(m4) : "v"(f1), "v"(f2), "v"(f3), "v"(f4));
 }
 __device__ __forceinline__ float dare4_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float* xn) {
   const DqTest t = dare4_quad_eval_dev(c, x, xn);
-  return dq_quad_max(t.m) + t.first;
+  return dq_quad_max(t.m) + qperm<QP_0000>(t.first);
 }
 __device__ __forceinline__ DqTest dare5_quad_eval_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
   const DqRows R = dq_AtX(c, x);
@@ -336,13 +341,14 @@ __device__ __forceinline__ DqTest dare5_quad_eval_dev(const QuadLane<float, uint
   DqTest o;
   o.m = dq_row(c, R, u[0], x, xn);
   x44n = (x44 - u[1] * x44) + 1.0f;
-  o.first = dq_first(xn[0] - x[0]);
+  const float d0 = xn[0] - x[0];
+  o.first = d0 - d0;
   o.m = __builtin_fmaxf(o.m, __builtin_fabsf(x44n - x44));
   return o;
 }
 __device__ __forceinline__ float dare5_quad_iter_dev(const QuadLane<float, uint32_t>& c, const float* x, float x44, float* xn, float& x44n) {
   const DqTest t = dare5_quad_eval_dev(c, x, x44, xn, x44n);
-  return dq_quad_max(t.m) + t.first;
+  return dq_quad_max(t.m) + qperm<QP_0000>(t.first);
 }
 #endif
 

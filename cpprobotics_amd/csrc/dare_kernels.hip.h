@@ -358,8 +358,10 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
 //
 // Converged agents are NOT masked off: every quad keeps evaluating (nobody looks at a converged agent's later iterates), and
 // an agent's X, K and iteration count go to memory straight from the — rare — pass in which its own test succeeds.  The hot
-// loop then carries one compare, one scalar and, and one not-taken branch per evaluation instead of two exec-mask regions
-// (~14 scalar instructions, which cost a lone wave as much as vector ones) and no live-out registers but the iterate itself.
+// loop runs four evaluations per trip behind one not-taken branch (their tests reduced across the quads in one interleaved DPP
+// sequence) instead of two exec-mask regions per evaluation (~14 scalar instructions, which cost a lone wave as much as vector
+// ones), and carries no live-out registers but the iterates themselves.  The evaluation itself is dare_math.h's
+// dare5_quad_iter_dev / dare4_quad_iter_dev: 65 issue slots.
 typedef unsigned long long dare_mask_t;
 
 // The quad's loop: iterate from X = Q = I until the test passes or the cap is reached, for the agents of `todo` (a lane mask, whole

@@ -233,7 +233,7 @@ CRX_HD F dare5_quad_iter(const QuadLane<F, M>& c, const F* x, F x44, F* xn, F& x
 //   * the two halves of independent scalar chains — (bv X33 bv, bd x44 bd), (m3, m0) / det, (R3 bv Si0 bv, x44 bd Si3 bd) — and the
 //     pairs of a row ride in packed fp32 instructions; products by the literal 1.0f are exact;
 //   * the quad maximum takes its partner lane as the DPP operand of v_max_f32 (fmaxf semantics: a NaN operand is dropped).
-// ~60 instead of ~77 VALU instructions per evaluation; tests/test_lqr_gpu.py and tests/test_track_gpu.py hold the kernels to the
+// 58 instead of 77 VALU instructions per evaluation (65 instead of 87 issue slots with the loop of dare_kernels.hip.h); tests/test_lqr_gpu.py and tests/test_track_gpu.py hold the kernels to the
 // oracle's bits (iteration counts included), tests/test_dare_host.py the generic code above.
 #if defined(__HIPCC__)
 typedef float dq_v2f __attribute__((ext_vector_type(2)));
@@ -287,7 +287,6 @@ __device__ __forceinline__ float dq_row(const QuadLane<float, uint32_t>& c, cons
   const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(da[0]), __builtin_fabsf(da[1])), __builtin_fmaxf(__builtin_fabsf(db[0]), __builtin_fabsf(db[1])));
   return m;
 }
-__device__ __forceinline__ float dq_first(float d0) { return qperm<QP_0000>(d0 - d0); }
 
 // lane-local part of an evaluation: the row's maximum |xn - x| (before the quad reduction) and the first-element term
 struct DqTest { float m, first; };   // first: (d00 - d00) on every lane from its own row — lane 0's is the one that counts

@@ -61,6 +61,7 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
+constexpr int kDareChainMaxAgents = 98304;   // one lane per agent: the unmasked two-evaluations-per-branch loop up to here (profiles/r03/dare_lanes_ab.txt)
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
 // waves (32..4 active lanes, to shorten the wait for a wave's slowest agent and to occupy idle SIMDs at BASELINE-sized batches)
@@ -420,10 +421,14 @@ static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_para
       hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
   } else {
     const dim3 grid(blocks_for(n, 64)), block(64);
-    if (dim == 5)
-      hipLaunchKernelGGL((crx::dare_from_v_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
-    else
-      hipLaunchKernelGGL((crx::dare_from_v_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+    // up to ~1.5 waves per SIMD the launch is a latency chain: nobody masked off, two evaluations per branch (89 VGPRs); beyond,
+    // the masked loop at eight waves per SIMD (60 VGPRs)
+    const bool chain = n <= kDareChainMaxAgents;
+#define CRX_LAUNCH_DV(KERNEL, DIM) \
+    hipLaunchKernelGGL((crx::KERNEL<DIM>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters)
+    if (dim == 5) { if (chain) CRX_LAUNCH_DV(dare_from_v_kernel, 5); else CRX_LAUNCH_DV(dare_from_v_masked_kernel, 5); }
+    else { if (chain) CRX_LAUNCH_DV(dare_from_v_kernel, 4); else CRX_LAUNCH_DV(dare_from_v_masked_kernel, 4); }
+#undef CRX_LAUNCH_DV
   }
   CRX_HIP(hipGetLastError());
   return CRX_OK;

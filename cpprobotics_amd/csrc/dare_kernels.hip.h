@@ -321,9 +321,12 @@ __device__ __forceinline__ int riccati_from_v(float dt, float v, float bv, float
   return it;
 }
 
+// The masked loop (riccati_from_v: 60 VGPRs, eight waves per SIMD) for batches that queue several waves on every SIMD: there the
+// converged lanes' exec regions cost nothing that another wave does not hide, and occupancy is what counts (the emit variant
+// below needs 89 VGPRs: measured 10 % slower at 1 M agents, 10-28 % faster up to 65,536).
 template <int DIM>
 __global__ void __launch_bounds__(64)
-dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
+dare_from_v_masked_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
                    float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
   constexpr int NN = DIM * DIM;
   constexpr int M = (DIM == 5) ? 2 : 1;
@@ -348,6 +351,85 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
   if (iters) iters[a] = it;
 }
 
+typedef unsigned long long dare_mask_t;
+
+// The same loop with nobody masked off (as in the four-lane kernel below): every lane keeps evaluating, two evaluations per trip behind
+// one not-taken branch, and emit(who, W, w44, it) hands the agents of `who` back from the — rare — pass in which their test succeeds
+// (W = the iterate after `it` evaluations).  Saves the two exec-mask regions per evaluation of riccati_from_v (~14 scalar
+// instructions) and lets an evaluation's test overlap the next one's start; used where the result can go straight to memory.
+template <int DIM, class Emit>
+__device__ __forceinline__ void riccati_from_v_emit(float dt, float v, float bv, float bd, float eps, int maxiter, dare_mask_t todo, Emit&& emit) {
+  Row4 X[4], Y[4];
+  float x44 = 1.0f, y44 = 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    X[i].a = (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+    X[i].b = (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+  }
+  auto iter = [&](const Row4* Xi, const float& xi44, Row4* Xo, float& xo44) -> float {
+    if constexpr (DIM == 5) { dare5_v_iter_pk(dt, v, bv, bd, Xi, xi44, Xo, xo44); return dare_max_abs_diff(Xo, xo44, Xi, xi44); }
+    else { dare4_v_iter_pk(dt, v, bv, Xi, Xo); return dare_max_abs_diff(Xo, Xi); }
+  };
+  if (maxiter <= 0) { emit(todo, X, x44, 0); return; }
+  int i = 0;
+  if (maxiter & 1) {
+    const float m = iter(X, x44, Y, y44);
+    const dare_mask_t hit = __builtin_amdgcn_ballot_w64(m < eps) & todo;
+    if (hit) { emit(hit, Y, y44, 1); todo &= ~hit; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[j] = Y[j];
+    x44 = y44;
+    i = 1;
+  }
+  for (; i < maxiter && todo; i += 2) {
+    const float m1 = iter(X, x44, Y, y44);
+    const float m2 = iter(Y, y44, X, x44);
+    const dare_mask_t hit1 = __builtin_amdgcn_ballot_w64(m1 < eps) & todo;
+    const dare_mask_t hit2 = __builtin_amdgcn_ballot_w64(m2 < eps) & todo & ~hit1;
+    if (hit1 | hit2) {
+      if (hit1) emit(hit1, Y, y44, i + 1);
+      if (hit2) emit(hit2, X, x44, i + 2);
+      todo &= ~(hit1 | hit2);
+    }
+  }
+  if (todo) emit(todo, X, x44, maxiter);
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(64)
+dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, float eps, int maxiter,
+                   float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
+  constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = a < (size_t)n;
+  const float v = live ? vg[a] : 1.0f;
+  const float bv = (float)((double)v / L);  // B(3,0) = state.v / L  (float / double literal)
+  auto emit = [&](dare_mask_t who, const Row4* W, float w44, int it) {
+    if (!((who >> (threadIdx.x & 63)) & 1)) return;
+    float X[NN];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      X[i + DIM * 0] = W[i].a.x; X[i + DIM * 1] = W[i].a.y; X[i + DIM * 2] = W[i].b.x; X[i + DIM * 3] = W[i].b.y;
+      if constexpr (DIM == 5) { X[i + DIM * 4] = 0.0f; X[4 + DIM * i] = 0.0f; }
+    }
+    if constexpr (DIM == 5) X[24] = w44;
+    if (Xg) {
+#pragma unroll
+      for (int j = 0; j < NN; ++j) Xg[a * NN + j] = X[j];
+    }
+    if (Kg) {
+      float K[M * DIM];
+      if (DIM == 5) dlqr5_v_gain(dt, v, bv, dt, X, K);
+      else dlqr4_v_gain(dt, v, bv, X, K);
+#pragma unroll
+      for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
+    }
+    if (iters) iters[a] = it;
+  };
+  riccati_from_v_emit<DIM>(dt, v, bv, dt, eps, maxiter, __builtin_amdgcn_ballot_w64(live), emit);
+}
+
 // ---------- four lanes per agent ---------------------------------------------------------------------------------------------
 // BASELINE-sized batches (configs[2]: 16,384 agents) are 256 waves of the kernel above on 1,024 SIMDs, and the launch lasts as
 // long as one wave needs for the 150 evaluations of an agent at the iteration cap: a latency chain on a quarter of the chip.
@@ -362,7 +444,6 @@ dare_from_v_kernel(int n, const float* __restrict__ vg, float dt, double L, floa
 // sequence) instead of two exec-mask regions per evaluation (~14 scalar instructions, which cost a lone wave as much as vector
 // ones), and carries no live-out registers but the iterates themselves.  The evaluation itself is dare_math.h's
 // dare5_quad_iter_dev / dare4_quad_iter_dev: 65 issue slots.
-typedef unsigned long long dare_mask_t;
 
 // The quad's loop: iterate from X = Q = I until the test passes or the cap is reached, for the agents of `todo` (a lane mask, whole
 // quads).  emit(who, W, w44, it): the agents of `who` return iterate (W = this lane's row of the 4x4 block, w44) after `it`

@@ -111,6 +111,22 @@ def test_dare_full_size(crx, oracle_mod):
         assert (ito == 150).sum() > 0 and ito.min() >= 40
 
 
+@pytest.mark.parametrize("n", [40000, 100001])
+def test_dare_from_v_every_kernel_variant(crx, oracle_mod, n):
+    """The product entry point picks its kernel by batch size: a DPP quad per agent up to 32,768 agents (test_dare_full_size), one agent per
+    lane with nobody masked off up to 98,304, the masked loop at eight waves per SIMD beyond.  Same bits from all of them, iteration counts and
+    odd / even / tiny caps included."""
+    v = lqr_speeds(n, seed=n)
+    for dim, maxiter in ((5, 150), (4, 150), (5, 7), (4, 2)):
+        A, B, Q, R = oracle_mod.lqr_build(v, dim)
+        Xo, Ko, ito = oracle_mod.dare(A, B, Q, R, maxiter=maxiter)
+        K, X, it = crx.dlqr_from_v(_t(v), dim=dim, maxiter=maxiter)
+        assert np.array_equal(it.cpu().numpy(), ito)
+        assert bit_equal(X.cpu().numpy(), Xo)
+        if maxiter == 150:
+            assert bit_equal(K.cpu().numpy(), Ko)
+
+
 def test_dare_edge_cases(crx, oracle_mod):
     import torch
     v = np.array([1.0, 2.0], dtype=np.float32)

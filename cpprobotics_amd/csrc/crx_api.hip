@@ -692,12 +692,14 @@ static int lqr_closed_loop_launch(int n, int dim, float* state, const crx_course
     return CRX_OK;
   }
   const dim3 grid(blocks_for(n, bs)), block(bs);
-#define CRX_LAUNCH_LOOP(DIM, LDS) \
-  hipLaunchKernelGGL((crx::lqr_closed_loop_kernel<DIM, LDS>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, loop->max_ticks, state, cv, \
+#define CRX_LAUNCH_LOOP(DIM, LDS, CHAIN) \
+  hipLaunchKernelGGL((crx::lqr_closed_loop_kernel<DIM, LDS, CHAIN>), grid, block, (LDS) ? lds_bytes(course) : 0, s, n, loop->max_ticks, state, cv, \
                      pe, pth_e, ind, p.dt, p.L, p.eps, p.maxiter, vp, loop->goal_x, loop->goal_y, loop->goal_dis, loop->kp,        \
                      loop->stop_speed, traj_hist, ticks_done)
-  if (dim == 5) { if (use_lds(course)) CRX_LAUNCH_LOOP(5, true); else CRX_LAUNCH_LOOP(5, false); }
-  else { if (use_lds(course)) CRX_LAUNCH_LOOP(4, true); else CRX_LAUNCH_LOOP(4, false); }
+  // one agent per lane: the unmasked Riccati loop while a SIMD holds a wave or two (as crx_dare_from_v_batch_dev does), the masked one beyond
+  const bool chain = n <= kDareChainMaxAgents && use_lds(course);
+  if (dim == 5) { if (chain) CRX_LAUNCH_LOOP(5, true, true); else if (use_lds(course)) CRX_LAUNCH_LOOP(5, true, false); else CRX_LAUNCH_LOOP(5, false, false); }
+  else { if (chain) CRX_LAUNCH_LOOP(4, true, true); else if (use_lds(course)) CRX_LAUNCH_LOOP(4, true, false); else CRX_LAUNCH_LOOP(4, false, false); }
 #undef CRX_LAUNCH_LOOP
   CRX_HIP(hipGetLastError());
   return CRX_OK;

@@ -91,10 +91,29 @@ __device__ __forceinline__ float calc_nearest_index_dev(float sx, float sy, cons
 
 // A, B from v; Q = I, R = I; cold-started fixed point (dare_kernels.hip.h).  All lanes of the wave iterate
 // until the slowest one has converged (each lane freezes its X when its own test passes).
-template <int DIM>
+template <int DIM, bool CHAIN = false>
 __device__ __forceinline__ void dlqr_from_v_dev(float v, float dtf, double L, float eps, int maxiter, bool live, float* K) {
   constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
   const float bv = (float)((double)v / L);   // B(3,0) = state.v / L
+  if constexpr (CHAIN) {
+    // nobody masked off, two evaluations per branch (dare_kernels.hip.h: riccati_from_v_emit); a lane's gain is taken in the rare pass
+    // in which its own test succeeds
+#pragma unroll
+    for (int i = 0; i < M * DIM; ++i) K[i] = 0.0f;
+    auto emit = [&](dare_mask_t who, const Row4* W, float w44, int) {
+      if (!((who >> (threadIdx.x & 63)) & 1)) return;
+      float X[NN];
+#pragma unroll
+      for (int i = 0; i < NN; ++i) X[i] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { X[i + DIM * 0] = W[i].a.x; X[i + DIM * 1] = W[i].a.y; X[i + DIM * 2] = W[i].b.x; X[i + DIM * 3] = W[i].b.y; }
+      if constexpr (DIM == 5) { X[24] = w44; dlqr5_v_gain(dtf, v, bv, dtf, X, K); }
+      else dlqr4_v_gain(dtf, v, bv, X, K);
+    };
+    riccati_from_v_emit<DIM>(dtf, v, bv, dtf, eps, maxiter, __builtin_amdgcn_ballot_w64(live), emit);
+    return;
+  }
   float X[NN];
   riccati_from_v<DIM>(dtf, v, bv, dtf, eps, maxiter, live, X);
   if (DIM == 5) dlqr5_v_gain(dtf, v, bv, dtf, X, K);
@@ -105,7 +124,7 @@ struct LqrCtl { float ai, delta; };
 
 // lqr_steering_control.  DIM 5: returns {ai, delta} (ind is a local starting at 0, :109).  DIM 4: returns
 // delta only (ai = 0 here; the caller adds its PID term) and `ind` is the caller's persistent index (:98).
-template <int DIM, bool LDS>
+template <int DIM, bool LDS, bool CHAIN = false>
 __device__ __forceinline__ LqrCtl lqr_steering_control_dev(float sx, float sy, float syaw, float sv,
                                                            const CourseView& c, const float2* __restrict__ pts,
                                                            int& ind, float& pe, float& pth_e, double dt, double L,
@@ -116,7 +135,7 @@ __device__ __forceinline__ LqrCtl lqr_steering_control_dev(float sx, float sy, f
   const float k = c.ck[j];
   const float th_e = (float)yaw_p2p(syaw - c.cyaw[j]);
   float K[(DIM == 5 ? 2 : 1) * DIM];
-  dlqr_from_v_dev<DIM>(sv, (float)dt, L, eps, maxiter, live, K);
+  dlqr_from_v_dev<DIM, CHAIN>(sv, (float)dt, L, eps, maxiter, live, K);
   const float x0 = e;
   const float x1 = (float)((double)(e - pe) / dt);
   const float x2 = th_e;
@@ -214,7 +233,7 @@ update_kernel(int n, float* __restrict__ state, const float* __restrict__ a_in, 
 // The reference's loops never advance `time_` (they run until the goal is reached); max_ticks bounds them here.
 // ticks_done[a] = number of control+update ticks executed (the goal tick included); traj_hist (optional,
 // [max_ticks][n][4]) receives the state after each tick (rows past ticks_done are left untouched).
-template <int DIM, bool LDS>
+template <int DIM, bool LDS, bool CHAIN = false>
 __global__ void __launch_bounds__(kTrackBlock)
 lqr_closed_loop_kernel(int n, int max_ticks, float* __restrict__ state, CourseView c, float* __restrict__ pe_io,
                        float* __restrict__ pth_io, int* __restrict__ ind_io, double dt, double L, float eps, int maxiter,
@@ -235,8 +254,8 @@ lqr_closed_loop_kernel(int n, int max_ticks, float* __restrict__ state, CourseVi
     float4 sn = s;
     float pe_n = pe, pth_n = pth;
     int ind_n = ind;
-    const LqrCtl u = lqr_steering_control_dev<DIM, LDS>(sn.x, sn.y, sn.z, sn.w, c, pts, ind_n, pe_n, pth_n, dt, L, eps,
-                                                        maxiter, !done);
+    const LqrCtl u = lqr_steering_control_dev<DIM, LDS, CHAIN>(sn.x, sn.y, sn.z, sn.w, c, pts, ind_n, pe_n, pth_n, dt, L, eps,
+                                                               maxiter, !done);
     float ai = u.ai;
     if (DIM == 4) {                                                   // float ai = KP * (speed_profile[ind]-state.v)
       const int js = ind_n < 0 ? 0 : (ind_n >= c.n ? c.n - 1 : ind_n);

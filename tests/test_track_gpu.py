@@ -174,6 +174,19 @@ def test_lqr_closed_loop_both_layouts(crx, oracle_mod, lqr_setup, dim, lanes):
             assert bit_equal(h[: tio[a], a], histo[: tio[a], a])
 
 
+@pytest.mark.parametrize("dim", [5, 4])
+def test_lqr_closed_loop_large_batch_variant(crx, oracle_mod, lqr_setup, dim):
+    """Beyond 98,304 agents the one-lane loop runs the masked Riccati iteration (eight waves per SIMD); up to there the unmasked one (forced
+    one-lane runs of the tests above), up to 32,768 a DPP quad per agent.  Two ticks of 100,001 agents through the product entry point."""
+    course, goal, dc = lqr_setup
+    n = 100001
+    st = tracking_agents(n, tuple(c[:200] for c in course), 91 + dim, spread=0.4)
+    so, tio, histo, peo, ptho, indo = oracle_mod.lqr_closed_loop(st, course, goal, dim=dim, max_ticks=2, want_hist=True)
+    sd = _t(st)
+    ticks, hist = crx.closed_loop_prediction(sd, dc, goal, dim=dim, max_ticks=2, want_hist=True)
+    assert np.array_equal(ticks.cpu().numpy(), tio) and bit_equal(sd.cpu().numpy(), so) and bit_equal(hist.cpu().numpy(), histo)
+
+
 def test_lqr_closed_loop_nan_position_both_layouts(crx, oracle_mod, lqr_setup):
     """A NaN position never compares smaller in the course scan: the index keeps its incoming value (0 in the 5-state file, the caller's in the
     4-state file) in both layouts."""

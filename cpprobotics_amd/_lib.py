@@ -119,6 +119,8 @@ _SIGNATURES = {
     "crx_mpc_closed_loop_work_bytes": (C.c_size_t, [_I, _I]),
     "crx_mpc_closed_loop_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
                                            _P, _P]),
+    "crx_mpc_closed_loop_flags_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
+                                                 _P, _P]),
     "crx_mpc_closed_loop_batch": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

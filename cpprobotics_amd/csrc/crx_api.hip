@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -34,6 +35,29 @@
 namespace {
 
 thread_local std::string g_err = "";
+
+// roctx ranges around every entry point, so that rocprofv3 --marker-trace output of an application is self-describing (which
+// crx call a kernel belongs to).  The marker library is looked up at run time: no link dependency, a no-op when it is absent.
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_GLOBAL);
+    if (!h) return;
+    push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+    pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~TraceRange() { if (on) roctx().pop(); }
+};
+#define CRX_TRACE() TraceRange crx_trace_range__(__func__)
 
 int fail(int code, const char* what) { g_err = what; return code; }
 int hip_fail(hipError_t e, const char* what) {
@@ -94,7 +118,7 @@ struct DevBuf {
 
 extern "C" {
 
-int crx_version(void) { return 300; }  // 0.3.0 (0.2.1 + host-pointer window search and MPC closed loop, quad Riccati kernel)
+int crx_version(void) { return 400; }  // 0.4.0 (0.3.0 + device selection and sharded host-pointer entries, grow-only workspace, crx_mpc_closed_loop_flags_batch_dev)
 
 // The engine keeps no global state: crx_init only checks that a device is there and forces the HIP runtime + code object to
 // load now rather than in the first timed call; crx_shutdown drains the device.  Both are optional.
@@ -140,6 +164,7 @@ void crx_mpc_default_params(crx_mpc_params* p) {
 // ---------------------------------------------------------------------------------------------
 int crx_motion_model_batch_dev(int n, const float* x, const float* u, float* x_out,
                                const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -151,6 +176,7 @@ int crx_motion_model_batch_dev(int n, const float* x, const float* u, float* x_o
 
 int crx_jacobF_batch_dev(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm,
                          void* stream) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -161,6 +187,7 @@ int crx_jacobF_batch_dev(int n, const float* x, const float* u, float* jF, const
 }
 
 int crx_observation_model_batch_dev(int n, const float* x, float* z_out, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -180,6 +207,7 @@ int crx_jacobH(float* jH_out) {
 
 int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const float* u, const float* Q,
                            const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
   if (n < 0 || !Q || !R || (n && (!x || !P || !z || !u)))
     return fail(CRX_ERR_INVALID, "ekf_step: bad argument");
   if (int rc = check_device()) return rc;
@@ -227,10 +255,12 @@ static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, cons
 
 int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
                           const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
   return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, false);
 }
 int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
                              const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
   return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, true);
 }
 
@@ -246,6 +276,7 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
                                 const float* w, float* z, float* ud, float* xTrue_hist,
                                 float* xDR_hist, const float qsim[2], const float rsim[2],
                                 const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
   if (n < 0 || T < 0 || !qsim || !rsim || (n && (!u_true || !xTrue || !xDR)) || (n && T && (!w || !z || !ud)))
     return fail(CRX_ERR_INVALID, "ekf_simulate_inputs: bad argument");
   if (int rc = check_device()) return rc;
@@ -267,6 +298,7 @@ int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue,
 // *left_domain comes back non-zero, xEst / PEst / x_hist of this call are not valid.
 int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
                                const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream) {
+  CRX_TRACE();
 #if !CRX_EXPERIMENTAL_KERNELS
   (void)x_hist; (void)prm; (void)left_domain; (void)stream;
   return fail(CRX_ERR_INVALID, "ekf_run_pair: this libcrx.so was built without the experimental kernels (CRX_EXPERIMENTAL_KERNELS=0)");
@@ -298,6 +330,7 @@ __global__ void __launch_bounds__(256) normal_draws_kernel(int n, int T, unsigne
 }  // namespace crx
 
 int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed, unsigned stream_id, float* w, void* stream) {
+  CRX_TRACE();
   if (n < 0 || T < 0 || agent0 < 0 || ((size_t)n * T && !w)) return fail(CRX_ERR_INVALID, "normal_draws: bad argument");
   if (int rc = check_device()) return rc;
   if ((size_t)n * T == 0) return CRX_OK;
@@ -309,6 +342,7 @@ int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed
 
 // ---- host-pointer variants (stage, launch, copy back, synchronise) ----------------------------
 int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out, const crx_ekf_params* prm) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -322,6 +356,7 @@ int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out, 
 }
 
 int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -335,6 +370,7 @@ int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx
 }
 
 int crx_observation_model_batch(int n, const float* x, float* z_out) {
+  CRX_TRACE();
   if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -348,11 +384,13 @@ int crx_observation_model_batch(int n, const float* x, float* z_out) {
 
 int crx_ekf_step_batch(int n, float* x, float* P, const float* z, const float* u, const float* Q,
                        const float* R, const crx_ekf_params* prm) {
+  CRX_TRACE();
   return crx_ekf_run_batch(n, 1, x, P, z, u, nullptr, nullptr, Q, R, prm);
 }
 
 int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
                       float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
+  CRX_TRACE();
   if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
     return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
   if (int rc = check_device()) return rc;
@@ -385,6 +423,7 @@ int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const fl
 // ---------------------------------------------------------------------------------------------
 int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
                        float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
@@ -436,16 +475,19 @@ static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_para
 
 int crx_dare_from_v_batch_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
                               int* iters, void* stream) {
+  CRX_TRACE();
   return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, 0);
 }
 
 int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
                                 int* iters, void* stream, int lanes_per_agent) {
+  CRX_TRACE();
   return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, lanes_per_agent);
 }
 
 int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* Q, const float* R, float eps,
                    int maxiter, float* X, float* K, int* iters) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
@@ -468,6 +510,7 @@ int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* 
 }
 
 int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K, int* iters) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || (n && !v))
     return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
@@ -525,19 +568,23 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
 }
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
+  CRX_TRACE();
   return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, 0);
 }
 int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int lanes_per_agent) {
+  CRX_TRACE();
   return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, lanes_per_agent);
 }
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
+  CRX_TRACE();
   return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, waves_per_workgroup);
 }
 
 int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
                         int* status, double* cost) {
+  CRX_TRACE();
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
@@ -610,6 +657,7 @@ void crx_vehicle_default_params(crx_vehicle_params* p, int mpc) {
 }
 
 int crx_calc_nearest_index_batch_dev(int n, const float* state, const crx_course* course, int* ind, float* e, void* stream) {
+  CRX_TRACE();
   if (n < 0 || !course_ok(course, false) || (n && (!state || !ind))) return fail(CRX_ERR_INVALID, "calc_nearest_index: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -624,6 +672,7 @@ int crx_calc_nearest_index_batch_dev(int n, const float* state, const crx_course
 
 int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
                                        float* pth_e, const crx_lqr_params* prm, float* control, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || (n && (!state || !pe || !pth_e || !control)))
     return fail(CRX_ERR_INVALID, "lqr_steering_control: bad argument");
   if (int rc = check_device()) return rc;
@@ -653,6 +702,7 @@ int crx_lqr_steering_control_batch_dev(int n, int dim, const float* state, const
 }
 
 int crx_update_batch_dev(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (n && (!state || !a || !delta))) return fail(CRX_ERR_INVALID, "update: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -707,16 +757,19 @@ static int lqr_closed_loop_launch(int n, int dim, float* state, const crx_course
 int crx_lqr_closed_loop_batch_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
                                   const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
                                   float* traj_hist, int* ticks_done, void* stream) {
+  CRX_TRACE();
   return lqr_closed_loop_launch(n, dim, state, course, pe, pth_e, ind, prm, veh, loop, traj_hist, ticks_done, stream, 0);
 }
 int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
                                     const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
                                     float* traj_hist, int* ticks_done, void* stream, int lanes_per_agent) {
+  CRX_TRACE();
   return lqr_closed_loop_launch(n, dim, state, course, pe, pth_e, ind, prm, veh, loop, traj_hist, ticks_done, stream, lanes_per_agent);
 }
 
 int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
                                             int* ind_out, void* stream) {
+  CRX_TRACE();
   if (n < 0 || nsearch < 0 || !course_ok(course, false) || (n && (!state || !pind || !ind_out)))
     return fail(CRX_ERR_INVALID, "calc_nearest_index(window): bad argument");
   if (int rc = check_device()) return rc;
@@ -729,6 +782,7 @@ int crx_calc_nearest_index_window_batch_dev(int n, const float* state, const crx
 
 int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const crx_course* course, float dl, double dt,
                                       int nsearch, int* target_ind, float* xref, void* stream) {
+  CRX_TRACE();
   if (n < 0 || T < 1 || nsearch < 0 || !course_ok(course, true) || (n && (!state || !target_ind || !xref)))
     return fail(CRX_ERR_INVALID, "calc_ref_trajectory: bad argument");
   if (int rc = check_device()) return rc;
@@ -748,7 +802,16 @@ size_t crx_mpc_closed_loop_work_bytes(int n, int T) {
 
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
-                                  int* ticks_done, int* solve_flags, void* stream) {
+                                  int* ticks_done, void* work, void* stream) {
+  CRX_TRACE();
+  (void)work;    // the 0.2 signature: ignored, never written (0.3.0 had reused this slot for solve_flags)
+  return crx_mpc_closed_loop_flags_batch_dev(n, T, state, course, dl, nsearch, prm, loop, target_ind, traj_hist, ticks_done, nullptr, stream);
+}
+
+int crx_mpc_closed_loop_flags_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
+                                        const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
+                                        int* ticks_done, int* solve_flags, void* stream) {
+  CRX_TRACE();
   if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 ||
       (n && (!state || !target_ind || !ticks_done)))
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
@@ -782,6 +845,7 @@ int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* 
 
 // ---- host-pointer variants -----------------------------------------------------------------------
 int crx_calc_nearest_index_batch(int n, const float* state, const crx_course* course, int* ind, float* e) {
+  CRX_TRACE();
   if (n < 0 || !course_ok(course, false) || (n && (!state || !ind))) return fail(CRX_ERR_INVALID, "calc_nearest_index: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -798,6 +862,7 @@ int crx_calc_nearest_index_batch(int n, const float* state, const crx_course* co
 
 int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
                                    float* pth_e, const crx_lqr_params* prm, float* control) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || (n && (!state || !pe || !pth_e || !control)))
     return fail(CRX_ERR_INVALID, "lqr_steering_control: bad argument");
   if (int rc = check_device()) return rc;
@@ -820,6 +885,7 @@ int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx
 }
 
 int crx_update_batch(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm) {
+  CRX_TRACE();
   if (n < 0 || (n && (!state || !a || !delta))) return fail(CRX_ERR_INVALID, "update: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
@@ -837,6 +903,7 @@ int crx_update_batch(int n, float* state, const float* a, const float* delta, co
 int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
                               const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
                               float* traj_hist, int* ticks_done) {
+  CRX_TRACE();
   if (n < 0 || (dim != 4 && dim != 5) || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
     return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
   if (int rc = check_device()) return rc;
@@ -863,6 +930,7 @@ int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* co
 
 int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
                                         int* ind_out) {
+  CRX_TRACE();
   if (n < 0 || nsearch < 0 || !course_ok(course, false) || (n && (!state || !pind || !ind_out)))
     return fail(CRX_ERR_INVALID, "calc_nearest_index(window): bad argument");
   if (int rc = check_device()) return rc;
@@ -880,6 +948,7 @@ int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_cou
 
 int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
                               const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done, int* solve_flags) {
+  CRX_TRACE();
   if (n < 0 || T < 2 || T > 64 || !course_ok(course, true) || !loop || loop->max_ticks < 0 || (n && !state))
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
@@ -891,8 +960,8 @@ int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* cour
   if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
   CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
   if (target_ind) CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
-  if (int rc = crx_mpc_closed_loop_batch_dev(n, T, ds.as<float>(), &dc.c, dl, nsearch, prm, loop, di.as<int>(),
-                                             traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), df.as<int>(), nullptr)) return rc;
+  if (int rc = crx_mpc_closed_loop_flags_batch_dev(n, T, ds.as<float>(), &dc.c, dl, nsearch, prm, loop, di.as<int>(),
+                                                   traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), df.as<int>(), nullptr)) return rc;
   if (solve_flags) CRX_HIP(hipMemcpy(solve_flags, df.p, 4 * nn, hipMemcpyDeviceToHost));
   CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
   if (target_ind) CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
@@ -903,6 +972,7 @@ int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* cour
 
 int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_course* course, float dl, double dt, int nsearch,
                                   int* target_ind, float* xref) {
+  CRX_TRACE();
   if (n < 0 || T < 1 || nsearch < 0 || !course_ok(course, true) || (n && (!state || !target_ind || !xref)))
     return fail(CRX_ERR_INVALID, "calc_ref_trajectory: bad argument");
   if (int rc = check_device()) return rc;
@@ -938,6 +1008,7 @@ void crx_pf_default_params(crx_pf_params* p) {
 int crx_pf_run_batch_dev(int n, int np, int T, int L, float* px, float* pw, float* xEst, float* PEst, const float* obs,
                          const int* nobs, const float* u, const float* nrm, const float* uni, const crx_pf_params* prm,
                          float* x_hist, int* n_resampled, void* stream) {
+  CRX_TRACE();
   if (n < 0 || T < 0 || L < 0 || (np != 100 && np != 64 && np != 128) ||
       (n && (!px || !pw || !xEst || !PEst)) || (n && T && (!nobs || !u || !nrm || !uni || (L && !obs))))
     return fail(CRX_ERR_INVALID, "pf_run: bad argument (np must be 64, 100 or 128)");
@@ -973,6 +1044,7 @@ void crx_dwa_default_config(crx_dwa_config* c) {
 int crx_dwa_run_batch_dev(int n, int max_ticks, float* state, float* u, const float* goal, const float* ob, int nob,
                           const crx_dwa_config* cfg, float* traj_hist, int* ticks_done, int* status, int* best_idx,
                           int* n_samples, void* stream) {
+  CRX_TRACE();
   if (n < 0 || max_ticks < 0 || nob < 0 || nob > crx::kDwaMaxOb || (nob && !ob) || (n && (!state || !u || !goal)))
     return fail(CRX_ERR_INVALID, "dwa_run: bad argument (nob <= 256)");
   if (int rc = check_device()) return rc;
@@ -1082,6 +1154,7 @@ int crx_frenet_num_paths(const crx_frenet_config* cfg) {
 }
 
 int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coef) {
+  CRX_TRACE();
   if (!wx || !wy || !coef || nx < 2 || nx > crx::kFrMaxKnots) return fail(CRX_ERR_INVALID, "frenet_spline_build: bad argument (2 <= nx <= 64)");
   float* s = coef;
   s[0] = 0.0f;                                   // Spline2D::calc_s :172-186
@@ -1098,6 +1171,7 @@ int crx_frenet_spline_build(const float* wx, const float* wy, int nx, float* coe
 }
 
 int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, int cap) {
+  CRX_TRACE();
   if (!coef || nx < 2 || cap < 0 || (cap && (!rx || !ry))) return fail(CRX_ERR_INVALID, "frenet_course_samples: bad argument");
   const float* s = coef;
   int k = 0;
@@ -1118,6 +1192,7 @@ int crx_frenet_course_samples(const float* coef, int nx, float* rx, float* ry, i
 // (calc_postion), heading (calc_yaw = atan2 of the first derivatives) and curvature (calc_curvature) per sample.  Host, once
 // per course.  Returns the number of samples; fills up to cap of each non-null array.
 int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double ds, float* cx, float* cy, float* cyaw, float* ck, int cap) {
+  CRX_TRACE();
   if (!wx || !wy || nx < 2 || nx > crx::kFrMaxKnots || !(ds > 0.0) || cap < 0) return fail(CRX_ERR_INVALID, "course_from_waypoints: bad argument");
   std::vector<float> coef(9 * (size_t)nx);
   if (int rc = crx_frenet_spline_build(wx, wy, nx, coef.data())) return rc;
@@ -1150,6 +1225,7 @@ int crx_course_from_waypoints(const float* wx, const float* wy, int nx, double d
 // variant 0 (src/model_predictive_control.cpp:83-105): sign from the direction of travel against the heading; the reference's
 // `speed_profile[-1] = 0.0` (:102) writes BEFORE the vector, so the last entry keeps its value, as here.
 int crx_calc_speed_profile(int variant, const float* rx, const float* ry, const float* ryaw, int n, float target_speed, float* sp) {
+  CRX_TRACE();
   if ((variant != 0 && variant != 4 && variant != 5) || n < 1 || !ryaw || !sp || (variant == 0 && (!rx || !ry)))
     return fail(CRX_ERR_INVALID, "calc_speed_profile: bad argument (variant 5, 4 or 0)");
   for (int i = 0; i < n; ++i) sp[i] = target_speed;
@@ -1221,7 +1297,9 @@ __global__ void __launch_bounds__(256) dsincos_probe_kernel(int n, const double*
 }
 }  // namespace crx
 int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream) {
+  CRX_TRACE();
   if (n < 0 || (n > 0 && (!x || !s || !c))) return fail(CRX_ERR_INVALID, "dsincos: bad arguments");
+  if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   hipLaunchKernelGGL(crx::dsincos_probe_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, x, s, c);
   CRX_HIP(hipGetLastError());
@@ -1232,6 +1310,7 @@ int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* co
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,
                              void* stream) {
+  CRX_TRACE();
   if (n < 0 || max_ticks < 0 || nob < 0 || nob > crx::kFrMaxOb || (nob && !ob) || nx < 2 || nx > crx::kFrMaxKnots || !coef ||
       !goal_xy || path_cap < 0 || (n && !state))
     return fail(CRX_ERR_INVALID, "frenet_run: bad argument (2 <= nx <= 64, nob <= 128)");

@@ -236,6 +236,15 @@ CRX_HD F dare5_quad_iter(const QuadLane<F, M>& c, const F* x, F x44, F* xn, F& x
 // 58 instead of 77 VALU instructions per evaluation (65 instead of 87 issue slots with the loop of dare_kernels.hip.h); tests/test_lqr_gpu.py and tests/test_track_gpu.py hold the kernels to the
 // oracle's bits (iteration counts included), tests/test_dare_host.py the generic code above.
 #if defined(__HIPCC__)
+// The inline assembly below is written for wave64 on the gfx9 family's DPP / exec-mask rules (s_and_saveexec_b64 over a 64-bit lane
+// mask, quad_perm DPP operands, hand-counted s_nop wait states).  The Makefile's ARCH can be overridden: refuse any target this
+// was not written and verified for rather than assemble something that runs wrong without a diagnostic.
+#if defined(__HIP_DEVICE_COMPILE__)
+#if !defined(__gfx950__) && !defined(__gfx942__)
+#error "dare_math.h: the hand-issued quad Riccati evaluation targets gfx950 (gfx942 shares its DPP hazard rules); other targets need the generic dare*_quad_iter"
+#endif
+// (gfx942 / gfx950 execute wave64 only — no wave32 mode exists on the gfx9 family, so the architecture test is the wave-size test)
+#endif
 typedef float dq_v2f __attribute__((ext_vector_type(2)));
 
 // acc[j] + src[j] on lane 2 of every quad, acc[j] elsewhere: the four adds under an exec mask of the lanes 2 (mod 4)

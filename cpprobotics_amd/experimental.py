@@ -18,20 +18,52 @@ _X_SIGNATURES = {
 }
 EXPERIMENTAL_SYMBOLS = tuple(sorted(_X_SIGNATURES))
 _bound = False
+_ab = None
+
+
+def _bind(l, what):
+    for name, (res, args) in _X_SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError as e:
+            raise L.CrxError(f"{what} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
 
 
 def xlib():
+    """The product library with the crx_x_ entry points bound (forced variants of PRODUCT kernels)."""
     global _bound
     l = L.lib()
     if not _bound:
-        for name, (res, args) in _X_SIGNATURES.items():
-            try:
-                fn = getattr(l, name)
-            except AttributeError as e:
-                raise L.CrxError(f"libcrx.so does not export {name}") from e
-            fn.restype, fn.argtypes = res, args
+        _bind(l, "libcrx.so")
         _bound = True
     return l
+
+
+def ab_lib_path():
+    import os
+    return os.environ.get("CRX_AB_LIB_PATH") or os.path.join(os.path.dirname(L.lib_path()), "libcrx_x.so")
+
+
+def ablib():
+    """The A/B build (libcrx_x.so = the same sources with CRX_EXPERIMENTAL_KERNELS=1): the only library that contains the two
+    measured-and-rejected kernel variants (two-lane EKF, four-lane MPC).  The product libcrx.so does not carry them."""
+    global _ab
+    if _ab is None:
+        import os
+        path = ab_lib_path()
+        if not os.path.exists(path):
+            raise L.CrxError(f"{path} is missing: `make -C cpprobotics_amd/csrc all` builds the A/B library beside libcrx.so")
+        L.lib()                       # torch's HIP runtime first, as for the product library
+        _ab = C.CDLL(path, mode=C.RTLD_LOCAL)
+        _bind(_ab, "libcrx_x.so")
+        _ab.crx_last_error.restype = C.c_char_p
+    return _ab
+
+
+def _check_ab(rc, what):
+    if rc != 0:
+        raise L.CrxError(f"{what} failed with status {rc}: {ablib().crx_last_error().decode('utf-8', 'replace')}")
 
 
 def dlqr_from_v_lanes(v, dim=5, lanes_per_agent=0, dt=0.1, L_wheelbase=0.5, eps=0.01, maxiter=150):
@@ -63,6 +95,10 @@ def mpc_solve_lanes(x0, xref, T, lanes_per_agent=0, params=None):
     sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
     status = torch.empty((n,), dtype=torch.int32, device=x0.device)
     cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    if int(lanes_per_agent) == 4:      # the rejected four-lane kernel lives in the A/B build only
+        _check_ab(ablib().crx_x_mpc_solve_lanes_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                    L.stream_ptr(), 4), "crx_x_mpc_solve_lanes_dev (libcrx_x.so)")
+        return sol, status, cost
     L.check(xlib().crx_x_mpc_solve_lanes_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                              L.stream_ptr(), int(lanes_per_agent)), "crx_x_mpc_solve_lanes_dev")
     return sol, status, cost
@@ -109,9 +145,9 @@ def ekf_run_pair(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):
     import torch
     n, T, q, r, p = _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist)
     flag = torch.zeros((4,), dtype=torch.int32, device=xEst.device)
-    L.check(xlib().crx_x_ekf_run_pair_batch_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist),
-                                                q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.ptr(flag),
-                                                L.stream_ptr()), "crx_x_ekf_run_pair_batch_dev")
+    _check_ab(ablib().crx_x_ekf_run_pair_batch_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist),
+                                                   q.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), C.byref(p), L.ptr(flag),
+                                                   L.stream_ptr()), "crx_x_ekf_run_pair_batch_dev (libcrx_x.so)")
     return bool(flag[0].item() == 0)
 
 

@@ -21,6 +21,24 @@ def shard_sizes(n, world):
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
+class _Done:
+    """A finished collective (what the host-staged path hands back in place of an async Work)."""
+    def wait(self):
+        return True
+
+
+def _all_gather_into(out, local, group=None, async_op=False):
+    """dist.all_gather_into_tensor, plus one portability case: device tensors on a gloo group (several ranks sharing one GPU in
+    bench.py's --oversubscribe dry run — RCCL refuses that, gloo has no device all-gather) are staged through the host,
+    synchronously.  RCCL groups and CPU tensors take the collective as it is."""
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        oc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(oc, local.contiguous().cpu(), group=group)
+        out.copy_(oc)
+        return _Done() if async_op else None
+    return dist.all_gather_into_tensor(out, local, group=group, async_op=async_op)
+
+
 def gather_agents(local, n_total, group=None):
     """All-gather per-agent rows.  `local` is [n_local, ...] on this rank (agent-major); returns
     [n_total, ...] in global agent order on every rank.  Equal shards use one
@@ -31,13 +49,13 @@ def gather_agents(local, n_total, group=None):
     tail = tuple(local.shape[1:])
     if len(set(sizes)) == 1:
         out = torch.empty((n_total,) + tail, dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        _all_gather_into(out, local.contiguous(), group)
         return out
     m = max(sizes)
     padded = torch.zeros((m,) + tail, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     buf = torch.empty((world * m,) + tail, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, padded, group=group)
+    _all_gather_into(buf, padded, group)
     return torch.cat([buf[r * m: r * m + sizes[r]] for r in range(world)], dim=0)
 
 
@@ -51,7 +69,7 @@ def gather_time_major(local, n_total, group=None):
     if len(set(sizes)) != 1:
         return gather_agents(local.transpose(0, 1).contiguous(), n_total, group).transpose(0, 1).contiguous()
     buf = torch.empty((world * T, nl, Cc), dtype=local.dtype, device=local.device)   # rank-major blocks
-    dist.all_gather_into_tensor(buf, local.contiguous(), group=group)
+    _all_gather_into(buf, local.contiguous(), group)
     return buf.view(world, T, nl, Cc).permute(1, 0, 2, 3).reshape(T, n_total, Cc).contiguous()
 
 
@@ -65,24 +83,27 @@ class RingGather:
     def __init__(self, n_total, tail, ring, device, dtype=torch.float32, group=None):
         self.ring, self.group = int(ring), group
         self.out = [torch.empty((n_total,) + tuple(tail), dtype=dtype, device=device) for _ in range(self.ring)]
-        self.last = None            # the most recent collective: collectives of one group complete in issue order
+        # Every collective still in flight.  RCCL runs a group's collectives in issue order on one stream, so waiting for the
+        # last one would do there; gloo hands them to a pool of worker threads that may finish out of order (the world-2 CPU
+        # test caught a lap whose first gather was still running when its buffer was reused) — so all of them are waited for.
+        self.pending = []
 
     def slot(self, step):
         return step % self.ring
 
     def begin_step(self, step):
-        if step % self.ring == 0 and self.last is not None:
-            self.last.wait()        # stream-level on GPUs: every gather of the previous lap is done
+        if step % self.ring == 0:
+            self.wait()             # stream-level on GPUs: every gather of the previous lap is done
 
     def gather(self, step, local):
         out = self.out[step % self.ring]
-        self.last = dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+        self.pending.append(_all_gather_into(out, local, self.group, async_op=True))
         return out
 
     def wait(self):
-        if self.last is not None:
-            self.last.wait()
-            self.last = None
+        for w in self.pending:
+            w.wait()
+        self.pending = []
 
 
 class ChunkedTrajectoryGather:
@@ -108,8 +129,8 @@ class ChunkedTrajectoryGather:
         self.wait()                                   # the previous pass's gathers still read self.local
         for c in range(self.chunks):
             launch(c, c * self.Tc, (c + 1) * self.Tc, self.local[c])
-            self.pending.append(dist.all_gather_into_tensor(self.gathered[c].view(self.world * self.Tc, self.nl, self.C), self.local[c],
-                                                            group=self.group, async_op=True))
+            self.pending.append(_all_gather_into(self.gathered[c].view(self.world * self.Tc, self.nl, self.C), self.local[c],
+                                                 self.group, async_op=True))
         return self
 
     def wait(self):
@@ -146,6 +167,7 @@ class MixedSwarmRound:
         self.n_total = n_total if n_total is not None else n_local * self.world
         self.cuda = torch.device(device).type == "cuda"
         self.chunks = chunks
+        assert T % chunks == 0, "the chunk count must divide the number of steps"
         self.cg = ChunkedTrajectoryGather(T, n_local, C, chunks, device, group=group) if (gather == "traj" and dist.is_initialized()) else None
         self.local_hist = None if self.cg is not None else torch.empty((chunks, T // chunks, n_local, C), dtype=torch.float32, device=device)
         self.est = torch.empty(((n_local + self.every - 1) // self.every, C), dtype=torch.float32, device=device)
@@ -189,5 +211,8 @@ class MixedSwarmRound:
         return {"traj": 4 * self.C * self.T * self.n_total, "final": 4 * self.C * self.n_total, "none": 0}[self.gather_kind]
 
     def trajectory_time_major(self):
-        """[T, n_total, C] in global agent order (a copy), from the chunked gather."""
+        """[T, n_total, C] in global agent order (a copy), from the chunked gather; without one (a single process, or a round
+        that gathers final estimates / nothing) the shard's own history [T, n_local, C]."""
+        if self.cg is None:
+            return self.local_hist.reshape(self.T, self.nl, self.C).clone()
         return self.cg.time_major()

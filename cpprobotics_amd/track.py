@@ -202,7 +202,7 @@ def mpc_simulation(state, course, goal, T, max_ticks, target_ind=None, dl=1.0, n
     hist = torch.zeros((max_ticks, n, 4), dtype=torch.float32, device=state.device) if want_hist else None
     lp = loop_params(goal, goal_dis, max_ticks)
     flags = torch.zeros((n,), dtype=torch.int32, device=state.device) if want_flags else None
-    L.check(L.lib().crx_mpc_closed_loop_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), int(nsearch), C.byref(p),
-                                                  C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), L.ptr(flags),
-                                                  L.stream_ptr()), "crx_mpc_closed_loop_batch_dev")
+    L.check(L.lib().crx_mpc_closed_loop_flags_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), int(nsearch), C.byref(p),
+                                                        C.byref(lp), L.ptr(target_ind), L.ptr(hist), L.ptr(ticks), L.ptr(flags),
+                                                        L.stream_ptr()), "crx_mpc_closed_loop_flags_batch_dev")
     return (ticks, hist, flags) if want_flags else (ticks, hist)

@@ -158,8 +158,9 @@ void crx_mpc_default_params(crx_mpc_params* p);
  * (Eigen::Matrix<float,NX,T>::data()).
  * sol: n x (4T + 2(T-1)) floats in the reference's variable layout
  *      [x(T) | y(T) | yaw(T) | v(T) | delta(T-1) | a(T-1)]   (:54-60, :341-345).
- * status (may be NULL): per agent, bit0 = converged to tol, bit1 = speed bound was active
- * (see DESIGN.md), bits 8.. = iterations used.  cost (may be NULL): final objective (double). */
+ * status (may be NULL): per agent, bit0 = converged to tol, bit1 = a speed knot of the returned trajectory lies outside
+ * [min_speed, max_speed] — which happens only when the START speed x0.v does (every rollout clamps the acceleration so that
+ * later knots stay inside; with an infeasible start the acceleration limits win) —, bits 8.. = iterations used.  cost (may be NULL): final objective (double). */
 int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref,
                         const crx_mpc_params* prm, float* sol, int* status, double* cost);
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,
@@ -246,13 +247,20 @@ int crx_calc_ref_trajectory_batch_dev(int n, int T, const float* state, const cr
  * (first control of the solution) -> goal test, for n agents, the WHOLE episode in one persistent kernel enqueued on `stream`
  * (state, target_ind and the reference trajectory of an agent never leave the lane between ticks).  Agents that reached the
  * goal stop being updated.  target_ind: in/out.
- * solve_flags (may be NULL; n ints, since 0.3.0 in the place of the `work` pointer that 0.2 ignored): per agent, bit 0 = at least
- * one tick's solve did not converge within max_iter (its first control was applied all the same — the reference applies whatever
- * IPOPT returns, :338-339), bit 1 = at least one tick started from a speed outside the speed bounds (crx_mpc_solve status bit 1). */
+ * crx_mpc_closed_loop_batch_dev keeps its 0.2 signature: `work` is ignored (crx_mpc_closed_loop_work_bytes() is 0) and never
+ * written, so a caller built against 0.2 that passes a dummy pointer stays safe.  (0.3.0 had put an `int* solve_flags` the kernel
+ * writes n ints into in that slot under the same symbol; 0.4 moved it to a symbol of its own.)
+ * crx_mpc_closed_loop_flags_batch_dev (since 0.4) — the same launch plus solve_flags (may be NULL; n ints): per agent, bit 0 = at
+ * least one tick's solve did not converge within max_iter (its first control was applied all the same — the reference applies
+ * whatever IPOPT returns, :338-339), bit 1 = at least one tick's solve reported crx_mpc_solve status bit 1 (it started from a
+ * speed outside [min_speed, max_speed]). */
 size_t crx_mpc_closed_loop_work_bytes(int n, int T);   /* 0 since 0.2: no work buffer */
 int crx_mpc_closed_loop_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
                                   const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
-                                  int* ticks_done, int* solve_flags, void* stream);
+                                  int* ticks_done, void* work /* ignored */, void* stream);
+int crx_mpc_closed_loop_flags_batch_dev(int n, int T, float* state, const crx_course* course, float dl, int nsearch,
+                                        const crx_mpc_params* prm, const crx_loop_params* loop, int* target_ind, float* traj_hist,
+                                        int* ticks_done, int* solve_flags, void* stream);
 /* host pointers (target_ind may be NULL = start from 0 as mpc_simulation does, :357) */
 int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
                               const crx_loop_params* loop, int* target_ind, float* traj_hist, int* ticks_done, int* solve_flags);

@@ -40,10 +40,30 @@ def test_experimental_entry_points_are_separate(crx):
     assert "getenv" not in api
 
 
+def test_product_library_does_not_carry_the_rejected_variants(crx):
+    """the two measured-and-rejected kernel variants (two-lane EKF, four-lane MPC) are compiled into the A/B build
+    libcrx_x.so only; the product libcrx.so neither contains their code objects nor runs them."""
+    from cpprobotics_amd import experimental as X
+    prod = open(crx.lib_path(), "rb").read()
+    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel"):
+        assert k not in prod, k
+    ab = X.ab_lib_path()
+    assert os.path.exists(ab), "libcrx_x.so missing: make -C cpprobotics_amd/csrc all"
+    abb = open(ab, "rb").read()
+    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel", b"ekf_run_kernel", b"mpc_kernel"):
+        assert k in abb, k
+    raw = C.CDLL(ab)
+    for name in _declared_functions() + _declared_functions("crx_experimental.h"):
+        assert hasattr(raw, name), f"libcrx_x.so does not export {name}"
+    l = X.xlib()                                     # the product library answers the rejected variants with CRX_ERR_INVALID
+    assert l.crx_x_ekf_run_pair_batch_dev(0, 0, None, None, None, None, None, None, None, None, None, None) == -1
+    assert b"without the experimental kernels" in l.crx_last_error()
+
+
 def test_version_and_defaults(crx):
     from cpprobotics_amd import _lib as L
     l = crx.lib()
-    assert l.crx_version() >= 100
+    assert l.crx_version() >= 400
     e = L.EkfParams(); l.crx_ekf_default_params(C.byref(e)); assert e.dt == 0.1
     q = L.LqrParams(); l.crx_lqr_default_params(C.byref(q))
     assert (q.dt, q.L, q.maxiter) == (0.1, 0.5, 150) and abs(q.eps - 0.01) < 1e-9

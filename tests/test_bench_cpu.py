@@ -30,6 +30,22 @@ def test_smoke_refuses_without_gpu():
     assert r.returncode != 0 and ("no HIP device" in r.stderr or "GPU" in r.stderr)
 
 
+@pytest.mark.skipif(not _no_gpu(), reason="a GPU is present")
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus N` invoked plainly must not die on an assert: without WORLD_SIZE it starts the ranks
+    itself.  On a GPU-less box that shows as (a) a clear refusal when fewer than N devices are visible, (b) with --oversubscribe, N
+    ranks started under torch.distributed.run, each refusing for lack of a GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "only 0 GPU(s) visible" in (r.stderr + r.stdout) and "--oversubscribe" in (r.stderr + r.stdout)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--oversubscribe"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    out = r.stderr + r.stdout
+    assert r.returncode != 0 and out.count("needs a GPU") >= 2, out[-2000:]       # both ranks ran bench.py's main()
+    assert "{\"metric\"" not in r.stdout
+
+
 def test_bench_host_helpers():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec)

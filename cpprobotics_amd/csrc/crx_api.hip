@@ -1306,6 +1306,55 @@ int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream
   return CRX_OK;
 }
 
+// Probes of the device's double atan2(y, 1.0) (crx_datan2.h).  tests/test_datan2.py compares the bits with the host libm's:
+// samples through crx_x_datan2_dev, all 2^32 float curvatures through the block checksums of crx_x_datan2_sweep_dev.
+namespace crx {
+__global__ void __launch_bounds__(256) datan2_probe_kernel(int n, const double* __restrict__ y, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = datan2_one_(y[i]);
+}
+__global__ void __launch_bounds__(256) datan2_sweep_kernel(double L, unsigned long long* __restrict__ sums, unsigned long long* __restrict__ ocml_diff,
+                                                           unsigned* __restrict__ diff_k) {
+  const unsigned base = blockIdx.x << 20;
+  unsigned long long sum = 0, dd = 0, df = 0;
+  for (unsigned i = 0; i < 4096; ++i) {
+    const unsigned w = base + i * 256u + threadIdx.x;
+    const double y = L * (double)__uint_as_float(w);
+    const double a = datan2_one_(y);
+    sum += (a != a) ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(a);   // one pattern for every NaN
+    const double o = atan(y);                                                                 // OCML's: what rounds 1-3 evaluated here
+    if (!(o != o && a != a)) {
+      dd += __double_as_longlong(o) != __double_as_longlong(a);
+      const bool fd = __float_as_uint((float)o) != __float_as_uint((float)a);
+      df += fd;
+      if (fd && diff_k) { const unsigned long long slot = atomicAdd(&ocml_diff[2], 1ull); if (slot < 64) diff_k[slot] = w; }
+    }
+  }
+  atomicAdd(&sums[blockIdx.x], sum);
+  if (ocml_diff) { if (dd) atomicAdd(&ocml_diff[0], dd); if (df) atomicAdd(&ocml_diff[1], df); }
+}
+}  // namespace crx
+int crx_x_datan2_dev(int n, const double* y, double* out, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || (n > 0 && (!y || !out))) return fail(CRX_ERR_INVALID, "datan2: bad arguments");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::datan2_probe_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, y, out);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream) {
+  CRX_TRACE();
+  if (!sums || (diff_k && !ocml_diff)) return fail(CRX_ERR_INVALID, "datan2_sweep: bad arguments");
+  if (int rc = check_device()) return rc;
+  CRX_HIP(hipMemsetAsync(sums, 0, 4096 * sizeof(unsigned long long), (hipStream_t)stream));
+  if (ocml_diff) CRX_HIP(hipMemsetAsync(ocml_diff, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+  if (diff_k) CRX_HIP(hipMemsetAsync(diff_k, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
+  hipLaunchKernelGGL(crx::datan2_sweep_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, L, sums, ocml_diff, diff_k);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
 int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* coef, int nx, const float* goal_xy,
                              const float* ob, int nob, const crx_frenet_config* cfg, float* hist, int* ticks_done,
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,

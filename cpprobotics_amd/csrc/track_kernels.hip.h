@@ -14,9 +14,9 @@
 // float, double where a `#define`d double literal (DT, L, WB, M_PI, MAX_STEER ...) promotes the expression,
 // one rounding back to float at each assignment to a float variable, no fma contraction; cosf/sinf =
 // crx_trig.h, atan2f/tanf = crx_fdlibm.h (both bit-identical to glibc), fmod is exact by definition.
-// One deviation is possible and documented: the feed-forward term atan2(L*k, 1.0) is a DOUBLE atan2 in the
-// reference (glibc, correctly rounded); the device evaluates OCML's double atan (<= 2 ulp) and rounds to
-// float, so that float can differ from the reference's in about one of 10^8 curvature values.
+// The feed-forward term atan2(L*k, 1.0) is a DOUBLE atan2 in the reference: crx_datan2.h restates glibc 2.35's (FMA build)
+// for x = 1.0 — equal to the host libm on all 2^32 float curvatures (rounds 1-3 used OCML's atan there, which rounds to a
+// different float for a handful of curvature values; profiles/r04/datan2.txt has the count).
 //
 // Layout: agent state [n][4] = (x, y, yaw, v) — the reference's `struct State` (include/motion_model.h:31-42);
 // the course is five shared read-only arrays of ncourse floats (cx, cy, cyaw, ck, sp).  One agent per lane.
@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "crx_fdlibm.h"
+#include "crx_datan2.h"
 #include "crx_trig.h"
 #include "dare_kernels.hip.h"
 #include "mpc_kernels.hip.h"
@@ -158,7 +159,7 @@ __device__ __forceinline__ LqrCtl lqr_steering_control_dev(float sx, float sy, f
     u0 = (t0 + t2) + (t1 + t3);
     out.ai = 0.0f;
   }
-  const float ff = (float)atan(L * (double)k);    // std::atan2((L*k), (double)1.0)
+  const float ff = (float)datan2_one_(L * (double)k);    // std::atan2((L*k), (double)1.0)
   const float fb = (float)yaw_p2p(u0);
   out.delta = ff + fb;
   pe = e;
@@ -357,7 +358,7 @@ __device__ __forceinline__ LqrCtl lqr_control_from_gain(const float* K, float e,
     u0 = (t0 + t2) + (t1 + t3);
     out.ai = 0.0f;
   }
-  const float ff = (float)atan(L * (double)k);
+  const float ff = (float)datan2_one_(L * (double)k);
   const float fb = (float)yaw_p2p(u0);
   out.delta = ff + fb;
   return out;

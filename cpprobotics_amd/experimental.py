@@ -13,6 +13,8 @@ _X_SIGNATURES = {
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
                                              C.POINTER(L.LoopParams), _P, _P, _P, _I]),
     "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
+    "crx_x_datan2_dev": (_I, [_I, _P, _P, _P]),
+    "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
@@ -160,6 +162,30 @@ def dsincos(x):
     s, c = torch.empty_like(x), torch.empty_like(x)
     L.check(xlib().crx_x_dsincos_dev(n, L.ptr(x), L.ptr(s), L.ptr(c), L.stream_ptr()), "crx_x_dsincos_dev")
     return s, c
+
+
+def datan2_one(y):
+    """atan2(y, 1.0) of a float64 tensor as the tracking kernels evaluate it on the device (csrc/crx_datan2.h)."""
+    import torch
+    L.require_cuda(y, dtypes=(torch.float64,))
+    n = y.numel()
+    L.expect("y", y, "d", n)
+    out = torch.empty_like(y)
+    L.check(xlib().crx_x_datan2_dev(n, L.ptr(y), L.ptr(out), L.stream_ptr()), "crx_x_datan2_dev")
+    return out
+
+
+def datan2_sweep(wheelbase=0.5, device="cuda"):
+    """All 2^32 float curvatures k, y = wheelbase * (double)k: (sums, ocml_diff, diff_k) — 4096 block checksums of the device's
+    atan2(y, 1.0) bit patterns (int64 tensor, wrap-around sums), the number of curvatures on which OCML's atan differs from it
+    (in double, after rounding to float) and up to 64 float32 curvatures of the second kind."""
+    import torch
+    sums = torch.zeros((4096,), dtype=torch.int64, device=device)
+    diff = torch.zeros((3,), dtype=torch.int64, device=device)
+    ks = torch.zeros((64,), dtype=torch.int32, device=device)
+    L.check(xlib().crx_x_datan2_sweep_dev(float(wheelbase), L.ptr(sums), L.ptr(diff), L.ptr(ks), L.stream_ptr()), "crx_x_datan2_sweep_dev")
+    m = int(min(64, diff[1].item()))
+    return sums, diff[:2], ks[:m].view(torch.float32)
 
 
 def closed_loop_prediction_lanes(state, course, goal, lanes_per_agent, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L_wheelbase=0.5, eps=0.01,

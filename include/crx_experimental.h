@@ -36,6 +36,18 @@ int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_cour
  * planner's frenet_optimal_trajectory.cpp:111-112): s[i] = sin(x[i]), c[i] = cos(x[i]) for |x[i]| < 105414336 (NaN beyond). */
 int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream);
 
+/* Probes of the device's double-precision atan2(y, 1.0) (csrc/crx_datan2.h: glibc 2.35's atan2() restated for the feed-forward
+ * term of lqr_steering_control, src/lqr_speed_steer_control.cpp:143, src/lqr_steer_control.cpp:126).
+ * crx_x_datan2_dev: out[i] = atan2(y[i], 1.0).
+ * crx_x_datan2_sweep_dev: ALL 2^32 float bit patterns k, y = L * (double)k.  sums[j], j = 0..4095 (device, 4096 x u64) = the sum
+ * mod 2^64 of the result's bit patterns over the patterns [j << 20, (j + 1) << 20) — an order-independent checksum that
+ * tests/tools/datan2_exhaustive.cpp forms from the host libm's atan2 (mode `sums`); ocml_diff (device, 3 x u64, may be NULL):
+ * [0] = curvatures whose OCML device atan(y) differs from it in double, [1] = [2] = those whose rounded FLOAT differs (what rounds
+ * 1-3 shipped); diff_k (device, 64 x u32, may be NULL; needs ocml_diff): the bit patterns of up to 64 such curvatures — the
+ * adversarial inputs of tests/test_track_gpu.py. */
+int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
+int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
+
 /* crx_ekf_run_batch_dev through the 64-bit-address instantiations of the fused kernel whatever n is (the product entry point
  * switches to them above 4 M vehicles). */
 int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,

@@ -114,6 +114,34 @@ def test_lqr_steering_control_bit_exact(crx, oracle_mod, lqr_setup, dim, n):
     assert bit_equal(ctl.cpu().numpy(), co)
 
 
+@pytest.mark.parametrize("dim", [5, 4])
+def test_lqr_steering_control_adversarial_curvatures(crx, oracle_mod, dim):
+    """The feed-forward term `(float)atan2(L*k, 1.0)` on the curvatures where a merely accurate double atan is not enough: the
+    values k on which OCML's device atan rounds to a different float than glibc's atan2 (found by the exhaustive device sweep,
+    crx_x_datan2_sweep_dev), curvatures at every branch boundary of glibc's algorithm (|L k| = 1/16, 1, 16, 2^-57, 2^57), the
+    table's own abscissae, huge / tiny / denormal / zero curvatures of both signs.  Equal bits with the oracle (host libm)."""
+    from cpprobotics_amd.experimental import datan2_sweep
+    _, diff, ks = datan2_sweep(0.5)
+    rng = np.random.default_rng(17 + dim)
+    edge = np.float32([0.0, -0.0, 0.125, 2.0, 32.0, 2.0 ** -56, 2.0 ** 58, 1e-45, 1e-38, 3e38, 0.12500001, 0.124999993, 1.9999999, 2.0000002,
+                       31.999998, 32.000004, 0.2539, 0.1269, 1.998, 0.5, 1.0, 3.0, 7.0, 15.9, 100.0, 1e6])
+    ck = np.concatenate([ks.cpu().numpy(), edge, -edge, rng.uniform(-4, 4, 400).astype(np.float32),
+                         (rng.uniform(-1, 1, 400) * np.exp2(rng.integers(-40, 40, 400))).astype(np.float32)]).astype(np.float32)
+    nc = ck.size
+    t = np.linspace(0.0, 6.0, nc)
+    cx = (20.0 * np.cos(t)).astype(np.float32); cy = (15.0 * np.sin(1.3 * t)).astype(np.float32)
+    course = (cx, cy, rng.uniform(-3, 3, nc).astype(np.float32), ck, np.full(nc, 2.0, np.float32))
+    st = np.stack([cx, cy, rng.uniform(-3, 3, nc), rng.uniform(0.2, 3, nc)], axis=1).astype(np.float32)    # agent j sits on course point j
+    pe = rng.normal(0, 0.3, nc).astype(np.float32); pth = rng.normal(0, 0.2, nc).astype(np.float32)
+    ind0 = np.zeros(nc, np.int32)
+    co, io, peo, ptho = oracle_mod.lqr_steering_control(st, course, pe, pth, dim=dim, ind=ind0)
+    assert len(set(io.tolist())) > nc * 0.9                      # the agents really read (nearly) every curvature of the list
+    ped, pthd, indd = _t(pe), _t(pth), _t(ind0)
+    ctl, ind = crx.lqr_steering_control(_t(st), crx.Course.from_numpy(course), ped, pthd, dim=dim, ind=indd)
+    assert np.array_equal(ind.cpu().numpy(), io) and bit_equal(ctl.cpu().numpy(), co)
+    print(f"adversarial list: {ks.numel()} curvatures on which OCML's atan rounds differently ({int(diff[1])} of 2^32 in all)")
+
+
 @pytest.mark.parametrize("mpc", [False, True])
 def test_update_bit_exact(crx, oracle_mod, mpc):
     rng = np.random.default_rng(7)

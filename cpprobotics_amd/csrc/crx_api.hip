@@ -421,21 +421,50 @@ int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const fl
 // ---------------------------------------------------------------------------------------------
 // DARE / dlqr
 // ---------------------------------------------------------------------------------------------
-int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
-                       float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
-  CRX_TRACE();
+// structured: 1 = detect the pattern lqr_steering_control builds (per agent) and serve those agents by the structured kernels, the
+// rest by the dense kernel (two launches, no workspace, no synchronisation); 0 = the dense kernel for everybody.
+static int dare_batch_launch(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
+                             float eps, int maxiter, float* X, float* K, int* iters, void* stream, int structured) {
   if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
+  hipStream_t s = (hipStream_t)stream;
   const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
-  if (dim == 5)
-    hipLaunchKernelGGL((crx::dare_dense_kernel<5>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
-  else
-    hipLaunchKernelGGL((crx::dare_dense_kernel<4>), grid, block, 0, (hipStream_t)stream, n, A, B, Q, R, eps, maxiter, X, K, iters);
+  if (structured) {
+    const crx::DareFromMats src{A, B, Q, R};
+    if (n <= kDareQuadMaxAgents) {
+      const dim3 qgrid(blocks_for(4 * (size_t)n, 256)), qblock(256);
+      if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<5, crx::DareFromMats>), qgrid, qblock, 0, s, n, src, eps, maxiter, X, K, iters);
+      else hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4, crx::DareFromMats>), qgrid, qblock, 0, s, n, src, eps, maxiter, X, K, iters);
+    } else if (n <= kDareChainMaxAgents) {
+      if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_kernel<5, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
+      else hipLaunchKernelGGL((crx::dare_from_v_kernel<4, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
+    } else {
+      if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_masked_kernel<5, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
+      else hipLaunchKernelGGL((crx::dare_from_v_masked_kernel<4, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
+    }
+    CRX_HIP(hipGetLastError());
+    if (dim == 5) hipLaunchKernelGGL((crx::dare_dense_kernel<5, true>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
+    else hipLaunchKernelGGL((crx::dare_dense_kernel<4, true>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
+  } else {
+    if (dim == 5) hipLaunchKernelGGL((crx::dare_dense_kernel<5, false>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
+    else hipLaunchKernelGGL((crx::dare_dense_kernel<4, false>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
+  }
   CRX_HIP(hipGetLastError());
   return CRX_OK;
+}
+
+int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
+                       float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
+  CRX_TRACE();
+  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 1);
+}
+int crx_x_dare_batch_dense_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
+                               float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
+  CRX_TRACE();
+  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 0);
 }
 
 // lanes_per_agent: 1 = dare_from_v_kernel, 4 = dare_from_v_quad_kernel, 0 = chosen by batch size.
@@ -452,19 +481,20 @@ static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_para
   // Four lanes per agent shorten the launch while the batch leaves SIMDs without a wave of their own; in the throughput
   // regime the one-lane kernel executes fewer instructions per agent (profiles/r03/dare_lanes_ab.txt).
   if (lanes_per_agent == 0) lanes_per_agent = (n <= kDareQuadMaxAgents) ? 4 : 1;
+  const crx::DareFromV src{v, (float)p.dt, p.L};
   if (lanes_per_agent == 4) {
     const dim3 grid(blocks_for(4 * (size_t)n, 256)), block(256);
     if (dim == 5)
-      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<5>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<5, crx::DareFromV>), grid, block, 0, (hipStream_t)stream, n, src, p.eps, p.maxiter, X, K, iters);
     else
-      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters);
+      hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4, crx::DareFromV>), grid, block, 0, (hipStream_t)stream, n, src, p.eps, p.maxiter, X, K, iters);
   } else {
     const dim3 grid(blocks_for(n, 64)), block(64);
     // up to ~1.5 waves per SIMD the launch is a latency chain: nobody masked off, two evaluations per branch (89 VGPRs); beyond,
     // the masked loop at eight waves per SIMD (60 VGPRs)
     const bool chain = n <= kDareChainMaxAgents;
 #define CRX_LAUNCH_DV(KERNEL, DIM) \
-    hipLaunchKernelGGL((crx::KERNEL<DIM>), grid, block, 0, (hipStream_t)stream, n, v, (float)p.dt, p.L, p.eps, p.maxiter, X, K, iters)
+    hipLaunchKernelGGL((crx::KERNEL<DIM, crx::DareFromV>), grid, block, 0, (hipStream_t)stream, n, src, p.eps, p.maxiter, X, K, iters)
     if (dim == 5) { if (chain) CRX_LAUNCH_DV(dare_from_v_kernel, 5); else CRX_LAUNCH_DV(dare_from_v_masked_kernel, 5); }
     else { if (chain) CRX_LAUNCH_DV(dare_from_v_kernel, 4); else CRX_LAUNCH_DV(dare_from_v_masked_kernel, 4); }
 #undef CRX_LAUNCH_DV

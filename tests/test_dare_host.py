@@ -31,6 +31,18 @@ def host(tmp_path_factory):
                 C.c_float(eps), C.c_int(maxiter), vp(X), vp(it))
         assert rc == 0
         return X, it
+
+    def run_params(kind, dim, dt, v, bv, bd, eps=0.01, maxiter=150):
+        n = len(v)
+        X = np.empty((n, dim * dim), dtype=np.float32)
+        it = np.empty(n, dtype=np.int32)
+        vp = lambda a: np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.c_void_p)
+        keep = [np.ascontiguousarray(a, dtype=np.float32) for a in (v, dt, bv, bd)]
+        rc = getattr(lib, f"dare_{kind}_run_params")(C.c_int(n), C.c_int(dim), *[k.ctypes.data_as(C.c_void_p) for k in keep], C.c_float(eps),
+                                                     C.c_int(maxiter), X.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        return X, it
+    run.params = run_params
     return run
 
 
@@ -62,6 +74,37 @@ def test_structured_iteration_other_parameters(host, oracle_mod, kind, dim):
         assert np.array_equal(it[ok], ito[ok])
         assert bit_equal(X[ok], Xo[ok])
         assert not np.isfinite(X[~ok]).all(axis=1).any()      # non-finite in the reference -> non-finite here
+
+
+@pytest.mark.parametrize("kind", ["lane", "quad"])
+@pytest.mark.parametrize("dim", [5, 4])
+def test_structured_iteration_over_the_accepted_box(host, oracle_mod, kind, dim):
+    """crx_dare_batch serves every agent whose dense arguments carry lqr_steering_control's pattern by the structured iteration
+    (DareFromMats, csrc/dare_kernels.hip.h) when its four free entries lie in the box |v| <= 100, 1e-3 <= |dt|, |bd| <= 1,
+    |bv| <= 1e3, each chosen per agent: over that box (log-uniform samples, both signs, its corners) the structured iteration is the
+    dense Eigen-order evaluation bit for bit, iteration counts included, and every iterate stays finite (largest entry < 1e11)."""
+    import itertools
+    rng = np.random.default_rng(100 + dim)
+    n = 6000
+    lu = lambda lo, hi, k=n: (np.exp(rng.uniform(np.log(lo), np.log(hi), k)) * rng.choice([-1.0, 1.0], k)).astype(np.float32)
+    v, dt, bv, bd = lu(1e-6, 100.0), lu(1e-3, 1.0), lu(1e-6, 1e3), lu(1e-3, 1.0)
+    corners = np.array(list(itertools.product([100.0, -100.0, 1e-6, 0.0], [1e-3, 1.0, -1.0], [1e3, -1e3, 1e-6, 0.0], [1e-3, 1.0])), dtype=np.float32)
+    v = np.concatenate([v, corners[:, 0]]); dt = np.concatenate([dt, corners[:, 1]])
+    bv = np.concatenate([bv, corners[:, 2]]); bd = np.concatenate([bd, corners[:, 3]])
+    n = len(v)
+    m = 2 if dim == 5 else 1
+    A = np.zeros((n, dim * dim), np.float32); B = np.zeros((n, dim * m), np.float32)
+    A[:, 0] = 1; A[:, 0 + dim * 1] = dt; A[:, 1 + dim * 2] = v; A[:, 2 + dim * 2] = 1; A[:, 2 + dim * 3] = dt
+    B[:, 3] = bv
+    if dim == 5:
+        A[:, 24] = 1; B[:, 4 + 5] = bd
+    Q = np.tile(np.eye(dim, dtype=np.float32).reshape(-1), (n, 1)); R = np.tile(np.eye(m, dtype=np.float32).reshape(-1), (n, 1))
+    for maxiter in (150, 1, 2, 3, 5, 17):                  # every iterate, not only the last, must agree and be finite
+        Xo, _, ito = oracle_mod.dare(A, B, Q, R, maxiter=maxiter)
+        assert np.isfinite(Xo).all() and np.abs(Xo).max() < 1e11
+        X, it = host.params(kind, dim, dt, v, bv, bd, maxiter=maxiter)
+        assert np.array_equal(it, ito)
+        assert bit_equal(X, Xo)
 
 
 def test_block_structure_of_the_reference_iterates(oracle_mod):

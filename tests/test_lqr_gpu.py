@@ -75,6 +75,91 @@ def test_dare_dense_matches_structured_and_oracle(crx, oracle_mod, dim):
     assert bit_equal(X.cpu().numpy(), Xo) and bit_equal(K.cpu().numpy(), Ko)
     K2, X2, it2 = crx.dlqr_from_v(_t(v), dim=dim)
     assert bit_equal(X2.cpu().numpy(), X.cpu().numpy()) and bit_equal(K2.cpu().numpy(), K.cpu().numpy())
+    # since round 4 solve_DARE() recognises these matrices and serves them by the structured kernels: the dense kernel itself on the
+    # same matrices, forced
+    from cpprobotics_amd.experimental import dare_dense
+    X3, K3, it3 = dare_dense(_t(A), _t(B), _t(Q), _t(R))
+    assert np.array_equal(it3.cpu().numpy(), ito) and bit_equal(X3.cpu().numpy(), Xo) and bit_equal(K3.cpu().numpy(), Ko)
+
+
+def _pattern_mats(dim, dt, v, bv, bd):
+    """A, B, Q, R with lqr_steering_control's zero pattern and per-agent free entries (column-major rows of length dim*dim ...)."""
+    n = len(v)
+    m = 2 if dim == 5 else 1
+    A = np.zeros((n, dim * dim), np.float32); B = np.zeros((n, dim * m), np.float32)
+    A[:, 0] = 1; A[:, 0 + dim * 1] = dt; A[:, 1 + dim * 2] = v; A[:, 2 + dim * 2] = 1; A[:, 2 + dim * 3] = dt
+    B[:, 3] = bv
+    if dim == 5:
+        A[:, 24] = 1; B[:, 4 + 5] = bd
+    Q = np.tile(np.eye(dim, dtype=np.float32).reshape(-1), (n, 1)); R = np.tile(np.eye(m, dtype=np.float32).reshape(-1), (n, 1))
+    return A, B, Q, R
+
+
+@pytest.mark.parametrize("dim", [5, 4])
+@pytest.mark.parametrize("n", [1, 1000, 16384, 40000, 100001])
+def test_dare_batch_recognises_the_reference_pattern(crx, oracle_mod, dim, n):
+    """crx_dare_batch (the solve_DARE(A,B,Q,R) signature) on matrices that carry lqr_steering_control's pattern, the four free
+    entries different for every agent and anywhere in the accepted box: served by the structured kernels (a DPP quad per agent up to
+    32,768 agents, one lane per agent above: all three variants here) with the bits and iteration counts of the dense Eigen-order
+    evaluation (oracle), and of the dense kernel forced on the same matrices."""
+    from cpprobotics_amd.experimental import dare_dense
+    rng = np.random.default_rng(n + dim)
+    lu = lambda lo, hi: (np.exp(rng.uniform(np.log(lo), np.log(hi), n)) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+    v, dt, bv, bd = lu(1e-4, 100.0), lu(1e-3, 1.0), lu(1e-4, 1e3), lu(1e-3, 1.0)
+    k = min(n, 64)
+    v[:k] = lqr_speeds(k, seed=5); dt[:k] = np.float32(0.1); bd[:k] = np.float32(0.1); bv[:k] = (v[:k].astype(np.float64) / 0.5).astype(np.float32)
+    v[0] = 0.0; bv[0] = 0.0                                       # the reference's stand-still case: the iteration cap
+    A, B, Q, R = _pattern_mats(dim, dt, v, bv, bd)
+    maxiter = 150 if n <= 16384 else 24
+    Xo, Ko, ito = oracle_mod.dare(A, B, Q, R, maxiter=maxiter)
+    assert np.isfinite(Xo).all()
+    X, it = crx.solve_DARE(_t(A), _t(B), _t(Q), _t(R), maxiter=maxiter)
+    K = crx.dlqr(_t(A), _t(B), _t(Q), _t(R), maxiter=maxiter)
+    assert np.array_equal(it.cpu().numpy(), ito)
+    assert bit_equal(X.cpu().numpy(), Xo) and bit_equal(K.cpu().numpy(), Ko)
+    if n <= 16384:
+        X3, K3, it3 = dare_dense(_t(A), _t(B), _t(Q), _t(R), maxiter=maxiter)
+        assert np.array_equal(it3.cpu().numpy(), ito) and bit_equal(X3.cpu().numpy(), Xo) and bit_equal(K3.cpu().numpy(), Ko)
+
+
+@pytest.mark.parametrize("dim", [5, 4])
+def test_dare_batch_mixed_structured_and_dense_agents(crx, oracle_mod, dim):
+    """One batch with every kind of agent: the reference's pattern, the pattern spoilt in one entry (a -0.0f, a 1e-30, A(0,1) !=
+    A(2,3), Q or R off the identity by an ulp, a NaN), the pattern outside the accepted box (a vehicle at 500 m/s, dt = 1e-5), and
+    dense random matrices — interleaved within waves and quads.  The entry point's result is the dense kernel's (forced) on every
+    agent, bit for bit, iteration counts included, and the oracle's wherever that stays finite."""
+    from cpprobotics_amd.experimental import dare_dense
+    rng = np.random.default_rng(40 + dim)
+    n, m = 3000, (2 if dim == 5 else 1)
+    v = lqr_speeds(n, seed=9)
+    A, B, Q, R = oracle_mod.lqr_build(v, dim)
+    kind = rng.integers(0, 12, n)
+    kind[:8] = np.arange(8)
+    for a in range(n):
+        k = kind[a]
+        if k == 1: A[a, 1] = -0.0
+        elif k == 2: A[a, 3 + dim * 0] = 1e-30
+        elif k == 3: A[a, 2 + dim * 3] = np.nextafter(A[a, 0 + dim * 1], np.float32(1))
+        elif k == 4: Q[a, 1 + dim * 1] = np.nextafter(np.float32(1), np.float32(2))
+        elif k == 5: R[a, 0] = np.nextafter(np.float32(1), np.float32(0))
+        elif k == 6: A[a, 1 + dim * 2] = 500.0
+        elif k == 7: A[a, 0 + dim * 1] = A[a, 2 + dim * 3] = 1e-5
+        elif k == 8: B[a, 3] = np.nan
+        elif k == 9:
+            A[a] = (np.eye(dim) * 0.9 + 0.15 * rng.standard_normal((dim, dim))).astype(np.float32).T.reshape(-1)
+            B[a] = rng.standard_normal(dim * m).astype(np.float32)
+        elif k == 10: Q[a, 2] = 0.25; Q[a, 2 * dim] = 0.25
+    Xo, Ko, ito = oracle_mod.dare(A, B, Q, R)
+    X, it = crx.solve_DARE(_t(A), _t(B), _t(Q), _t(R))
+    K = crx.dlqr(_t(A), _t(B), _t(Q), _t(R))
+    X3, K3, it3 = dare_dense(_t(A), _t(B), _t(Q), _t(R))
+    X, K, it, X3, K3, it3 = (t.cpu().numpy() for t in (X, K, it, X3, K3, it3))
+    assert np.array_equal(it, it3) and np.array_equal(it, ito)
+    ok = np.isfinite(Xo).all(axis=1) & np.isfinite(Ko).all(axis=1)
+    assert ok.sum() > n // 2 and (~ok).sum() > 0
+    assert bit_equal(X[ok], Xo[ok]) and bit_equal(K[ok], Ko[ok]) and bit_equal(X3[ok], Xo[ok])
+    # non-finite agents took the dense kernel in both calls: identical bit patterns (NaN payloads included)
+    assert np.array_equal(X[~ok].view(np.uint32), X3[~ok].view(np.uint32)) and np.array_equal(K[~ok].view(np.uint32), K3[~ok].view(np.uint32))
 
 
 @pytest.mark.parametrize("dim", [5, 4])

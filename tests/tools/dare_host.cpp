@@ -8,10 +8,13 @@
 
 using namespace crx;
 
-extern "C" int dare_lane_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
-  const float dt = (float)dt_d;
+// per-agent free entries (A(0,1) = A(2,3) = dt, A(1,2) = v, B(3,0) = bv, B(4,1) = bd): what crx_dare_batch's structure detection hands to
+// the same iteration (DareFromMats, csrc/dare_kernels.hip.h); dts / bvs / bds NULL = built from the speed as dare_*_run does
+static int lane_core(int n, int dim, const float* vs, const float* dts, const float* bvs, const float* bds, double dt_d, double L, float eps,
+                     int maxiter, float* Xout, int* iters) {
   for (int a = 0; a < n; ++a) {
-    const float v = vs[a], bv = (float)((double)v / L), bd = dt;
+    const float dt = dts ? dts[a] : (float)dt_d;
+    const float v = vs[a], bv = bvs ? bvs[a] : (float)((double)v / L), bd = bds ? bds[a] : dt;
     Row4 X[4], Y[4];
     float x44 = 1.0f, y44 = 1.0f;
     for (int i = 0; i < 4; ++i) {
@@ -37,12 +40,21 @@ extern "C" int dare_lane_run(int n, int dim, const float* vs, double dt_d, doubl
   return 0;
 }
 
-extern "C" int dare_quad_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
-  const float dt = (float)dt_d;
+extern "C" int dare_lane_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
+  return lane_core(n, dim, vs, nullptr, nullptr, nullptr, dt_d, L, eps, maxiter, Xout, iters);
+}
+extern "C" int dare_lane_run_params(int n, int dim, const float* vs, const float* dts, const float* bvs, const float* bds, float eps, int maxiter,
+                                    float* Xout, int* iters) {
+  return lane_core(n, dim, vs, dts, bvs, bds, 0.0, 1.0, eps, maxiter, Xout, iters);
+}
+
+static int quad_core(int n, int dim, const float* vs, const float* dts, const float* bvs, const float* bds, double dt_d, double L, float eps,
+                     int maxiter, float* Xout, int* iters) {
   for (int a = 0; a < n; ++a) {
+    const float dt = dts ? dts[a] : (float)dt_d;
     const float v = vs[a];
     QuadLane<Quad4f, Quad4u> c;
-    c.dt = dt; c.v = v; c.bd = dt; c.bv = (float)((double)v / L);
+    c.dt = dt; c.v = v; c.bd = bds ? bds[a] : dt; c.bv = bvs ? bvs[a] : (float)((double)v / L);
     c.a = Quad4f(1.0f, dt, v, dt);
     c.m2 = Quad4u{{0u, 0u, 0xffffffffu, 0u}};
     for (int j = 0; j < 4; ++j) { c.q[j] = Quad4f(0.0f); c.q[j].l[j] = 1.0f; }
@@ -67,4 +79,11 @@ extern "C" int dare_quad_run(int n, int dim, const float* vs, double dt_d, doubl
     iters[a] = it;
   }
   return 0;
+}
+extern "C" int dare_quad_run(int n, int dim, const float* vs, double dt_d, double L, float eps, int maxiter, float* Xout, int* iters) {
+  return quad_core(n, dim, vs, nullptr, nullptr, nullptr, dt_d, L, eps, maxiter, Xout, iters);
+}
+extern "C" int dare_quad_run_params(int n, int dim, const float* vs, const float* dts, const float* bvs, const float* bds, float eps, int maxiter,
+                                    float* Xout, int* iters) {
+  return quad_core(n, dim, vs, dts, bvs, bds, 0.0, 1.0, eps, maxiter, Xout, iters);
 }

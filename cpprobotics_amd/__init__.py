@@ -18,6 +18,7 @@ from .mpc import mpc_n_vars, mpc_solve  # noqa: F401
 from .dwa import dwa_control, dwa_default_config, dwa_run  # noqa: F401
 from .frenet import FrenetCourse, frenet_default_config, frenet_num_paths, frenet_optimal_planning, frenet_run  # noqa: F401
 from .pf import pf_default_params, pf_run  # noqa: F401
+from . import host  # noqa: F401  (host-pointer entry points on numpy arrays, device selection / device set)
 from .track import (  # noqa: F401
     Course, course_from_waypoints, calc_speed_profile, calc_nearest_index, calc_nearest_index_window, calc_ref_trajectory, closed_loop_prediction,
     lqr_steering_control, mpc_simulation, smooth_yaw, update, vehicle_params,

@@ -65,6 +65,13 @@ _SIGNATURES = {
     "crx_init": (_I, []),
     "crx_shutdown": (_I, []),
     "crx_device_count": (_I, []),
+    "crx_set_device": (_I, [_I]),
+    "crx_get_device": (_I, []),
+    "crx_set_devices": (_I, [_P, _I, _I]),
+    "crx_get_devices": (_I, [_P, _I]),
+    "crx_host_alloc": (_P, [C.c_size_t]),
+    "crx_host_free": (None, [_P]),
+    "crx_release_workspace": (_I, []),
     "crx_last_error": (C.c_char_p, []),
     "crx_ekf_default_params": (None, [C.POINTER(EkfParams)]),
     "crx_lqr_default_params": (None, [C.POINTER(LqrParams)]),

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 
+#include "crx_host.h"
 #include "../../include/crx.h"
 #include "../../include/crx_experimental.h"
 #include "dare_kernels.hip.h"
@@ -100,19 +101,194 @@ crx::EkfConsts make_consts(const float* Q, const float* R, const crx_ekf_params*
   return k;
 }
 
-// RAII device scratch for the host-pointer entry points.
-struct DevBuf {
-  void* p = nullptr;
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  ~DevBuf() { if (p) (void)hipFree(p); }
-  template <class T> T* as() { return static_cast<T*>(p); }
+// ---- host-pointer calls (crx_host.h: contexts, workspaces, copy pool, device set) ---------------------------------------------
+// the context of the calling thread's current device, locked for the duration of one host-pointer call
+int ctx_open(crxh::DeviceCtx** out, std::unique_lock<std::mutex>& lock) {
+  if (int rc = check_device()) return rc;
+  int dev = 0;
+  CRX_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= crxh::kMaxDevices) return fail(CRX_ERR_INVALID, "device ordinal out of range");
+  crxh::DeviceCtx& c = crxh::ctx_table()[dev];
+  lock = std::unique_lock<std::mutex>(c.mu);
+  const hipError_t e = c.init(dev);
+  if (e != hipSuccess) return hip_fail(e, "crx host context (streams / events)");
+  *out = &c;
+  return CRX_OK;
+}
+
+// One host-pointer call on the current device: register the arguments, commit() (places them — zero-copy pinned block or device
+// workspace — and moves the inputs), run the `_dev` entry point on stream(), finish() (moves the outputs, synchronises).
+class HostCall {
+ public:
+  // an argument: `rows` rows of `row_bytes`; on the host they lie `pitch` bytes apart (a shard's columns of a time-major array),
+  // in the workspace densely.  src: copied in (NULL: not); dst: copied back (NULL: not); zero: cleared when there is no src.
+  struct Arg { const char* src; char* dst; size_t row_bytes, rows, pitch; bool zero; char* d; };
+
+  int open() { return ctx_open(&c_, lock_); }
+  // kernels that come back to their inputs tick after tick (the closed loops read the course from global memory every tick) must
+  // not run out of host memory across PCIe
+  void forbid_zero_copy() { allow_zc_ = false; }
+  int add(const void* src, void* dst, size_t bytes, bool zero = false) { return add2d(src, dst, bytes, 1, bytes, zero); }
+  int add2d(const void* src, void* dst, size_t row_bytes, size_t rows, size_t pitch, bool zero = false) {
+    args_.push_back(Arg{static_cast<const char*>(src), static_cast<char*>(dst), row_bytes, rows, pitch, zero, nullptr});
+    return (int)args_.size() - 1;
+  }
+  template <class T> T* p(int i) { return reinterpret_cast<T*>(args_[i].d); }
+  hipStream_t stream() const { return c_->s_cmp; }
+  bool zero_copy() const { return zc_; }
+
+  int commit() {
+    size_t total = 0, biggest_row = 0;
+    for (auto& a : args_) { total += crxh::align_up(a.row_bytes * a.rows); biggest_row = std::max(biggest_row, a.row_bytes); }
+    zc_ = allow_zc_ && total <= crxh::kZeroCopyBytes;
+    slot_ = std::max(crxh::kStageChunk, crxh::align_up(std::min<size_t>(biggest_row, 64u << 20)));
+    hipError_t e = zc_ ? c_->pws.reserve(total) : c_->dws.reserve(total);
+    if (e == hipSuccess && !zc_) e = c_->pws.reserve(2 * slot_);
+    if (e != hipSuccess) { hip_fail(e, zc_ ? "hipHostMalloc (pinned workspace)" : "hipMalloc (device workspace)"); return CRX_ERR_ALLOC; }
+    char* base = static_cast<char*>(zc_ ? c_->pws.p : c_->dws.p);
+    size_t off = 0;
+    for (auto& a : args_) { a.d = base + off; off += crxh::align_up(a.row_bytes * a.rows); }
+    for (auto& a : args_) {
+      const size_t bytes = a.row_bytes * a.rows;
+      if (!bytes) continue;
+      if (a.src) { if (int rc = copy_in(a)) return rc; }
+      else if (a.zero) {
+        if (zc_) std::memset(a.d, 0, bytes);
+        else CRX_HIP(hipMemsetAsync(a.d, 0, bytes, c_->s_cmp));
+      }
+    }
+    return CRX_OK;
+  }
+  int finish() {
+    if (zc_) {
+      CRX_HIP(hipStreamSynchronize(c_->s_cmp));
+      for (auto& a : args_)
+        if (a.dst) crxh::CopyPool::get().submit(crxh::CopyPool::Job{a.dst, a.d, a.row_bytes, a.rows, a.pitch, a.row_bytes}, nullptr);
+      return CRX_OK;
+    }
+    for (auto& a : args_)
+      if (a.dst && a.row_bytes * a.rows) { if (int rc = copy_out(a)) return rc; }
+    CRX_HIP(hipStreamSynchronize(c_->s_cmp));
+    return CRX_OK;
+  }
+
+ private:
+  crxh::DeviceCtx* c_ = nullptr;
+  std::unique_lock<std::mutex> lock_;
+  std::vector<Arg> args_;
+  bool zc_ = false, allow_zc_ = true;
+  size_t slot_ = crxh::kStageChunk;
+
+  // how a staged copy is cut: `rows == 1` along the bytes, otherwise along the rows
+  struct Cut { size_t chunks, unit_rows, unit_bytes; };
+  Cut cut(const Arg& a) const {
+    if (a.rows == 1) return Cut{(a.row_bytes + slot_ - 1) / slot_, 1, slot_};
+    const size_t rpc = std::max<size_t>(1, slot_ / a.row_bytes);
+    return Cut{(a.rows + rpc - 1) / rpc, rpc, a.row_bytes};
+  }
+  int copy_in(const Arg& a) {
+    const size_t bytes = a.row_bytes * a.rows;
+    if (zc_) {
+      crxh::CopyPool::Ticket t;
+      crxh::CopyPool::get().submit(crxh::CopyPool::Job{a.d, a.src, a.row_bytes, a.rows, a.row_bytes, a.pitch}, bytes >= (1u << 20) ? &t : nullptr);
+      crxh::CopyPool::get().wait(&t);
+      return CRX_OK;
+    }
+    const bool dense = a.rows == 1 || a.pitch == a.row_bytes;
+    if (dense && (bytes < (1u << 20) || crxh::is_pinned(a.src))) {      // small, or DMA straight from the caller's pinned memory
+      CRX_HIP(hipMemcpyAsync(a.d, a.src, bytes, hipMemcpyHostToDevice, c_->s_cmp));
+      return CRX_OK;
+    }
+    if (!dense && a.row_bytes <= (64u << 20) && crxh::is_pinned(a.src)) {
+      CRX_HIP(hipMemcpy2DAsync(a.d, a.row_bytes, a.src, a.pitch, a.row_bytes, a.rows, hipMemcpyHostToDevice, c_->s_cmp));
+      return CRX_OK;
+    }
+    // pageable: through the pinned ring; the copy threads fill slot k+1 while the DMA of slot k is in flight
+    char* pin = static_cast<char*>(c_->pws.p);
+    const Cut ct = cut(a);
+    for (size_t k = 0; k < ct.chunks; ++k) {
+      char* slot = pin + (k & 1) * slot_;
+      if (k >= 2) CRX_HIP(hipEventSynchronize(c_->ev_tmp[k & 1]));
+      size_t len, doff;
+      crxh::CopyPool::Ticket t;
+      if (a.rows == 1) {
+        doff = k * ct.unit_bytes; len = std::min(ct.unit_bytes, a.row_bytes - doff);
+        crxh::CopyPool::get().submit(crxh::CopyPool::Job{slot, a.src + doff, len, 1, len, len}, &t);
+      } else {
+        const size_t r0 = k * ct.unit_rows, nr = std::min(ct.unit_rows, a.rows - r0);
+        doff = r0 * a.row_bytes; len = nr * a.row_bytes;
+        crxh::CopyPool::get().submit(crxh::CopyPool::Job{slot, a.src + r0 * a.pitch, a.row_bytes, nr, a.row_bytes, a.pitch}, &t);
+      }
+      crxh::CopyPool::get().wait(&t);
+      CRX_HIP(hipMemcpyAsync(a.d + doff, slot, len, hipMemcpyHostToDevice, c_->s_cmp));
+      CRX_HIP(hipEventRecord(c_->ev_tmp[k & 1], c_->s_cmp));
+    }
+    return CRX_OK;
+  }
+  int copy_out(const Arg& a) {
+    const size_t bytes = a.row_bytes * a.rows;
+    const bool dense = a.rows == 1 || a.pitch == a.row_bytes;
+    if (dense && (bytes < (1u << 20) || crxh::is_pinned(a.dst))) {
+      CRX_HIP(hipMemcpyAsync(a.dst, a.d, bytes, hipMemcpyDeviceToHost, c_->s_cmp));
+      return CRX_OK;
+    }
+    if (!dense && a.row_bytes <= (64u << 20) && crxh::is_pinned(a.dst)) {
+      CRX_HIP(hipMemcpy2DAsync(a.dst, a.pitch, a.d, a.row_bytes, a.row_bytes, a.rows, hipMemcpyDeviceToHost, c_->s_cmp));
+      return CRX_OK;
+    }
+    // pageable: the DMA of slot k+1 runs while the copy threads drain slot k into the caller's array
+    char* pin = static_cast<char*>(c_->pws.p);
+    const Cut ct = cut(a);
+    auto piece = [&](size_t k, size_t& doff, size_t& len, size_t& r0, size_t& nr) {
+      if (a.rows == 1) { doff = k * ct.unit_bytes; len = std::min(ct.unit_bytes, a.row_bytes - doff); r0 = 0; nr = 1; }
+      else { r0 = k * ct.unit_rows; nr = std::min(ct.unit_rows, a.rows - r0); doff = r0 * a.row_bytes; len = nr * a.row_bytes; }
+    };
+    auto issue = [&](size_t k) -> hipError_t {
+      size_t doff, len, r0, nr; piece(k, doff, len, r0, nr);
+      hipError_t e = hipMemcpyAsync(pin + (k & 1) * slot_, a.d + doff, len, hipMemcpyDeviceToHost, c_->s_cmp);
+      if (e != hipSuccess) return e;
+      return hipEventRecord(c_->ev_tmp[k & 1], c_->s_cmp);
+    };
+    CRX_HIP(issue(0));
+    for (size_t k = 0; k < ct.chunks; ++k) {
+      if (k + 1 < ct.chunks) CRX_HIP(issue(k + 1));
+      CRX_HIP(hipEventSynchronize(c_->ev_tmp[k & 1]));
+      size_t doff, len, r0, nr; piece(k, doff, len, r0, nr);
+      crxh::CopyPool::Ticket t;
+      if (a.rows == 1) crxh::CopyPool::get().submit(crxh::CopyPool::Job{a.dst + doff, pin + (k & 1) * slot_, len, 1, len, len}, &t);
+      else crxh::CopyPool::get().submit(crxh::CopyPool::Job{a.dst + r0 * a.pitch, pin + (k & 1) * slot_, a.row_bytes, nr, a.pitch, a.row_bytes}, &t);
+      crxh::CopyPool::get().wait(&t);
+    }
+    return CRX_OK;
+  }
 };
 
-#define CRX_ALLOC(buf, bytes)                                               \
-  do {                                                                      \
-    hipError_t e__ = (buf).alloc(bytes);                                    \
-    if (e__ != hipSuccess) { hip_fail(e__, "hipMalloc"); return CRX_ERR_ALLOC; } \
-  } while (0)
+#define CRX_TRY(call) do { if (int rc__ = (call)) return rc__; } while (0)
+
+// Run fn(shard) for every shard of [0, n) over the device set (crx_set_devices): one host thread per shard, each on its device;
+// the first failure is reported.  With no device set: one shard on the calling thread's current device, no thread.
+template <class F>
+int run_sharded(int n, F&& fn) {
+  if (int rc = check_device()) return rc;
+  int cur = 0;
+  CRX_HIP(hipGetDevice(&cur));
+  const std::vector<crxh::Shard> sh = crxh::shards_for(n, cur);
+  if (sh.size() == 1 && sh[0].dev == cur) return fn(sh[0]);
+  std::vector<int> rcs(sh.size(), CRX_OK);
+  std::vector<std::string> errs(sh.size());
+  std::vector<std::thread> th;
+  for (size_t i = 0; i < sh.size(); ++i)
+    th.emplace_back([&, i] {
+      const hipError_t e = hipSetDevice(sh[i].dev);
+      if (e != hipSuccess) { rcs[i] = hip_fail(e, "hipSetDevice (shard)"); errs[i] = g_err; return; }
+      rcs[i] = fn(sh[i]);
+      if (rcs[i]) errs[i] = g_err;
+    });
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < sh.size(); ++i)
+    if (rcs[i]) { g_err = "shard " + std::to_string(i) + " (device " + std::to_string(sh[i].dev) + "): " + errs[i]; return rcs[i]; }
+  return CRX_OK;
+}
 
 }  // namespace
 
@@ -120,15 +296,33 @@ extern "C" {
 
 int crx_version(void) { return 400; }  // 0.4.0 (0.3.0 + device selection and sharded host-pointer entries, grow-only workspace, crx_mpc_closed_loop_flags_batch_dev)
 
-// The engine keeps no global state: crx_init only checks that a device is there and forces the HIP runtime + code object to
-// load now rather than in the first timed call; crx_shutdown drains the device.  Both are optional.
+// crx_init only checks that a device is there and forces the HIP runtime + code object to load now rather than in the first
+// timed call; crx_shutdown drains the devices and gives the host-pointer workspaces back.  Both are optional.  The only state the
+// engine keeps is on the host-pointer side (crx_host.h): per-device grow-only workspaces and the device set.
 int crx_init(void) {
   if (int rc = check_device()) return rc;
   CRX_HIP(hipFree(nullptr));
   return CRX_OK;
 }
+int crx_release_workspace(void) {
+  const int nd = crx_device_count();
+  int cur = 0;
+  if (nd == 0) return CRX_OK;
+  CRX_HIP(hipGetDevice(&cur));
+  for (int d = 0; d < nd && d < crxh::kMaxDevices; ++d) {
+    crxh::DeviceCtx& c = crxh::ctx_table()[d];
+    std::lock_guard<std::mutex> l(c.mu);
+    if (!c.dws.p && !c.pws.p) continue;
+    CRX_HIP(hipSetDevice(d));
+    CRX_HIP(hipDeviceSynchronize());
+    c.release_workspace();
+  }
+  CRX_HIP(hipSetDevice(cur));
+  return CRX_OK;
+}
 int crx_shutdown(void) {
   if (crx_device_count() == 0) return CRX_OK;
+  if (int rc = crx_release_workspace()) return rc;
   CRX_HIP(hipDeviceSynchronize());
   return CRX_OK;
 }
@@ -137,6 +331,62 @@ int crx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
+}
+
+// The device of the calling thread: what the `_dev` entry points launch on (their pointers and stream must belong to it) and what
+// a host-pointer call uses when no device set is installed.  Thin wrappers over hipSetDevice / hipGetDevice so that a C++ host
+// needs no HIP header for device selection.
+int crx_set_device(int device) {
+  if (int rc = check_device()) return rc;
+  if (device < 0 || device >= crx_device_count()) return fail(CRX_ERR_INVALID, "set_device: no such device");
+  CRX_HIP(hipSetDevice(device));
+  return CRX_OK;
+}
+int crx_get_device(void) {
+  int d = 0;
+  if (crx_device_count() == 0 || hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return d;
+}
+// The device set of the host-pointer BATCH entry points (process-wide): with ndev >= 1 they split [0, n) contiguously over
+// devices[0..ndev) — shard r on devices[r], the first n % G shards one agent longer, as few shards as keep min_agents_per_device
+// agents each — one host thread per shard, results straight into the caller's arrays.  ndev = 0 restores the default (the calling
+// thread's current device).  A device may be named more than once (its shards then run one after the other: a way to exercise
+// the sharding on a single GPU).  devices = NULL with ndev > 0 means devices 0 .. ndev-1.
+int crx_set_devices(const int* devices, int ndev, int min_agents_per_device) {
+  if (ndev < 0 || ndev > 1024) return fail(CRX_ERR_INVALID, "set_devices: bad device count");
+  std::vector<int> v;
+  if (ndev > 0) {
+    if (int rc = check_device()) return rc;
+    const int have = crx_device_count();
+    for (int i = 0; i < ndev; ++i) {
+      const int d = devices ? devices[i] : i;
+      if (d < 0 || d >= have || d >= crxh::kMaxDevices) return fail(CRX_ERR_INVALID, "set_devices: no such device");
+      v.push_back(d);
+    }
+  }
+  crxh::DeviceSet& s = crxh::device_set();
+  std::lock_guard<std::mutex> l(s.m);
+  s.devs = v;
+  s.min_agents = min_agents_per_device < 0 ? 0 : min_agents_per_device;
+  return CRX_OK;
+}
+int crx_get_devices(int* devices, int cap) {
+  crxh::DeviceSet& s = crxh::device_set();
+  std::lock_guard<std::mutex> l(s.m);
+  for (int i = 0; i < (int)s.devs.size() && i < cap && devices; ++i) devices[i] = s.devs[i];
+  return (int)s.devs.size();
+}
+// Pinned (page-locked, device-visible) host memory: arrays allocated here cross PCIe by DMA straight from / into the caller's
+// memory, without the staging copy pageable memory needs.
+void* crx_host_alloc(size_t bytes) {
+  if (check_device()) return nullptr;
+  void* p = nullptr;
+  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { hip_fail(e, "hipHostMalloc"); return nullptr; }
+  return p;
+}
+void crx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 const char* crx_last_error(void) { return g_err.c_str(); }
@@ -340,19 +590,23 @@ int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed
   return CRX_OK;
 }
 
-// ---- host-pointer variants (stage, launch, copy back, synchronise) ----------------------------
+// ---- host-pointer variants --------------------------------------------------------------------------
+// Arguments are marshalled by HostCall (zero-copy for small calls, workspace + staged DMA otherwise) and the agents are split
+// over the device set (crx_set_devices) — every array here is per agent, so a shard is a pointer offset.
 int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out, const crx_ekf_params* prm) {
   CRX_TRACE();
   if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  DevBuf dx, du;
-  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(du, sizeof(float) * 2 * n);
-  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(du.p, u, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
-  if (int rc = crx_motion_model_batch_dev(n, dx.as<float>(), du.as<float>(), dx.as<float>(), prm, nullptr)) return rc;
-  CRX_HIP(hipMemcpy(x_out, dx.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, x_out + 4 * a0, 16 * nl), iu = hc.add(u + 2 * a0, nullptr, 8 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_motion_model_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iu), hc.p<float>(ix), prm, hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm) {
@@ -360,13 +614,15 @@ int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx
   if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  DevBuf dx, du, dj;
-  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(du, sizeof(float) * 2 * n); CRX_ALLOC(dj, sizeof(float) * 16 * n);
-  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(du.p, u, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
-  if (int rc = crx_jacobF_batch_dev(n, dx.as<float>(), du.as<float>(), dj.as<float>(), prm, nullptr)) return rc;
-  CRX_HIP(hipMemcpy(jF, dj.p, sizeof(float) * 16 * n, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, nullptr, 16 * nl), iu = hc.add(u + 2 * a0, nullptr, 8 * nl), ij = hc.add(nullptr, jF + 16 * a0, 64 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_jacobF_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iu), hc.p<float>(ij), prm, hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_observation_model_batch(int n, const float* x, float* z_out) {
@@ -374,19 +630,155 @@ int crx_observation_model_batch(int n, const float* x, float* z_out) {
   if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  DevBuf dx, dz;
-  CRX_ALLOC(dx, sizeof(float) * 4 * n); CRX_ALLOC(dz, sizeof(float) * 2 * n);
-  CRX_HIP(hipMemcpy(dx.p, x, sizeof(float) * 4 * n, hipMemcpyHostToDevice));
-  if (int rc = crx_observation_model_batch_dev(n, dx.as<float>(), dz.as<float>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(z_out, dz.p, sizeof(float) * 2 * n, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, nullptr, 16 * nl), iz = hc.add(nullptr, z_out + 2 * a0, 8 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_observation_model_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iz), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_ekf_step_batch(int n, float* x, float* P, const float* z, const float* u, const float* Q,
                        const float* R, const crx_ekf_params* prm) {
-  CRX_TRACE();
   return crx_ekf_run_batch(n, 1, x, P, z, u, nullptr, nullptr, Q, R, prm);
 }
+
+}  // extern "C"
+
+namespace {
+
+// The fused EKF run for the agents [a0, a1) of an n-agent batch, host pointers, on the current device: a three-stream pipeline
+// over time chunks.  z, u are [T][n][2], x_hist [T][n][4], P_hist [T][n][16] (time-major: a shard's columns of a chunk are
+// `rows` of nl agents, n agents apart).  Chunk k: its z,u rows are gathered into a pinned slot by the copy threads (or DMA'd
+// straight from the caller's memory when that is pinned), go to the device on s_in, the kernel runs its steps on s_cmp — the
+// filter state x, P staying in the workspace from chunk to chunk, so the results are those of ONE T-step launch bit for bit —
+// and the chunk's history rows return on s_out, scattered into the caller's arrays by the copy threads.  While the device works
+// on chunk k the host fills chunk k+1 and drains chunk k-1.  Rings of kRing slots; reuse is fenced by events.
+int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
+                       float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
+  using crxh::kRing;
+  crxh::DeviceCtx* c = nullptr;
+  std::unique_lock<std::mutex> lock;
+  CRX_TRY(ctx_open(&c, lock));
+  const size_t nl = (size_t)(a1 - a0), nn = (size_t)n;
+  const size_t per_step_in = 16 * nl, per_step_out = (x_hist ? 16 * nl : 0) + (P_hist ? 64 * nl : 0);
+  // steps per chunk: ~16 MB of the larger direction, at least 1, at most T
+  const size_t per_step = std::max(per_step_in, per_step_out);
+  size_t Tc = std::max<size_t>(1, (16u << 20) / per_step);
+  Tc = std::min<size_t>(Tc, (size_t)T);
+  const int C = (int)(((size_t)T + Tc - 1) / Tc);
+  // a slot of the input ring is [z rows | u rows], of the output ring [x_hist rows | P_hist rows]; every part 256-byte aligned
+  const size_t zb = crxh::align_up(8 * nl * Tc), inb = 2 * zb, hx = crxh::align_up(16 * nl * Tc);
+  const size_t outb = (x_hist ? hx : 0) + (P_hist ? crxh::align_up(64 * nl * Tc) : 0);
+  const size_t xb = crxh::align_up(16 * nl), Pb = crxh::align_up(64 * nl);
+  const bool direct_in = crxh::is_pinned(z) && crxh::is_pinned(u);
+  const bool direct_out = (!x_hist || crxh::is_pinned(x_hist)) && (!P_hist || crxh::is_pinned(P_hist));
+  hipError_t e = c->dws.reserve(xb + Pb + kRing * (inb + outb));
+  if (e == hipSuccess) e = c->pws.reserve(xb + Pb + (direct_in ? 0 : kRing * inb) + (direct_out ? 0 : kRing * outb));
+  if (e != hipSuccess) { hip_fail(e, "workspace (ekf_run)"); return CRX_ERR_ALLOC; }
+  char* dbase = static_cast<char*>(c->dws.p);
+  float* dx = reinterpret_cast<float*>(dbase);
+  float* dP = reinterpret_cast<float*>(dbase + xb);
+  char* din = dbase + xb + Pb;                         // ring: [z rows | u rows] of a chunk
+  char* dout = din + kRing * inb;                      // ring: [x_hist rows | P_hist rows] of a chunk
+  char* pbase = static_cast<char*>(c->pws.p);
+  char* pxP = pbase;
+  char* pin_in = pbase + xb + Pb;
+  char* pin_out = pin_in + (direct_in ? 0 : kRing * inb);
+  crxh::CopyPool& pool = crxh::CopyPool::get();
+
+  // initial state: through the pinned block, on the compute stream
+  std::memcpy(pxP, x + 4 * (size_t)a0, 16 * nl);
+  std::memcpy(pxP + xb, P + 16 * (size_t)a0, 64 * nl);
+  CRX_HIP(hipMemcpyAsync(dx, pxP, 16 * nl, hipMemcpyHostToDevice, c->s_cmp));
+  CRX_HIP(hipMemcpyAsync(dP, pxP + xb, 64 * nl, hipMemcpyHostToDevice, c->s_cmp));
+
+  auto steps_of = [&](int k) { return std::min(Tc, (size_t)T - (size_t)k * Tc); };
+  // rows of chunk k in the caller's time-major arrays
+  auto zrow = [&](int k) { return reinterpret_cast<const char*>(z) + ((size_t)k * Tc * nn + (size_t)a0) * 8; };
+  auto urow = [&](int k) { return reinterpret_cast<const char*>(u) + ((size_t)k * Tc * nn + (size_t)a0) * 8; };
+  auto xhrow = [&](int k) { return reinterpret_cast<char*>(x_hist) + ((size_t)k * Tc * nn + (size_t)a0) * 16; };
+  auto Phrow = [&](int k) { return reinterpret_cast<char*>(P_hist) + ((size_t)k * Tc * nn + (size_t)a0) * 64; };
+
+  for (int it = 0; it <= C + 1; ++it) {
+    // (a) device work of chunk k = it - 1 (its inputs were staged during the previous trip)
+    const int k = it - 1;
+    if (k >= 0 && k < C) {
+      const int sl = k % kRing;
+      const size_t tc = steps_of(k);
+      char* dz = din + (size_t)sl * inb;
+      char* du = dz + zb;
+      if (k >= kRing) CRX_HIP(hipStreamWaitEvent(c->s_in, c->ev_cmp[sl], 0));          // the kernel of chunk k - kRing has read this slot
+      if (direct_in) {
+        CRX_HIP(hipMemcpy2DAsync(dz, 8 * nl, zrow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
+        CRX_HIP(hipMemcpy2DAsync(du, 8 * nl, urow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
+      } else {
+        CRX_HIP(hipMemcpyAsync(dz, pin_in + (size_t)sl * inb, zb + 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));   // z rows, padding, u rows
+      }
+      CRX_HIP(hipEventRecord(c->ev_in[sl], c->s_in));
+      CRX_HIP(hipStreamWaitEvent(c->s_cmp, c->ev_in[sl], 0));
+      if (k >= kRing) CRX_HIP(hipStreamWaitEvent(c->s_cmp, c->ev_out[sl], 0));         // the D2H of chunk k - kRing has left this slot
+      float* dxh = x_hist ? reinterpret_cast<float*>(dout + (size_t)sl * outb) : nullptr;
+      float* dPh = P_hist ? reinterpret_cast<float*>(dout + (size_t)sl * outb + (x_hist ? hx : 0)) : nullptr;
+      int rc;
+      if (T == 1 && !x_hist && !P_hist)
+        rc = crx_ekf_step_batch_dev((int)nl, dx, dP, reinterpret_cast<float*>(dz), reinterpret_cast<float*>(du), Q, R, prm, c->s_cmp);
+      else
+        rc = crx_ekf_run_batch_dev((int)nl, (int)tc, dx, dP, reinterpret_cast<float*>(dz), reinterpret_cast<float*>(du), dxh, dPh, Q, R, prm, c->s_cmp);
+      if (rc) return rc;
+      CRX_HIP(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
+      if (per_step_out) {
+        CRX_HIP(hipStreamWaitEvent(c->s_out, c->ev_cmp[sl], 0));
+        if (direct_out) {
+          if (x_hist) CRX_HIP(hipMemcpy2DAsync(xhrow(k), 16 * nn, dxh, 16 * nl, 16 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpy2DAsync(Phrow(k), 64 * nn, dPh, 64 * nl, 64 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
+        } else {
+          char* po = pin_out + (size_t)sl * outb;
+          if (x_hist) CRX_HIP(hipMemcpyAsync(po, dxh, 16 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpyAsync(po + (x_hist ? hx : 0), dPh, 64 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+        }
+        CRX_HIP(hipEventRecord(c->ev_out[sl], c->s_out));
+      }
+    }
+    // (b) stage the inputs of chunk `it` into its pinned slot (free once the H2D of chunk it - kRing has completed)
+    crxh::CopyPool::Ticket tin, tout;
+    if (it < C && !direct_in) {
+      const int sl = it % kRing;
+      const size_t tc = steps_of(it);
+      if (it >= kRing) CRX_HIP(hipEventSynchronize(c->ev_in[sl]));
+      char* pz = pin_in + (size_t)sl * inb;
+      pool.submit(crxh::CopyPool::Job{pz, zrow(it), 8 * nl, tc, 8 * nl, 8 * nn}, &tin);
+      pool.submit(crxh::CopyPool::Job{pz + zb, urow(it), 8 * nl, tc, 8 * nl, 8 * nn}, &tin);
+    }
+    // (c) drain the history rows of chunk it - 2 into the caller's arrays
+    const int d = it - 2;
+    if (d >= 0 && d < C && per_step_out && !direct_out) {
+      const int sl = d % kRing;
+      const size_t tc = steps_of(d);
+      CRX_HIP(hipEventSynchronize(c->ev_out[sl]));
+      char* po = pin_out + (size_t)sl * outb;
+      if (x_hist) pool.submit(crxh::CopyPool::Job{xhrow(d), po, 16 * nl, tc, 16 * nn, 16 * nl}, &tout);
+      if (P_hist) pool.submit(crxh::CopyPool::Job{Phrow(d), po + (x_hist ? hx : 0), 64 * nl, tc, 64 * nn, 64 * nl}, &tout);
+    }
+    pool.wait(&tin);
+    pool.wait(&tout);
+  }
+  // final state (the compute stream is behind the last kernel); every history row has left the device before we return
+  CRX_HIP(hipMemcpyAsync(pxP, dx, 16 * nl, hipMemcpyDeviceToHost, c->s_cmp));
+  CRX_HIP(hipMemcpyAsync(pxP + xb, dP, 64 * nl, hipMemcpyDeviceToHost, c->s_cmp));
+  CRX_HIP(hipStreamSynchronize(c->s_cmp));
+  if (per_step_out) CRX_HIP(hipStreamSynchronize(c->s_out));
+  std::memcpy(x + 4 * (size_t)a0, pxP, 16 * nl);
+  std::memcpy(P + 16 * (size_t)a0, pxP + xb, 64 * nl);
+  return CRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
                       float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
@@ -395,27 +787,25 @@ int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const fl
     return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0 || T == 0) return CRX_OK;
-  const size_t nn = (size_t)n, tt = (size_t)T;
-  DevBuf dx, dP, dz, du, dxh, dPh;
-  CRX_ALLOC(dx, 16 * nn); CRX_ALLOC(dP, 64 * nn); CRX_ALLOC(dz, 8 * nn * tt); CRX_ALLOC(du, 8 * nn * tt);
-  if (x_hist) CRX_ALLOC(dxh, 16 * nn * tt);
-  if (P_hist) CRX_ALLOC(dPh, 64 * nn * tt);
-  CRX_HIP(hipMemcpy(dx.p, x, 16 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dP.p, P, 64 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dz.p, z, 8 * nn * tt, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(du.p, u, 8 * nn * tt, hipMemcpyHostToDevice));
-  int rc;
-  if (T == 1 && !x_hist && !P_hist)
-    rc = crx_ekf_step_batch_dev(n, dx.as<float>(), dP.as<float>(), dz.as<float>(), du.as<float>(), Q, R, prm, nullptr);
-  else
-    rc = crx_ekf_run_batch_dev(n, T, dx.as<float>(), dP.as<float>(), dz.as<float>(), du.as<float>(),
-                               x_hist ? dxh.as<float>() : nullptr, P_hist ? dPh.as<float>() : nullptr, Q, R, prm, nullptr);
-  if (rc) return rc;
-  CRX_HIP(hipMemcpy(x, dx.p, 16 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(P, dP.p, 64 * nn, hipMemcpyDeviceToHost));
-  if (x_hist) CRX_HIP(hipMemcpy(x_hist, dxh.p, 16 * nn * tt, hipMemcpyDeviceToHost));
-  if (P_hist) CRX_HIP(hipMemcpy(P_hist, dPh.p, 64 * nn * tt, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nn = (size_t)n, tt = (size_t)T;
+    if (nl * tt * (32 + (P_hist ? 64 : 0)) + 80 * nl > crxh::kZeroCopyBytes)
+      return ekf_run_host_shard(n, sh.a0, sh.a1, T, x, P, z, u, x_hist, P_hist, Q, R, prm);
+    // a small call — the literal drop-in, ekf_estimation() for one vehicle — is zero-copy: one pinned block, one launch
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, x + 4 * a0, 16 * nl), iP = hc.add(P + 16 * a0, P + 16 * a0, 64 * nl);
+    const int iz = hc.add2d(z + 2 * a0, nullptr, 8 * nl, tt, 8 * nn), iu = hc.add2d(u + 2 * a0, nullptr, 8 * nl, tt, 8 * nn);
+    const int ih = x_hist ? hc.add2d(nullptr, x_hist + 4 * a0, 16 * nl, tt, 16 * nn) : -1;
+    const int iH = P_hist ? hc.add2d(nullptr, P_hist + 16 * a0, 64 * nl, tt, 64 * nn) : -1;
+    CRX_TRY(hc.commit());
+    if (T == 1 && !x_hist && !P_hist)
+      CRX_TRY(crx_ekf_step_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iP), hc.p<float>(iz), hc.p<float>(iu), Q, R, prm, hc.stream()));
+    else
+      CRX_TRY(crx_ekf_run_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(iP), hc.p<float>(iz), hc.p<float>(iu),
+                                    ih >= 0 ? hc.p<float>(ih) : nullptr, iH >= 0 ? hc.p<float>(iH) : nullptr, Q, R, prm, hc.stream()));
+    return hc.finish();
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -522,21 +912,20 @@ int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* 
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = n, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim;
-  DevBuf dA, dB, dQ, dR, dX, dK, dI;
-  CRX_ALLOC(dA, 4 * d2 * nn); CRX_ALLOC(dB, 4 * dim * m * nn); CRX_ALLOC(dQ, 4 * d2 * nn); CRX_ALLOC(dR, 4 * m * m * nn);
-  CRX_ALLOC(dX, 4 * d2 * nn); CRX_ALLOC(dK, 4 * dim * m * nn); CRX_ALLOC(dI, 4 * nn);
-  CRX_HIP(hipMemcpy(dA.p, A, 4 * d2 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dB.p, B, 4 * dim * m * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dQ.p, Q, 4 * d2 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dR.p, R, 4 * m * m * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_dare_batch_dev(n, dim, dA.as<float>(), dB.as<float>(), dQ.as<float>(), dR.as<float>(), eps, maxiter,
-                                  dX.as<float>(), dK.as<float>(), dI.as<int>(), nullptr)) return rc;
-  if (X) CRX_HIP(hipMemcpy(X, dX.p, 4 * d2 * nn, hipMemcpyDeviceToHost));
-  if (K) CRX_HIP(hipMemcpy(K, dK.p, 4 * dim * m * nn, hipMemcpyDeviceToHost));
-  if (iters) CRX_HIP(hipMemcpy(iters, dI.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipDeviceSynchronize());
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim, db = (size_t)dim * m;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int iA = hc.add(A + d2 * a0, nullptr, 4 * d2 * nl), iB = hc.add(B + db * a0, nullptr, 4 * db * nl);
+    const int iQ = hc.add(Q + d2 * a0, nullptr, 4 * d2 * nl), iR = hc.add(R + m * m * a0, nullptr, 4 * m * m * nl);
+    const int iX = X ? hc.add(nullptr, X + d2 * a0, 4 * d2 * nl) : -1, iK = K ? hc.add(nullptr, K + db * a0, 4 * db * nl) : -1;
+    const int iI = iters ? hc.add(nullptr, iters + a0, 4 * nl) : -1;
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_dare_batch_dev((int)nl, dim, hc.p<float>(iA), hc.p<float>(iB), hc.p<float>(iQ), hc.p<float>(iR), eps, maxiter,
+                               iX >= 0 ? hc.p<float>(iX) : nullptr, iK >= 0 ? hc.p<float>(iK) : nullptr, iI >= 0 ? hc.p<int>(iI) : nullptr,
+                               hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K, int* iters) {
@@ -545,16 +934,18 @@ int crx_dare_from_v_batch(int n, int dim, const float* v, const crx_lqr_params* 
     return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = n, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim;
-  DevBuf dv, dX, dK, dI;
-  CRX_ALLOC(dv, 4 * nn); CRX_ALLOC(dX, 4 * d2 * nn); CRX_ALLOC(dK, 4 * dim * m * nn); CRX_ALLOC(dI, 4 * nn);
-  CRX_HIP(hipMemcpy(dv.p, v, 4 * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_dare_from_v_batch_dev(n, dim, dv.as<float>(), prm, dX.as<float>(), dK.as<float>(), dI.as<int>(), nullptr)) return rc;
-  if (X) CRX_HIP(hipMemcpy(X, dX.p, 4 * d2 * nn, hipMemcpyDeviceToHost));
-  if (K) CRX_HIP(hipMemcpy(K, dK.p, 4 * dim * m * nn, hipMemcpyDeviceToHost));
-  if (iters) CRX_HIP(hipMemcpy(iters, dI.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipDeviceSynchronize());
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, m = (dim == 5) ? 2 : 1, d2 = (size_t)dim * dim, db = (size_t)dim * m;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int iv = hc.add(v + a0, nullptr, 4 * nl);
+    const int iX = X ? hc.add(nullptr, X + d2 * a0, 4 * d2 * nl) : -1, iK = K ? hc.add(nullptr, K + db * a0, 4 * db * nl) : -1;
+    const int iI = iters ? hc.add(nullptr, iters + a0, 4 * nl) : -1;
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_dare_from_v_batch_dev((int)nl, dim, hc.p<float>(iv), prm, iX >= 0 ? hc.p<float>(iX) : nullptr,
+                                      iK >= 0 ? hc.p<float>(iK) : nullptr, iI >= 0 ? hc.p<int>(iI) : nullptr, hc.stream()));
+    return hc.finish();
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,18 +1010,18 @@ int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const 
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = n, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
-  DevBuf dx0, dxr, dsol, dst, dc;
-  CRX_ALLOC(dx0, 16 * nn); CRX_ALLOC(dxr, 16 * T * nn); CRX_ALLOC(dsol, 4 * nv * nn); CRX_ALLOC(dst, 4 * nn); CRX_ALLOC(dc, 8 * nn);
-  CRX_HIP(hipMemcpy(dx0.p, x0, 16 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dxr.p, xref, 16 * T * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_mpc_solve_batch_dev(n, T, dx0.as<float>(), dxr.as<float>(), prm, dsol.as<float>(), dst.as<int>(),
-                                       dc.as<double>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(sol, dsol.p, 4 * nv * nn, hipMemcpyDeviceToHost));
-  if (status) CRX_HIP(hipMemcpy(status, dst.p, 4 * nn, hipMemcpyDeviceToHost));
-  if (cost) CRX_HIP(hipMemcpy(cost, dc.p, 8 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipDeviceSynchronize());
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x0 + 4 * a0, nullptr, 16 * nl), ir = hc.add(xref + 4 * (size_t)T * a0, nullptr, 16 * (size_t)T * nl);
+    const int is = hc.add(nullptr, sol + nv * a0, 4 * nv * nl);
+    const int it = hc.add(nullptr, status ? status + a0 : nullptr, 4 * nl), ic = hc.add(nullptr, cost ? cost + a0 : nullptr, 8 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_mpc_solve_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it), hc.p<double>(ic),
+                                    hc.stream()));
+    return hc.finish();
+  });
 }
 
 }  // extern "C"
@@ -654,21 +1045,18 @@ inline size_t lds_bytes(const crx_course* c) { return use_lds(c) ? sizeof(float4
 // the four-lanes-per-agent tracking kernels keep a gain slot per agent in static LDS next to the staged course (64 KB per workgroup in all)
 inline bool use_quad(const crx_course* c, int n) { return n <= kDareQuadMaxAgents && use_lds(c) && lds_bytes(c) + 1024 <= 64 * 1024; }
 
-// host-side staging of a course for the host-pointer entry points
-struct DevCourse {
-  DevBuf b[5];
-  crx_course c;
-  int upload(const crx_course* h) {
+// the course of a host-pointer call: its five arrays travel with the call's other arguments (replicated per shard)
+struct CallCourse {
+  int idx[5], n;
+  void add(HostCall& hc, const crx_course* h) {
     const float* src[5] = {h->cx, h->cy, h->cyaw, h->ck, h->sp};
-    const float* dst[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    for (int i = 0; i < 5; ++i) {
-      if (!src[i]) continue;
-      if (b[i].alloc(sizeof(float) * (size_t)h->n) != hipSuccess) return CRX_ERR_ALLOC;
-      if (hipMemcpy(b[i].p, src[i], sizeof(float) * (size_t)h->n, hipMemcpyHostToDevice) != hipSuccess) return CRX_ERR_HIP;
-      dst[i] = b[i].as<float>();
-    }
-    c = crx_course{h->n, dst[0], dst[1], dst[2], dst[3], dst[4]};
-    return CRX_OK;
+    n = h->n;
+    for (int i = 0; i < 5; ++i) idx[i] = src[i] ? hc.add(src[i], nullptr, sizeof(float) * (size_t)h->n) : -1;
+  }
+  crx_course dev(HostCall& hc) const {
+    const float* d[5];
+    for (int i = 0; i < 5; ++i) d[i] = idx[i] >= 0 ? hc.p<float>(idx[i]) : nullptr;
+    return crx_course{n, d[0], d[1], d[2], d[3], d[4]};
   }
 };
 
@@ -879,15 +1267,17 @@ int crx_calc_nearest_index_batch(int n, const float* state, const crx_course* co
   if (n < 0 || !course_ok(course, false) || (n && (!state || !ind))) return fail(CRX_ERR_INVALID, "calc_nearest_index: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  DevCourse dc; DevBuf ds, di, de;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * (size_t)n); CRX_ALLOC(di, 4 * (size_t)n); CRX_ALLOC(de, 4 * (size_t)n);
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * (size_t)n, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(di.p, ind, 4 * (size_t)n, hipMemcpyHostToDevice));
-  if (int rc = crx_calc_nearest_index_batch_dev(n, ds.as<float>(), &dc.c, di.as<int>(), de.as<float>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(ind, di.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-  if (e) CRX_HIP(hipMemcpy(e, de.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, nullptr, 16 * nl), ii = hc.add(ind + a0, ind + a0, 4 * nl), ie = hc.add(nullptr, e ? e + a0 : nullptr, 4 * nl);
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_calc_nearest_index_batch_dev((int)nl, hc.p<float>(is), &dc, hc.p<int>(ii), hc.p<float>(ie), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx_course* course, int* ind, float* pe,
@@ -897,21 +1287,21 @@ int crx_lqr_steering_control_batch(int n, int dim, const float* state, const crx
     return fail(CRX_ERR_INVALID, "lqr_steering_control: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n, nc = dim == 5 ? 2 : 1;
-  DevCourse dc; DevBuf ds, di, dpe, dpt, dct;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dpe, 4 * nn); CRX_ALLOC(dpt, 4 * nn); CRX_ALLOC(dct, 4 * nc * nn);
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  if (ind) CRX_HIP(hipMemcpy(di.p, ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
-  CRX_HIP(hipMemcpy(dpe.p, pe, 4 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dpt.p, pth_e, 4 * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_lqr_steering_control_batch_dev(n, dim, ds.as<float>(), &dc.c, di.as<int>(), dpe.as<float>(), dpt.as<float>(), prm,
-                                                  dct.as<float>(), nullptr)) return rc;
-  if (ind) CRX_HIP(hipMemcpy(ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(pe, dpe.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(pth_e, dpt.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(control, dct.p, 4 * nc * nn, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nc = dim == 5 ? 2 : 1;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, nullptr, 16 * nl);
+    const int ii = hc.add(ind ? ind + a0 : nullptr, ind ? ind + a0 : nullptr, 4 * nl, true);
+    const int ip = hc.add(pe + a0, pe + a0, 4 * nl), it = hc.add(pth_e + a0, pth_e + a0, 4 * nl);
+    const int ic = hc.add(nullptr, control + nc * a0, 4 * nc * nl);
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_lqr_steering_control_batch_dev((int)nl, dim, hc.p<float>(is), &dc, hc.p<int>(ii), hc.p<float>(ip), hc.p<float>(it), prm,
+                                               hc.p<float>(ic), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_update_batch(int n, float* state, const float* a, const float* delta, const crx_vehicle_params* prm) {
@@ -919,15 +1309,15 @@ int crx_update_batch(int n, float* state, const float* a, const float* delta, co
   if (n < 0 || (n && (!state || !a || !delta))) return fail(CRX_ERR_INVALID, "update: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n;
-  DevBuf ds, da, dd;
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(da, 4 * nn); CRX_ALLOC(dd, 4 * nn);
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(da.p, a, 4 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dd.p, delta, 4 * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_update_batch_dev(n, ds.as<float>(), da.as<float>(), dd.as<float>(), prm, nullptr)) return rc;
-  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int is = hc.add(state + 4 * a0, state + 4 * a0, 16 * nl), ia = hc.add(a + a0, nullptr, 4 * nl), id = hc.add(delta + a0, nullptr, 4 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_update_batch_dev((int)nl, hc.p<float>(is), hc.p<float>(ia), hc.p<float>(id), prm, hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* course, float* pe, float* pth_e, int* ind,
@@ -938,24 +1328,25 @@ int crx_lqr_closed_loop_batch(int n, int dim, float* state, const crx_course* co
     return fail(CRX_ERR_INVALID, "lqr_closed_loop: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n, mt = (size_t)loop->max_ticks;
-  DevCourse dc; DevBuf ds, dpe, dpt, di, dh, dt;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(dpe, 4 * nn); CRX_ALLOC(dpt, 4 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn);
-  if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  if (pe) CRX_HIP(hipMemcpy(dpe.p, pe, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(dpe.p, 0, 4 * nn));
-  if (pth_e) CRX_HIP(hipMemcpy(dpt.p, pth_e, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(dpt.p, 0, 4 * nn));
-  if (ind) CRX_HIP(hipMemcpy(di.p, ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
-  if (int rc = crx_lqr_closed_loop_batch_dev(n, dim, ds.as<float>(), &dc.c, dpe.as<float>(), dpt.as<float>(), di.as<int>(), prm, veh,
-                                             loop, traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
-  if (pe) CRX_HIP(hipMemcpy(pe, dpe.p, 4 * nn, hipMemcpyDeviceToHost));
-  if (pth_e) CRX_HIP(hipMemcpy(pth_e, dpt.p, 4 * nn, hipMemcpyDeviceToHost));
-  if (ind) CRX_HIP(hipMemcpy(ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
-  if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));
-  if (ticks_done) CRX_HIP(hipMemcpy(ticks_done, dt.p, 4 * nn, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nn = (size_t)n, mt = (size_t)loop->max_ticks;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    hc.forbid_zero_copy();
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, state + 4 * a0, 16 * nl);
+    const int ip = hc.add(pe ? pe + a0 : nullptr, pe ? pe + a0 : nullptr, 4 * nl, true);
+    const int it = hc.add(pth_e ? pth_e + a0 : nullptr, pth_e ? pth_e + a0 : nullptr, 4 * nl, true);
+    const int ii = hc.add(ind ? ind + a0 : nullptr, ind ? ind + a0 : nullptr, 4 * nl, true);
+    const int ik = hc.add(nullptr, ticks_done ? ticks_done + a0 : nullptr, 4 * nl);
+    // the trajectory is time-major [tick][n][4]: a shard's columns, cleared first (agents that reach the goal stop writing)
+    const int ih = traj_hist ? hc.add2d(nullptr, traj_hist + 4 * a0, 16 * nl, mt, 16 * nn, true) : -1;
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_lqr_closed_loop_batch_dev((int)nl, dim, hc.p<float>(is), &dc, hc.p<float>(ip), hc.p<float>(it), hc.p<int>(ii), prm, veh,
+                                          loop, ih >= 0 ? hc.p<float>(ih) : nullptr, hc.p<int>(ik), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_course* course, const int* pind, int nsearch,
@@ -965,15 +1356,17 @@ int crx_calc_nearest_index_window_batch(int n, const float* state, const crx_cou
     return fail(CRX_ERR_INVALID, "calc_nearest_index(window): bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n;
-  DevCourse dc; DevBuf ds, dp, di;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(dp, 4 * nn); CRX_ALLOC(di, 4 * nn);
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(dp.p, pind, 4 * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_calc_nearest_index_window_batch_dev(n, ds.as<float>(), &dc.c, dp.as<int>(), nsearch, di.as<int>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(ind_out, di.p, 4 * nn, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, nullptr, 16 * nl), ip = hc.add(pind + a0, nullptr, 4 * nl), io = hc.add(nullptr, ind_out + a0, 4 * nl);
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_calc_nearest_index_window_batch_dev((int)nl, hc.p<float>(is), &dc, hc.p<int>(ip), nsearch, hc.p<int>(io), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* course, float dl, int nsearch, const crx_mpc_params* prm,
@@ -983,21 +1376,23 @@ int crx_mpc_closed_loop_batch(int n, int T, float* state, const crx_course* cour
     return fail(CRX_ERR_INVALID, "mpc_closed_loop: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n, mt = (size_t)loop->max_ticks;
-  DevCourse dc; DevBuf ds, di, dh, dt, df;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dt, 4 * nn); CRX_ALLOC(df, 4 * nn);
-  if (traj_hist) { CRX_ALLOC(dh, 16 * nn * mt); CRX_HIP(hipMemset(dh.p, 0, 16 * nn * mt)); }
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  if (target_ind) CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice)); else CRX_HIP(hipMemset(di.p, 0, 4 * nn));
-  if (int rc = crx_mpc_closed_loop_flags_batch_dev(n, T, ds.as<float>(), &dc.c, dl, nsearch, prm, loop, di.as<int>(),
-                                                   traj_hist ? dh.as<float>() : nullptr, dt.as<int>(), df.as<int>(), nullptr)) return rc;
-  if (solve_flags) CRX_HIP(hipMemcpy(solve_flags, df.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(state, ds.p, 16 * nn, hipMemcpyDeviceToHost));
-  if (target_ind) CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
-  if (traj_hist) CRX_HIP(hipMemcpy(traj_hist, dh.p, 16 * nn * mt, hipMemcpyDeviceToHost));
-  if (ticks_done) CRX_HIP(hipMemcpy(ticks_done, dt.p, 4 * nn, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nn = (size_t)n, mt = (size_t)loop->max_ticks;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    hc.forbid_zero_copy();
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, state + 4 * a0, 16 * nl);
+    const int ii = hc.add(target_ind ? target_ind + a0 : nullptr, target_ind ? target_ind + a0 : nullptr, 4 * nl, true);
+    const int ik = hc.add(nullptr, ticks_done ? ticks_done + a0 : nullptr, 4 * nl);
+    const int iflag = hc.add(nullptr, solve_flags ? solve_flags + a0 : nullptr, 4 * nl);
+    const int ih = traj_hist ? hc.add2d(nullptr, traj_hist + 4 * a0, 16 * nl, mt, 16 * nn, true) : -1;
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_mpc_closed_loop_flags_batch_dev((int)nl, T, hc.p<float>(is), &dc, dl, nsearch, prm, loop, hc.p<int>(ii),
+                                                ih >= 0 ? hc.p<float>(ih) : nullptr, hc.p<int>(ik), hc.p<int>(iflag), hc.stream()));
+    return hc.finish();
+  });
 }
 
 int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_course* course, float dl, double dt, int nsearch,
@@ -1007,16 +1402,18 @@ int crx_calc_ref_trajectory_batch(int n, int T, const float* state, const crx_co
     return fail(CRX_ERR_INVALID, "calc_ref_trajectory: bad argument");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
-  const size_t nn = (size_t)n;
-  DevCourse dc; DevBuf ds, di, dx;
-  if (int rc = dc.upload(course)) return fail(rc, "course upload");
-  CRX_ALLOC(ds, 16 * nn); CRX_ALLOC(di, 4 * nn); CRX_ALLOC(dx, 16 * nn * T);
-  CRX_HIP(hipMemcpy(ds.p, state, 16 * nn, hipMemcpyHostToDevice));
-  CRX_HIP(hipMemcpy(di.p, target_ind, 4 * nn, hipMemcpyHostToDevice));
-  if (int rc = crx_calc_ref_trajectory_batch_dev(n, T, ds.as<float>(), &dc.c, dl, dt, nsearch, di.as<int>(), dx.as<float>(), nullptr)) return rc;
-  CRX_HIP(hipMemcpy(target_ind, di.p, 4 * nn, hipMemcpyDeviceToHost));
-  CRX_HIP(hipMemcpy(xref, dx.p, 16 * nn * T, hipMemcpyDeviceToHost));
-  return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc; CallCourse cc;
+    CRX_TRY(hc.open());
+    cc.add(hc, course);
+    const int is = hc.add(state + 4 * a0, nullptr, 16 * nl), ii = hc.add(target_ind + a0, target_ind + a0, 4 * nl);
+    const int ix = hc.add(nullptr, xref + 4 * (size_t)T * a0, 16 * (size_t)T * nl);
+    CRX_TRY(hc.commit());
+    const crx_course dc = cc.dev(hc);
+    CRX_TRY(crx_calc_ref_trajectory_batch_dev((int)nl, T, hc.p<float>(is), &dc, dl, dt, nsearch, hc.p<int>(ii), hc.p<float>(ix), hc.stream()));
+    return hc.finish();
+  });
 }
 
 }  // extern "C"

@@ -39,9 +39,35 @@ typedef enum crx_status {
 /* ---- runtime ------------------------------------------------------------------------- */
 int crx_version(void);                 /* 10000*major + 100*minor + patch                 */
 int crx_init(void);                    /* optional: device check + runtime warm-up         */
-int crx_shutdown(void);                /* optional: hipDeviceSynchronize                   */
+int crx_shutdown(void);                /* optional: drain the devices, release workspaces  */
 int crx_device_count(void);            /* number of HIP devices visible (0 if none)       */
 const char* crx_last_error(void);      /* thread-local, never NULL                        */
+
+/* Devices (since 0.4).  The `_dev` entry points launch on the calling thread's current device (crx_set_device = hipSetDevice);
+ * their pointers and stream must belong to it.  The host-pointer entry points use the calling thread's current device too —
+ * unless a device set is installed: then every host-pointer BATCH entry point (crx_ekf_run_batch, crx_ekf_step_batch,
+ * crx_dare_batch, crx_dare_from_v_batch, crx_mpc_solve_batch, the tracking functions and both closed loops) splits its agents
+ * [0, n) contiguously over devices[0 .. ndev) — shard r on devices[r], the first n % G shards one agent longer, as few shards as
+ * keep min_agents_per_device agents each —, one host thread and one set of streams per shard, results landing directly in the
+ * caller's arrays.  No collective: agents never read one another (src/extended_kalman_filter.cpp:64-78,
+ * src/lqr_speed_steer_control.cpp:85-151, src/model_predictive_control.cpp:255-346).  The result does not depend on the
+ * partition (tests/test_multi_device.py: a forced split equals the unsplit call bit for bit).  Shared inputs (Q, R, params, the
+ * course) are replicated.  ndev = 0 removes the set; devices = NULL means 0 .. ndev-1; a device may be listed more than once.
+ * Serves the reference's fleet-sized callers: the EKF main loop (src/extended_kalman_filter.cpp:171-183) and the tracking loops
+ * (src/lqr_speed_steer_control.cpp:194-205, src/model_predictive_control.cpp:371-385) for n vehicles on 1 .. N GPUs. */
+int crx_set_device(int device);
+int crx_get_device(void);              /* -1 without a device */
+int crx_set_devices(const int* devices, int ndev, int min_agents_per_device);
+int crx_get_devices(int* devices, int cap);   /* returns the size of the set (0: none installed) */
+
+/* Host-pointer calls keep per-device workspaces (device memory + pinned staging) that grow to the largest call seen and are
+ * reused — no allocation in steady state.  Small calls (arguments <= 256 KB in all: the literal one-vehicle drop-in calls) are
+ * zero-copy: one pinned block the kernel reads and writes across PCIe.  Large pageable arrays are staged through pinned rings by
+ * copy threads; arrays from crx_host_alloc (pinned) are DMA'd in place — the fastest way across the bus.
+ * crx_release_workspace gives the workspaces back (so does crx_shutdown). */
+void* crx_host_alloc(size_t bytes);    /* pinned host memory (NULL on failure) */
+void crx_host_free(void* p);
+int crx_release_workspace(void);
 
 /* ---- EKF localisation (src/extended_kalman_filter.cpp) --------------------------------- */
 typedef struct crx_ekf_params {

@@ -64,6 +64,19 @@ def test_bench_host_helpers():
         sys.argv = old
 
 
+def test_bench_builds_the_reference_matrices_itself(oracle_mod):
+    """bench.py's timed DARE legs build lqr_steering_control's A, B, Q, R without the oracle (only its cpu_baseline leg may touch
+    oracle/): the helper equals the oracle's builder bit for bit."""
+    import numpy as np
+    from common import lqr_speeds
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    v = lqr_speeds(2000, 3)
+    for got, want in zip(b.lqr_pattern_mats(v), oracle_mod.lqr_build(v, 5)):
+        assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).reshape(got.shape).view(np.uint32))
+
+
 def test_committed_bench_line_has_the_contract_fields():
     d = json.load(open(os.path.join(ROOT, "profiles", "r02", "bench_n1.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",

@@ -8,12 +8,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path_factory, name):
+def _build(tmp_path_factory, name, compiler="/opt/rocm/bin/hipcc"):
     out = str(tmp_path_factory.mktemp("ex") / name)
     libdir = os.path.join(ROOT, "cpprobotics_amd")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".cpp"),
-                           "-o", out, "-L", libdir, "-lcrx", f"-Wl,-rpath,{libdir}"])
+    subprocess.check_call([compiler, "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", name + ".cpp"), "-o", out, "-L", libdir, "-lcrx", f"-Wl,-rpath,{libdir}"])
     return out
+
+
+@pytest.fixture(scope="module")
+def host_exe(tmp_path_factory, crx):
+    return _build(tmp_path_factory, "ekf_fleet_host", compiler="g++")        # plain C++: no HIP header, no hipcc
 
 
 @pytest.fixture(scope="module")
@@ -43,7 +48,25 @@ def test_example_builds_and_fails_loudly_without_gpu(exe):
 def test_example_runs(exe):
     r = subprocess.run([exe, "4096", "200"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "EKF updates/s" in r.stdout
+    assert "EKF updates/s" in r.stdout and "GPU(s)" in r.stdout
+
+
+def test_host_example_builds_with_a_plain_cxx_compiler_and_fails_loudly_without_gpu(host_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([host_exe, "64", "10"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", ["0", "1"])
+def test_host_example_runs(host_exe, pinned):
+    """The fleet through the host-pointer entry point (std::vector or pinned arrays), sharded over every visible GPU by
+    crx_set_devices: the estimate tracks the truth."""
+    r = subprocess.run([host_exe, "20000", "120", "99", pinned], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "GB/s across the boundary" in r.stdout
 
 
 def test_planner_example_builds_and_fails_loudly_without_gpu(planner_exe):

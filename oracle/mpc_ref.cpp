@@ -26,6 +26,7 @@
 namespace {
 
 int p_n_gn = 2; double p_up = 10.0, p_down = 0.1;  // tuning knobs (set through oracle_mpc_tune)
+int p_warm = 0;       // experiment knob (oracle_mpc_warm): 0 = the reference's zero initial guess (:266-274), 1 / 2 = see solve_one
 
 struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the reference's #defines
   double dt, wb, max_steer, max_accel, max_speed, min_speed;
@@ -302,7 +303,18 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
     for (int i = 0; i < N; ++i) {
       double a_lo, a_hi; bool sp_lo, sp_hi;
       accel_box(p, s[3], &a_lo, &a_hi, &sp_lo, &sp_hi);
-      w.U[NU * i + 1] = clampd(0.0, a_lo, a_hi);
+      double a_w = 0.0, d_w = 0.0;
+      if (p_warm >= 1) a_w = ((double)xref[4 * (i + 1) + 3] - s[3]) / p.dt;                     // reach the reference speed of knot i+1
+      if (p_warm >= 2 && std::fabs(s[3]) > 0.5) {                                               // reach the reference heading of knot i+1
+        const double tn = ((double)xref[4 * (i + 1) + 2] - s[2]) * p.wb / (s[3] * p.dt);
+        d_w = clampd(std::atan(tn), -p.max_steer, p.max_steer);
+      }
+      if (p_warm == 3 && std::fabs(s[3]) > 0.5) {                                               // heading rate of the REFERENCE (feed-forward)
+        const double tn = ((double)xref[4 * (i + 1) + 2] - (double)xref[4 * i + 2]) * p.wb / (s[3] * p.dt);
+        d_w = clampd(std::atan(tn), -p.max_steer, p.max_steer);
+      }
+      w.U[NU * i + 0] = d_w;
+      w.U[NU * i + 1] = clampd(a_w, a_lo, a_hi);
       dyn(p, s, w.U.data() + NU * i, sn);
       std::memcpy(s, sn, sizeof(s));
     }
@@ -412,6 +424,7 @@ void oracle_mpc_solve(int n, int T, const float* x0, const float* xref, const do
 }
 
 void oracle_mpc_tune(int n_gn, double up, double down) { p_n_gn = n_gn; p_up = up; p_down = down; }
+void oracle_mpc_warm(int mode) { p_warm = mode; }
 
 // Debug aid for the tests: per-iteration (J, max|k|, mu, accepted alpha), 4 doubles x max_iter.
 int oracle_mpc_trace(int T, const float* x0, const float* xref, const double* params, int max_iter, double* trace) {

@@ -28,7 +28,9 @@ for s in $STEPS; do
     host) nproc > $OUT/host.txt; cat /sys/fs/cgroup/cpu.max >> $OUT/host.txt 2>&1; python -c "import os;print(len(os.sched_getaffinity(0)))" >> $OUT/host.txt; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1 >> $OUT/host.txt; cat $OUT/host.txt ;;
     tests) timeout 900 python -m pytest ${TESTS:-tests} -m gpu -q -p no:cacheprovider 2>&1 | tail -8 > $OUT/tests.log; cat $OUT/tests.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log ;;
-    bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 1500 $OUT/bench.json; echo; tail -2 $OUT/bench.err ;;
+    bench) rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temperature" | head -8 > $OUT/bench_smi_before.txt
+           timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; head -c 1500 $OUT/bench.json; echo; tail -2 $OUT/bench.err
+           rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "sclk|mclk|Power|Temperature" | head -8 > $OUT/bench_smi_after.txt; cat $OUT/bench_smi_after.txt ;;
     forcedist) timeout 300 python bench.py --force-dist --steps 20 --no-cpu-baseline --no-extras > $OUT/bench_forcedist.json 2> $OUT/bench_forcedist.err; head -c 600 $OUT/bench_forcedist.json; echo ;;
     oversub) timeout 600 python bench.py --gpus 2 --oversubscribe --steps 10 --warmup 2 --settle 20 > $OUT/bench_oversub2.json 2> $OUT/bench_oversub2.err; tail -c 1200 $OUT/bench_oversub2.json; echo; tail -3 $OUT/bench_oversub2.err ;;
     ab) timeout 200 python scripts/gpu_dare_lanes_ab.py > $OUT/dare_lanes_ab.jsonl 2> $OUT/dare_ab.err; cut -c1-200 $OUT/dare_lanes_ab.jsonl

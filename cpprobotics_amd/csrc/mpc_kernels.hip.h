@@ -151,9 +151,9 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
                                        double hi0, double lo1, double hi1, double& k0, double& k1, bool& f0,
                                        bool& f1) {
   // Straight-line: every candidate is formed and scored, the winner is picked by selects in the order (and with the
-  // strict comparison) of the enumeration in oracle/mpc_ref.cpp — per-lane booleans carried through divergent branches
-  // cost more scalar mask bookkeeping than the arithmetic they skip.  Only the whole enumeration is skipped, when every
-  // lane of the wave has its interior stationary point inside the box.
+  // strict comparison) of oracle/mpc_ref.cpp — per-lane booleans carried through divergent branches cost more scalar
+  // mask bookkeeping than the arithmetic they skip.  Whole candidate sets are skipped only when NO lane of the wave needs them
+  // (every lane interior; every lane on the edge rule) — which set a lane's answer comes from is decided by its own problem.
   const double tiny = 1e-12;
   const double det = h00 * h11 - hod * hod;
   const bool pd = h00 > tiny && det > tiny * h00;
@@ -171,40 +171,44 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   };
   const bool c11 = h11 > tiny, c00 = h00 > tiny;
   const double ih11 = fast_div(1.0, c11 ? h11 : 1.0), ih00 = fast_div(1.0, c00 ? h00 : 1.0);   // one reciprocal per edge pair
-  if (__all(c00 && c11)) {
-    // Both diagonal curvatures positive in every lane (always so in a Gauss-Newton sweep): the problem along each of the four
-    // edges is a convex parabola, whose minimiser over the edge is the stationary point clamped to it — four candidates
-    // cover the whole boundary, corners included.  A control counts as free under the rule of the full enumeration below (its
-    // unclamped stationary value lies in the closed interval), so the two paths agree on the point and on the flags except for
-    // exact ties between two DIFFERENT boundary points of equal objective, which the two candidate orders may break differently
-    // (a measure-zero coincidence; which path runs is a wave-level decision, the CPU twin mirrors the enumeration below).
+  // Both diagonal curvatures positive (always so in a Gauss-Newton sweep): the problem along each of the four edges is a convex
+  // parabola, whose minimiser over the edge is the stationary point clamped to it — four candidates cover the whole boundary,
+  // corners included.  A control counts as free under the rule of the full enumeration below (its unclamped stationary value lies
+  // in the closed interval), so the two rules agree on the point and on the flags except for exact ties between two DIFFERENT
+  // boundary points of equal objective.  The rule is a property of the LANE's problem (round 4; the CPU twin applies
+  // it per problem too): a wave in which some lane needs the enumeration runs both and every lane keeps the result of its own
+  // rule, so an agent's answer never depends on which agents share its wave.
+  const bool edge_rule = c00 && c11;
+  const bool all_edge = __all(edge_rule);      // the common case keeps its mask-free candidate scoring
+  auto edge_candidates = [&](auto valid) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const double c0 = b ? hi0 : lo0;
       const double u1 = -(g1 + hod * c0) * ih11;
-      consider(c0, clampd(u1, lo1, hi1), (u1 >= lo1 && u1 <= hi1) ? 2 : 0, true);
+      consider(c0, clampd(u1, lo1, hi1), (u1 >= lo1 && u1 <= hi1) ? 2 : 0, valid());
       const double c1 = b ? hi1 : lo1;
       const double u0 = -(g0 + hod * c1) * ih00;
-      consider(clampd(u0, lo0, hi0), c1, (u0 >= lo0 && u0 <= hi0) ? 1 : 0, true);
+      consider(clampd(u0, lo0, hi0), c1, (u0 >= lo0 && u0 <= hi0) ? 1 : 0, valid());
     }
-    const lanemask_t in = lanes_where(interior);
-    k0 = sel64(in, ia, b0); k1 = sel64(in, ib, b1);
-    f0 = interior || (bf & 1); f1 = interior || (bf & 2);
-    return;
+  };
+  if (all_edge) edge_candidates([] { return true; });
+  else edge_candidates([&] { return edge_rule; });
+  if (!all_edge) {      // rare: an indefinite or semidefinite stage Hessian somewhere in the wave (Newton sweeps only)
+    const bool en = !edge_rule;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const double c0 = b ? hi0 : lo0;
+      const double t1 = -(g1 + hod * c0) * ih11;
+      consider(c0, t1, 2, en && c11 && t1 >= lo1 && t1 <= hi1);
+      const double c1 = b ? hi1 : lo1;
+      const double t0 = -(g0 + hod * c1) * ih00;
+      consider(t0, c1, 1, en && c00 && t0 >= lo0 && t0 <= hi0);
+    }
+#pragma unroll
+    for (int q0 = 0; q0 < 2; ++q0)
+#pragma unroll
+      for (int q1 = 0; q1 < 2; ++q1) consider(q0 ? hi0 : lo0, q1 ? hi1 : lo1, 0, en);
   }
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const double c0 = b ? hi0 : lo0;
-    const double t1 = -(g1 + hod * c0) * ih11;
-    consider(c0, t1, 2, c11 && t1 >= lo1 && t1 <= hi1);
-    const double c1 = b ? hi1 : lo1;
-    const double t0 = -(g0 + hod * c1) * ih00;
-    consider(t0, c1, 1, c00 && t0 >= lo0 && t0 <= hi0);
-  }
-#pragma unroll
-  for (int q0 = 0; q0 < 2; ++q0)
-#pragma unroll
-    for (int q1 = 0; q1 < 2; ++q1) consider(q0 ? hi0 : lo0, q1 ? hi1 : lo1, 0, true);
   const lanemask_t in = lanes_where(interior);
   k0 = sel64(in, ia, b0); k1 = sel64(in, ib, b1);
   f0 = interior || (bf & 1); f1 = interior || (bf & 2);

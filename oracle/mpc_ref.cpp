@@ -113,6 +113,22 @@ void boxqp2(const double H[4], const double g[2], const double lo[2], const doub
     const double k1 = -(-hod * g[0] + H[0] * g[1]) / det;
     if (k0 >= lo[0] && k0 <= hi[0] && k1 >= lo[1] && k1 <= hi[1]) { consider(k0, k1, 1, 1); return; }
   }
+  if (H[0] > tiny && H[3] > tiny) {
+    // Both diagonal curvatures positive: along each of the four edges the problem is a convex parabola whose minimiser over the edge
+    // is the stationary point clamped to it — four candidates cover the whole boundary, corners included; a control counts as free
+    // when its unclamped stationary value lies in the closed interval.  The same point and flags as the enumeration below except for
+    // exact ties between two different boundary points of equal objective; the rule is applied PER PROBLEM (the kernel does the
+    // same per lane since round 4: ADVICE r3), so which candidates a problem sees never depends on its neighbours in a wave.
+    for (int b = 0; b < 2; ++b) {
+      const double c0 = b ? hi[0] : lo[0];
+      const double u1 = -(g[1] + hod * c0) / H[3];
+      consider(c0, clampd(u1, lo[1], hi[1]), 0, (u1 >= lo[1] && u1 <= hi[1]) ? 1 : 0);
+      const double c1 = b ? hi[1] : lo[1];
+      const double u0 = -(g[0] + hod * c1) / H[0];
+      consider(clampd(u0, lo[0], hi[0]), c1, (u0 >= lo[0] && u0 <= hi[0]) ? 1 : 0, 0);
+    }
+    return;
+  }
   for (int b = 0; b < 2; ++b) {
     const double c0 = b ? hi[0] : lo[0];
     if (H[3] > tiny) {

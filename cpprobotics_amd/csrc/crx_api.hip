@@ -744,7 +744,8 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
       }
     }
     // (b) stage the inputs of chunk `it` into its pinned slot (free once the H2D of chunk it - kRing has completed)
-    crxh::CopyPool::Ticket tin, tout;
+    crxh::CopyPool::Joined jin, jout;             // joined at the end of the trip — and on every early return
+    crxh::CopyPool::Ticket &tin = jin.t, &tout = jout.t;
     if (it < C && !direct_in) {
       const int sl = it % kRing;
       const size_t tc = steps_of(it);
@@ -763,8 +764,6 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
       if (x_hist) pool.submit(crxh::CopyPool::Job{xhrow(d), po, 16 * nl, tc, 16 * nn, 16 * nl}, &tout);
       if (P_hist) pool.submit(crxh::CopyPool::Job{Phrow(d), po + (x_hist ? hx : 0), 64 * nl, tc, 64 * nn, 64 * nl}, &tout);
     }
-    pool.wait(&tin);
-    pool.wait(&tout);
   }
   // final state (the compute stream is behind the last kernel); every history row has left the device before we return
   CRX_HIP(hipMemcpyAsync(pxP, dx, 16 * nl, hipMemcpyDeviceToHost, c->s_cmp));

@@ -45,6 +45,12 @@ class CopyPool {
     std::mutex m; std::condition_variable cv;
     void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return left.load() == 0; }); }
   };
+  // A ticket that joins when it goes out of scope: no early return (a failed HIP call between submit and wait) can leave pool
+  // threads writing through a dead ticket or into buffers the caller is about to hand back.
+  struct Joined {
+    Ticket t;
+    ~Joined() { CopyPool::get().wait(&t); }
+  };
   static CopyPool& get() { static CopyPool p; return p; }
   int threads() const { return (int)workers_.size(); }
 

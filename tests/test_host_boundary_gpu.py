@@ -136,6 +136,31 @@ def test_sharded_closed_loops_equal_unsharded(crx, oracle_mod, split3):
     assert bit_equal(sharded[0][0], so) and np.array_equal(sharded[0][1], tio) and bit_equal(sharded[0][2], histo)
 
 
+def test_concurrent_host_calls(crx, oracle_mod):
+    """Host threads calling host-pointer entry points at once (ctypes drops the GIL): the per-device context is locked for the
+    duration of a call, the shared workspaces are never used by two calls at a time, every result is the serial one."""
+    from concurrent.futures import ThreadPoolExecutor
+    Q, R = ekf_QR()
+    jobs = []
+    for k, (n, T) in enumerate([(30000, 24), (7, 9), (50000, 16), (1, 1), (20000, 40), (300, 30)]):
+        x0, P0, z, ud = _ekf_inputs(oracle_mod, n, T, seed=50 + k)
+        jobs.append((x0, P0, z, ud, crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)))
+    v = lqr_speeds(9000, seed=4)
+    dref = crx.host.dare_from_v(v, 5)
+
+    def ekf(j):
+        x0, P0, z, ud, ref = jobs[j % len(jobs)]
+        got = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)
+        return all(bit_equal(a, b) for a, b in zip(got[:3], ref[:3]))
+
+    def dare(_):
+        got = crx.host.dare_from_v(v, 5)
+        return all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(got, dref))
+    with ThreadPoolExecutor(6) as ex:
+        res = list(ex.map(lambda j: ekf(j) if j % 3 else dare(j), range(36)))
+    assert all(res)
+
+
 def test_device_selection(crx):
     import torch
     assert crx.host.get_device() == torch.cuda.current_device()

@@ -34,7 +34,7 @@ struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the re
   int max_iter;
 };
 
-constexpr double kTrustSteer = 0.4, kTrustAccel = 0.5;   // trust box of a Newton step, see backward()
+double kTrustSteer = 0.4, kTrustAccel = 0.5;   // trust box of a Newton step, see backward() (variables only for the round-4 portfolio experiment: oracle_mpc_trust)
 constexpr int NS = 6;  // x, y, yaw, v, previous delta, previous a
 constexpr int NU = 2;  // delta, a
 
@@ -441,6 +441,7 @@ void oracle_mpc_solve(int n, int T, const float* x0, const float* xref, const do
 
 void oracle_mpc_tune(int n_gn, double up, double down) { p_n_gn = n_gn; p_up = up; p_down = down; }
 void oracle_mpc_warm(int mode) { p_warm = mode; }
+void oracle_mpc_trust(double steer, double accel) { kTrustSteer = steer; kTrustAccel = accel; }
 
 // Debug aid for the tests: per-iteration (J, max|k|, mu, accepted alpha), 4 doubles x max_iter.
 int oracle_mpc_trace(int T, const float* x0, const float* xref, const double* params, int max_iter, double* trace) {

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "crx_host_alloc": (_P, [C.c_size_t]),
     "crx_host_free": (None, [_P]),
     "crx_release_workspace": (_I, []),
+    "crx_reserve_workspace": (_I, [C.c_size_t, C.c_size_t]),
     "crx_last_error": (C.c_char_p, []),
     "crx_ekf_default_params": (None, [C.POINTER(EkfParams)]),
     "crx_lqr_default_params": (None, [C.POINTER(LqrParams)]),

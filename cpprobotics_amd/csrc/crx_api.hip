@@ -320,6 +320,18 @@ int crx_release_workspace(void) {
   CRX_HIP(hipSetDevice(cur));
   return CRX_OK;
 }
+// Grow the current device's workspaces ahead of time (a latency-sensitive host calls this once at start-up with the sizes of its
+// largest call, so that no call pays for the growth: hipMalloc / hipHostMalloc of hundreds of MB take tens of milliseconds).
+int crx_reserve_workspace(size_t device_bytes, size_t pinned_bytes) {
+  CRX_TRACE();
+  crxh::DeviceCtx* c = nullptr;
+  std::unique_lock<std::mutex> lock;
+  if (int rc = ctx_open(&c, lock)) return rc;
+  hipError_t e = c->dws.reserve(device_bytes);
+  if (e == hipSuccess) e = c->pws.reserve(pinned_bytes);
+  if (e != hipSuccess) { hip_fail(e, "reserve_workspace"); return CRX_ERR_ALLOC; }
+  return CRX_OK;
+}
 int crx_shutdown(void) {
   if (crx_device_count() == 0) return CRX_OK;
   if (int rc = crx_release_workspace()) return rc;

@@ -45,6 +45,11 @@ def get_devices():
     return list(arr[:n])
 
 
+def reserve_workspace(device_bytes, pinned_bytes):
+    """Grow the current device's workspaces ahead of the first large call."""
+    L.check(L.lib().crx_reserve_workspace(int(device_bytes), int(pinned_bytes)), "crx_reserve_workspace")
+
+
 def release_workspace():
     L.check(L.lib().crx_release_workspace(), "crx_release_workspace")
 

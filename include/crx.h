@@ -68,6 +68,8 @@ int crx_get_devices(int* devices, int cap);   /* returns the size of the set (0:
 void* crx_host_alloc(size_t bytes);    /* pinned host memory (NULL on failure) */
 void crx_host_free(void* p);
 int crx_release_workspace(void);
+/* Grow the CURRENT device's workspaces now (sizes of the largest call to come), so that no later call pays for the growth. */
+int crx_reserve_workspace(size_t device_bytes, size_t pinned_bytes);
 
 /* ---- EKF localisation (src/extended_kalman_filter.cpp) --------------------------------- */
 typedef struct crx_ekf_params {

@@ -75,7 +75,8 @@ def test_workspace_is_reused_and_released(crx, oracle_mod):
     a = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)
     b = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)            # second call: no allocation
     crx.host.release_workspace()
-    c = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)            # grows again
+    crx.host.reserve_workspace(64 << 20, 64 << 20)                                      # ahead of time this time
+    c = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True)
     for r in (b, c):
         assert bit_equal(r[0], a[0]) and bit_equal(r[1], a[1]) and bit_equal(r[2], a[2])
     crx.host.release_workspace()

@@ -26,4 +26,4 @@ def test_device_entry_points_without_a_gpu(crx):
     assert l.crx_set_devices(None, 2, 1) == -2 and l.crx_set_devices(None, 0, 0) == 0 and l.crx_get_devices(None, 0) == 0
     assert l.crx_set_devices(None, -1, 0) == -1
     assert not l.crx_host_alloc(64) and b"no HIP device" in l.crx_last_error()
-    assert l.crx_release_workspace() == 0 and l.crx_shutdown() == 0
+    assert l.crx_release_workspace() == 0 and l.crx_shutdown() == 0 and l.crx_reserve_workspace(1 << 20, 1 << 20) == -2

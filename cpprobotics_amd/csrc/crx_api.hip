@@ -139,9 +139,9 @@ class HostCall {
 
   int commit() {
     size_t total = 0, biggest_row = 0;
-    for (auto& a : args_) { total += crxh::align_up(a.row_bytes * a.rows); biggest_row = std::max(biggest_row, a.row_bytes); }
+    for (auto& a : args_) { total += crxh::align_up(a.row_bytes * a.rows); if (a.rows > 1) biggest_row = std::max(biggest_row, a.row_bytes); }
     zc_ = allow_zc_ && total <= crxh::kZeroCopyBytes;
-    slot_ = std::max(crxh::kStageChunk, crxh::align_up(std::min<size_t>(biggest_row, 64u << 20)));
+    slot_ = std::max(crxh::kStageChunk, crxh::align_up(biggest_row));      // a staging slot holds at least one row of every strided argument
     hipError_t e = zc_ ? c_->pws.reserve(total) : c_->dws.reserve(total);
     if (e == hipSuccess && !zc_) e = c_->pws.reserve(2 * slot_);
     if (e != hipSuccess) { hip_fail(e, zc_ ? "hipHostMalloc (pinned workspace)" : "hipMalloc (device workspace)"); return CRX_ERR_ALLOC; }
@@ -199,7 +199,7 @@ class HostCall {
       CRX_HIP(hipMemcpyAsync(a.d, a.src, bytes, hipMemcpyHostToDevice, c_->s_cmp));
       return CRX_OK;
     }
-    if (!dense && a.row_bytes <= (64u << 20) && crxh::is_pinned(a.src)) {
+    if (!dense && crxh::is_pinned(a.src)) {
       CRX_HIP(hipMemcpy2DAsync(a.d, a.row_bytes, a.src, a.pitch, a.row_bytes, a.rows, hipMemcpyHostToDevice, c_->s_cmp));
       return CRX_OK;
     }
@@ -232,7 +232,7 @@ class HostCall {
       CRX_HIP(hipMemcpyAsync(a.dst, a.d, bytes, hipMemcpyDeviceToHost, c_->s_cmp));
       return CRX_OK;
     }
-    if (!dense && a.row_bytes <= (64u << 20) && crxh::is_pinned(a.dst)) {
+    if (!dense && crxh::is_pinned(a.dst)) {
       CRX_HIP(hipMemcpy2DAsync(a.dst, a.pitch, a.d, a.row_bytes, a.row_bytes, a.rows, hipMemcpyDeviceToHost, c_->s_cmp));
       return CRX_OK;
     }

@@ -677,17 +677,19 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
   CRX_TRY(ctx_open(&c, lock));
   const size_t nl = (size_t)(a1 - a0), nn = (size_t)n;
   const size_t per_step_in = 16 * nl, per_step_out = (x_hist ? 16 * nl : 0) + (P_hist ? 64 * nl : 0);
-  // steps per chunk: ~16 MB of the larger direction, at least 1, at most T
+  const bool direct_in = crxh::is_pinned(z) && crxh::is_pinned(u);
+  const bool direct_out = (!x_hist || crxh::is_pinned(x_hist)) && (!P_hist || crxh::is_pinned(P_hist));
+  // steps per chunk: ~16 MB of the larger direction when the chunk is staged by the copy threads (short enough to overlap, long
+  // enough to amortise the trip), ~64 MB when both directions are DMA'd in place; at least 1, at most T
   const size_t per_step = std::max(per_step_in, per_step_out);
-  size_t Tc = std::max<size_t>(1, (16u << 20) / per_step);
+  size_t Tc = std::max<size_t>(1, ((direct_in && direct_out) ? (64u << 20) : (16u << 20)) / per_step);
   Tc = std::min<size_t>(Tc, (size_t)T);
   const int C = (int)(((size_t)T + Tc - 1) / Tc);
   // a slot of the input ring is [z rows | u rows], of the output ring [x_hist rows | P_hist rows]; every part 256-byte aligned
   const size_t zb = crxh::align_up(8 * nl * Tc), inb = 2 * zb, hx = crxh::align_up(16 * nl * Tc);
   const size_t outb = (x_hist ? hx : 0) + (P_hist ? crxh::align_up(64 * nl * Tc) : 0);
   const size_t xb = crxh::align_up(16 * nl), Pb = crxh::align_up(64 * nl);
-  const bool direct_in = crxh::is_pinned(z) && crxh::is_pinned(u);
-  const bool direct_out = (!x_hist || crxh::is_pinned(x_hist)) && (!P_hist || crxh::is_pinned(P_hist));
+  const bool whole = nl == nn;                       // the shard is the whole batch: a chunk's rows are one contiguous block
   hipError_t e = c->dws.reserve(xb + Pb + kRing * (inb + outb));
   if (e == hipSuccess) e = c->pws.reserve(xb + Pb + (direct_in ? 0 : kRing * inb) + (direct_out ? 0 : kRing * outb));
   if (e != hipSuccess) { hip_fail(e, "workspace (ekf_run)"); return CRX_ERR_ALLOC; }
@@ -724,7 +726,10 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
       char* dz = din + (size_t)sl * inb;
       char* du = dz + zb;
       if (k >= kRing) CRX_HIP(hipStreamWaitEvent(c->s_in, c->ev_cmp[sl], 0));          // the kernel of chunk k - kRing has read this slot
-      if (direct_in) {
+      if (direct_in && whole) {
+        CRX_HIP(hipMemcpyAsync(dz, zrow(k), 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));
+        CRX_HIP(hipMemcpyAsync(du, urow(k), 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));
+      } else if (direct_in) {
         CRX_HIP(hipMemcpy2DAsync(dz, 8 * nl, zrow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
         CRX_HIP(hipMemcpy2DAsync(du, 8 * nl, urow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
       } else {
@@ -744,7 +749,10 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
       CRX_HIP(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
       if (per_step_out) {
         CRX_HIP(hipStreamWaitEvent(c->s_out, c->ev_cmp[sl], 0));
-        if (direct_out) {
+        if (direct_out && whole) {
+          if (x_hist) CRX_HIP(hipMemcpyAsync(xhrow(k), dxh, 16 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpyAsync(Phrow(k), dPh, 64 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+        } else if (direct_out) {
           if (x_hist) CRX_HIP(hipMemcpy2DAsync(xhrow(k), 16 * nn, dxh, 16 * nl, 16 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
           if (P_hist) CRX_HIP(hipMemcpy2DAsync(Phrow(k), 64 * nn, dPh, 64 * nl, 64 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
         } else {

@@ -26,6 +26,8 @@
 namespace {
 
 int p_n_gn = 2; double p_up = 10.0, p_down = 0.1;  // tuning knobs (set through oracle_mpc_tune)
+int p_trust_mode = 0;  // experiment knob (oracle_mpc_trust_mode): 0 = trust box on every Newton sweep (the engine), 1 = only after the first refused Newton step, 2 = doubled after every accepted full step, back to the base after a refused one
+thread_local double t_trust_scale = 1.0; thread_local bool t_trust_on = true;
 int p_warm = 0;       // experiment knob (oracle_mpc_warm): 0 = the reference's zero initial guess (:266-274), 1 / 2 = see solve_one
 
 struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the reference's #defines
@@ -243,9 +245,10 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     // whole tail of the iteration-count distribution (on the BASELINE batch: 50-iteration cap hit by 3 agents, 22+ by 8;
     // with the trust box every agent converges in <= 21, with the active set above in <= 16).  Gauss-Newton steps (positive definite) are not restricted.
     if (exact) {
-      lo[0] = lo[0] < -kTrustSteer ? -kTrustSteer : lo[0]; hi[0] = hi[0] > kTrustSteer ? kTrustSteer : hi[0];
-      if (lo[1] < -kTrustAccel) { lo[1] = -kTrustAccel; sp_lo = false; }     // that end of the box is no longer the speed bound's
-      if (hi[1] > kTrustAccel) { hi[1] = kTrustAccel; sp_hi = false; }
+      const double tS = t_trust_on ? kTrustSteer * t_trust_scale : 1e9, tA = t_trust_on ? kTrustAccel * t_trust_scale : 1e9;
+      lo[0] = lo[0] < -tS ? -tS : lo[0]; hi[0] = hi[0] > tS ? tS : hi[0];
+      if (lo[1] < -tA) { lo[1] = -tA; sp_lo = false; }     // that end of the box is no longer the speed bound's
+      if (hi[1] > tA) { hi[1] = tA; sp_hi = false; }
     }
     if (hold0) { lo[0] = 0.0; hi[0] = 0.0; }
     if (hold1) { lo[1] = 0.0; hi[1] = 0.0; }
@@ -341,6 +344,7 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
   int status = 0, it = 0;
   const int n_gn = p_n_gn;
   const double lb[2] = {-p.max_steer, -p.max_accel}, ub[2] = {p.max_steer, p.max_accel};
+  t_trust_scale = 1.0; t_trust_on = (p_trust_mode != 1);
   int gn_left = n_gn;   // Gauss-Newton iterations still to do before the next exact (Newton) attempt
   int gn_run = n_gn;    // ... and how many follow a failed one: doubles (up to 16) with every failure
   for (it = 0; it < p.max_iter; ++it) {
@@ -383,6 +387,8 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
         break;
       }
     }
+    if (p_trust_mode == 2 && exact) t_trust_scale = (accepted && alpha == 1.0) ? (t_trust_scale * 2.0 > 8.0 ? 8.0 : t_trust_scale * 2.0) : 1.0;
+    if (p_trust_mode == 1 && exact && !accepted) t_trust_on = true;
     if (accepted) {
       if (gn_left > 0) gn_left--;
       mu = (alpha == 1.0) ? mu * p_down : mu;
@@ -441,6 +447,7 @@ void oracle_mpc_solve(int n, int T, const float* x0, const float* xref, const do
 
 void oracle_mpc_tune(int n_gn, double up, double down) { p_n_gn = n_gn; p_up = up; p_down = down; }
 void oracle_mpc_warm(int mode) { p_warm = mode; }
+void oracle_mpc_trust_mode(int mode) { p_trust_mode = mode; }
 void oracle_mpc_trust(double steer, double accel) { kTrustSteer = steer; kTrustAccel = accel; }
 
 // Debug aid for the tests: per-iteration (J, max|k|, mu, accepted alpha), 4 doubles x max_iter.

@@ -44,3 +44,26 @@ for seed in (4,5,6,7):
     best.sort()
     for b in best[:6]: print("   ",b)
     # cost differences of winners vs base
+
+
+# ---- second experiment: when the trust box of a Newton step applies -------------------------------------------------------------
+# mode 0 = on every Newton sweep (the engine); 1 = only after the first refused Newton step; 2 = doubled (up to 8x) after every accepted
+# full step, back to the base after a refused one.  Result: modes 1 and 2 lower the MEAN (6.8 -> 6.4 / 6.6 sweeps) and lengthen the TAIL
+# (slowest agent 16-28 -> 17-50, a few agents no longer converge) — the launch time is the tail.
+print("\nseed trust-mode | mean sweeps, slowest agent, mean of wave max, converged, agents ending lower / higher in cost than mode 0")
+def run_trust_mode(x0,xref,T,mode):
+    lib.oracle_mpc_trust_mode(mode)
+    n=len(x0); cuts=[n*k//TH for k in range(TH+1)]; res=[None]*TH
+    def f(k): res[k]=oracle.mpc_solve(x0[cuts[k]:cuts[k+1]], xref[cuts[k]:cuts[k+1]], T)
+    with ThreadPoolExecutor(TH) as ex: list(ex.map(f, range(TH)))
+    lib.oracle_mpc_trust_mode(0)
+    return tuple(np.concatenate([r[j] for r in res]) for j in range(3))
+for seed in (4,5,6,7,8,9):
+    x0,xref=mpc_problem(8192,21,seed)
+    base=None
+    for mode in (0,1,2):
+        sol,st,c=run_trust_mode(x0,xref,21,mode)
+        it=(st>>8); conv=(st&1)==1
+        if mode==0: base=c
+        d=c-base; s_=np.maximum(1,abs(base))
+        print(seed,mode,"mean %.2f max %d wavemax %.2f conv %.5f lower %d higher %d"%(it.mean(),it.max(),it.reshape(-1,64).max(axis=1).mean(),conv.mean(),(d<-1e-6*s_).sum(),(d>1e-6*s_).sum()))

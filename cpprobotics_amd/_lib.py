@@ -65,6 +65,7 @@ _SIGNATURES = {
     "crx_init": (_I, []),
     "crx_shutdown": (_I, []),
     "crx_device_count": (_I, []),
+    "crx_host_libm_check": (_I, []),
     "crx_set_device": (_I, [_I]),
     "crx_get_device": (_I, []),
     "crx_set_devices": (_I, [_P, _I, _I]),

@@ -388,6 +388,36 @@ int crx_get_devices(int* devices, int cap) {
   for (int i = 0; i < (int)s.devs.size() && i < cap && devices; ++i) devices[i] = s.devs[i];
   return (int)s.devs.size();
 }
+// Do the libm functions of THIS host return the bits the engine's restatements return (crx_trig.h, crx_fdlibm.h, crx_dsincos.h,
+// crx_datan2.h: glibc 2.35, x86-64 FMA build)?  Bit parity with a reference built on this host holds only if they do — the
+// reference calls the host's libm, the kernels carry the restatements.  200,000 pseudo-random arguments per family (a few ms):
+// 0 = all equal; bit 0: sinf / cosf, bit 1: expf, bit 2: atanf / atan2f / tanf / acosf, bit 3: double sin / cos (arguments of the
+// form (double)f + pi/2, the Frenet planner's), bit 4: double atan2(y, 1.0).  Needs no device.
+int crx_host_libm_check(void) {
+  unsigned long long st = 0x9e3779b97f4a7c15ull;
+  auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  auto same32 = [](float a, float b) { return std::memcmp(&a, &b, 4) == 0 || (a != a && b != b); };
+  auto same64 = [](double a, double b) { return std::memcmp(&a, &b, 8) == 0 || (a != a && b != b); };
+  int bad = 0;
+  for (int i = 0; i < 200000; ++i) {
+    const unsigned long long r = next();
+    // a float spread over the magnitudes the path sees: |x| from 2^-20 to 2^12, either sign
+    const float mag = std::ldexp(1.0f + (float)((r >> 8) & 0x7fffff) / 8388608.0f, (int)(r % 33) - 20);
+    const float x = (r >> 63) ? -mag : mag;
+    const float unit = (float)((double)((r >> 20) & 0xffffff) / 8388608.0 - 1.0);             // [-1, 1)
+    if (!same32(::sinf(x), crx::sinf_(x)) || !same32(::cosf(x), crx::cosf_(x))) bad |= 1;
+    if (!same32(::expf(-0.5f * mag), crx::expf_(-0.5f * mag))) bad |= 2;
+    if (!same32(::atanf(x), crx::atanf_(x)) || !same32(::atan2f(x, unit), crx::atan2f_(x, unit)) || !same32(::tanf(x), crx::tanf_(x)) ||
+        !same32(::acosf(unit), crx::acosf_(unit))) bad |= 4;
+    const float yaw = 3.2f * unit;
+    const double xd = (double)yaw + M_PI / 2.0;
+    if (!same64(::sin(xd), crx::dsin_(xd)) || !same64(::cos(xd), crx::dcos_(xd))) bad |= 8;
+    const double y = 0.5 * (double)x;
+    if (!same64(::atan2(y, (double)1.0), crx::datan2_one_(y))) bad |= 16;
+  }
+  return bad;
+}
+
 // Pinned (page-locked, device-visible) host memory: arrays allocated here cross PCIe by DMA straight from / into the caller's
 // memory, without the staging copy pageable memory needs.
 void* crx_host_alloc(size_t bytes) {

@@ -43,6 +43,12 @@ int crx_shutdown(void);                /* optional: drain the devices, release w
 int crx_device_count(void);            /* number of HIP devices visible (0 if none)       */
 const char* crx_last_error(void);      /* thread-local, never NULL                        */
 
+/* Bit parity with a reference built on a given host needs that host's libm to be the one the kernels restate (glibc 2.35's
+ * x86-64 FMA build: sinf, cosf, expf, atanf, atan2f, tanf, acosf, double sin / cos / atan2).  crx_host_libm_check() compares the
+ * two on 200,000 pseudo-random arguments per family and returns 0 when all agree, else a bit mask (bit 0 sinf / cosf, 1 expf,
+ * 2 atanf / atan2f / tanf / acosf, 3 double sin / cos, 4 double atan2(y, 1)).  Needs no device; a few milliseconds. */
+int crx_host_libm_check(void);
+
 /* Devices (since 0.4).  The `_dev` entry points launch on the calling thread's current device (crx_set_device = hipSetDevice);
  * their pointers and stream must belong to it.  The host-pointer entry points use the calling thread's current device too —
  * unless a device set is installed: then every host-pointer BATCH entry point (crx_ekf_run_batch, crx_ekf_step_batch,

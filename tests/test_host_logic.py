@@ -27,3 +27,10 @@ def test_device_entry_points_without_a_gpu(crx):
     assert l.crx_set_devices(None, -1, 0) == -1
     assert not l.crx_host_alloc(64) and b"no HIP device" in l.crx_last_error()
     assert l.crx_release_workspace() == 0 and l.crx_shutdown() == 0 and l.crx_reserve_workspace(1 << 20, 1 << 20) == -2
+
+
+def test_host_libm_is_the_one_the_kernels_restate(crx):
+    """crx_host_libm_check: this host's libm (the oracle's sinf / cosf / expf / atan2f / tanf / acosf / sin / cos / atan2) against the
+    engine's restatements on 200,000 pseudo-random arguments per family — a host-side regression test of every restated libm
+    function at once, and the check a maintainer runs on a new host before trusting bit parity there."""
+    assert crx.lib().crx_host_libm_check() == 0

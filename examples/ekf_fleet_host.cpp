@@ -4,7 +4,8 @@
 // splits the vehicles over every visible GPU (one host thread and one set of streams per GPU, no collective).
 //
 //   g++ -O2 -std=c++17 -I include examples/ekf_fleet_host.cpp -o ekf_fleet_host -L cpprobotics_amd -lcrx -Wl,-rpath,$PWD/cpprobotics_amd
-//   ./ekf_fleet_host [n=65536] [T=500] [gpus=all visible] [pinned=0]
+//   ./ekf_fleet_host [n=65536] [T=500] [gpus=all visible] [pinned=0] [split=0]
+//   (split = k > 0: name device 0 k times in the device set — k shards on one GPU, the code path of a k-GPU host; same results)
 //
 // The loop of main() (:171-188) for every vehicle: the input side (ud = u + noise, xTrue = motion_model(xTrue, u), z = position +
 // noise, :174-181) is evaluated here on the host with the reference's own statements, the T ekf_estimation() calls (:183) are ONE
@@ -14,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <vector>
 #include "crx.h"
@@ -27,6 +29,7 @@ int main(int argc, char** argv) {
   if (have == 0) { std::fprintf(stderr, "no HIP device visible: crx has no CPU fallback\n"); return 1; }
   const int g = std::max(1, std::min(argc > 3 ? std::atoi(argv[3]) : have, have));
   const bool pinned = argc > 4 && std::atoi(argv[4]) != 0;
+  const int split = argc > 5 ? std::atoi(argv[5]) : 0;
   const size_t nn = (size_t)n, tt = (size_t)T;
   const double DT = 0.1;
 
@@ -61,7 +64,12 @@ int main(int argc, char** argv) {
       z[(t * nn + a) * 2 + 1] = x[1] + gaussian_d(gen) * rsim;
     }
 
-  CRX_OK_(crx_set_devices(nullptr, g, 4096));                                  // devices 0 .. g-1; at least 4,096 vehicles per GPU
+  if (split > 0) {
+    std::vector<int> same(split, 0);
+    CRX_OK_(crx_set_devices(same.data(), split, 1));                           // `split` shards, all on device 0
+  } else {
+    CRX_OK_(crx_set_devices(nullptr, g, 4096));                                // devices 0 .. g-1; at least 4,096 vehicles per GPU
+  }
   CRX_OK_(crx_ekf_run_batch(std::min(n, 4096), 1, xEst.data(), PEst.data(), z, ud, nullptr, nullptr, Q, R, nullptr));   // warm-up: contexts, code objects
   std::fill(xEst.begin(), xEst.end(), 0.0f);
   std::fill(PEst.begin(), PEst.end(), 0.0f);
@@ -79,8 +87,10 @@ int main(int argc, char** argv) {
   const double gb = 32.0 * nn * tt / 1e9;
   std::printf("fleet of %d vehicles x %d steps, host arrays (%s) over %d GPU(s): %.2f ms per call = %.2f G EKF updates/s, %.1f GB/s across the "
               "boundary (z, u in; trajectory out)\n", n, T, pinned ? "pinned" : "pageable", g, best * 1e3, nn * tt / best / 1e9, gb / best);
-  std::printf("mean final position error of the estimate: %.3f m; last estimate of vehicle 0 in the trajectory: (%.3f, %.3f)\n", e_est / n,
-              hist[((tt - 1) * nn) * 4 + 0], hist[((tt - 1) * nn) * 4 + 1]);
+  unsigned long long sum = 0;                                                  // checksum of every estimate of the trajectory
+  for (size_t i = 0; i < 4 * nn * tt; ++i) { unsigned w; std::memcpy(&w, &hist[i], 4); sum = sum * 1099511628211ull + w; }
+  std::printf("mean final position error of the estimate: %.3f m; last estimate of vehicle 0 in the trajectory: (%.3f, %.3f); "
+              "trajectory checksum %016llx\n", e_est / n, hist[((tt - 1) * nn) * 4 + 0], hist[((tt - 1) * nn) * 4 + 1], sum);
   if (pinned) { crx_host_free(z); crx_host_free(ud); crx_host_free(hist); }
   CRX_OK_(crx_shutdown());
   return (e_est / n < 1.0) ? 0 : 4;

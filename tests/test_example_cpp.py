@@ -64,9 +64,15 @@ def test_host_example_builds_with_a_plain_cxx_compiler_and_fails_loudly_without_
 def test_host_example_runs(host_exe, pinned):
     """The fleet through the host-pointer entry point (std::vector or pinned arrays), sharded over every visible GPU by
     crx_set_devices: the estimate tracks the truth."""
+    import re
     r = subprocess.run([host_exe, "20000", "120", "99", pinned], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "GB/s across the boundary" in r.stdout
+    # the same fleet split into three shards (device 0 named three times: the code path of a 3-GPU C++ host): the same trajectory, bit for bit
+    r3 = subprocess.run([host_exe, "20000", "120", "99", pinned, "3"], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    c1, c3 = (re.search(r"trajectory checksum ([0-9a-f]{16})", o.stdout) for o in (r, r3))
+    assert c1 and c3 and c1.group(1) == c3.group(1), (r.stdout, r3.stdout)
 
 
 def test_planner_example_builds_and_fails_loudly_without_gpu(planner_exe):

@@ -57,7 +57,7 @@ int crx_host_libm_check(void);
  * keep min_agents_per_device agents each —, one host thread and one set of streams per shard, results landing directly in the
  * caller's arrays.  No collective: agents never read one another (src/extended_kalman_filter.cpp:64-78,
  * src/lqr_speed_steer_control.cpp:85-151, src/model_predictive_control.cpp:255-346).  The result does not depend on the
- * partition (tests/test_multi_device.py: a forced split equals the unsplit call bit for bit).  Shared inputs (Q, R, params, the
+ * partition (tests/test_host_boundary_gpu.py: a forced 3-way split on one GPU equals the unsplit call bit for bit).  Shared inputs (Q, R, params, the
  * course) are replicated.  ndev = 0 removes the set; devices = NULL means 0 .. ndev-1; a device may be listed more than once.
  * Serves the reference's fleet-sized callers: the EKF main loop (src/extended_kalman_filter.cpp:171-183) and the tracking loops
  * (src/lqr_speed_steer_control.cpp:194-205, src/model_predictive_control.cpp:371-385) for n vehicles on 1 .. N GPUs. */

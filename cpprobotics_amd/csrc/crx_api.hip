@@ -1041,6 +1041,20 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
   CRX_TRACE();
   return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, 0);
 }
+// mpc_solve for n agents with the four-variant portfolio (mpc_kernels.hip.h: mpc_variant): the same NLP, every agent answered by the
+// variant of the solver that converges in the fewest sweeps.
+int crx_mpc_solve_portfolio_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                                      float* sol, int* status, double* cost, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (portfolio): bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_portfolio_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc portfolio launch");
+}
 int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int lanes_per_agent) {
   CRX_TRACE();

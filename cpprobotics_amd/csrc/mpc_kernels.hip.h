@@ -214,14 +214,31 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   f0 = interior || (bf & 1); f1 = interior || (bf & 2);
 }
 
+// The variants of the PORTFOLIO solve (crx_mpc_solve_portfolio_batch_dev; round 4).  The BASELINE batch leaves 7/8 of the SIMDs idle
+// and its launch lasts as long as its slowest agent's chain of sweeps; different globalisation settings have different stragglers
+// (profiles/r04/mpc_experiments.txt).  In the portfolio an agent is a quad of lanes, lane r solving the SAME problem with variant r
+// — the number of leading Gauss-Newton sweeps and the size of a Newton step's trust box — in lockstep; the first variant to converge
+// (fewest sweeps; ties: lowest r) is the agent's answer and stops its siblings.  Variant 0 is the engine's solver: an agent never
+// needs more sweeps than crx_mpc_solve_batch_dev gives it.  Deterministic, and reproducible by the CPU twin (oracle_mpc_solve_portfolio),
+// which runs the four variants one after the other.
+struct MpcVariant { int n_gn; double trust_scale; };
+__device__ __forceinline__ MpcVariant mpc_variant(int r) {
+  return MpcVariant{r == 1 ? 3 : (r == 3 ? 1 : 2), r >= 2 ? 2.0 : 1.0};   // (2, 1) the engine's | (3, 1) | (2, 2) | (1, 2)
+}
+
 // One lane's solve.  xi = (x, y, yaw, v) of x0; xr4 = the lane's reference trajectory, T columns (x, y, yaw, v) — global memory
 // in mpc_kernel, the lane's private array in the closed loop; so (may be null) receives the solution in the reference's layout;
 // a0 / d0 = the first acceleration and steering of the solution rounded to float, what mpc_simulation applies (:376).
 // Wave-synchronous: every lane of the wave must call it (finished / padding lanes with live = false).
-template <int MAXT>
+// PORTFOLIO: the four lanes of a quad solve the same problem with mpc_variant(lane & 3); `so` and the outputs are valid on the
+// winning lane only (status_out < 0 on the others).
+template <int MAXT, bool PORTFOLIO = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, const float4 xi, const float4* __restrict__ xr4, const MpcP& p,
                                                float* __restrict__ so, int& status_out, double& cost_out, float& a0_out, float& d0_out) {
   const int N = T - 1;
+  const int quad_lane = (int)(threadIdx.x & 3);
+  const MpcVariant var = PORTFOLIO ? mpc_variant(quad_lane) : MpcVariant{2, 1.0};
+  const double trust_steer = kMpcTrustSteer * var.trust_scale, trust_accel = kMpcTrustAccel * var.trust_scale;
 
   // per-lane problem storage (private memory)
   double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
@@ -303,15 +320,20 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
 
   double mu = 0.0;
   const double mu_min = 1e-6, mu_max = 1e10;
-  const int n_gn = 2;
+  const int n_gn = var.n_gn;
   int gn_left = n_gn, gn_run = n_gn;
   int status = 0, it = 0;
   bool done = !live;
+  auto quad_converged = [&]() -> unsigned {       // which lanes of this lane's quad have converged (bit r = variant r)
+    const lanemask_t cm = lanes_where(live && (status & 1));
+    return (unsigned)(cm >> (threadIdx.x & 60)) & 0xFu;
+  };
 
 #ifdef CRX_MPC_TICKS
   long long tk_b = 0, tk_f = 0, tk_nb = 0, tk_nf = 0; const long long tk_0 = clock64();
 #endif
   for (int iter = 0; iter < p.max_iter; ++iter) {
+    if (PORTFOLIO) { if (quad_converged()) done = true; }      // a sibling variant has the answer: every lane of the quad stops
     if (__all(done)) break;
     if (done) continue;
     it = iter;
@@ -456,9 +478,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       // length, and the solver falls back to linearly converging Gauss-Newton steps: that is the whole tail of the
       // iteration-count distribution.  Gauss-Newton steps are not restricted.
       if (exact) {
-        lo0 = fmax(lo0, -kMpcTrustSteer); hi0 = fmin(hi0, kMpcTrustSteer);
-        if (lo1 < -kMpcTrustAccel) { lo1 = -kMpcTrustAccel; ab.sp_lo = false; }
-        if (hi1 > kMpcTrustAccel) { hi1 = kMpcTrustAccel; ab.sp_hi = false; }
+        lo0 = fmax(lo0, -trust_steer); hi0 = fmin(hi0, trust_steer);
+        if (lo1 < -trust_accel) { lo1 = -trust_accel; ab.sp_lo = false; }
+        if (hi1 > trust_accel) { hi1 = trust_accel; ab.sp_hi = false; }
       }
       if (hold0) { lo0 = 0.0; hi0 = 0.0; }
       if (hold1) { lo1 = 0.0; hi1 = 0.0; }
@@ -638,6 +660,14 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
     if (iter == p.max_iter - 1) it = p.max_iter;
   }
   status_out = 0; cost_out = 0.0; a0_out = 0.0f; d0_out = 0.0f;
+  if (PORTFOLIO) {
+    // the agent's answer: the converged variant of lowest index; if none converged within max_iter sweeps, variant 0's iterate
+    const unsigned q = quad_converged();
+    const int winner = q ? (__builtin_ctz(q)) : 0;
+    status_out = -1;
+    if (quad_lane != winner) return;
+    if (live) status |= winner << 2;
+  }
   if (!live) return;
   if (!(status & 1) && !done) it = p.max_iter;
   for (int i = 0; i < T; ++i) {
@@ -694,6 +724,47 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
+}
+
+// The portfolio launch: agent a on lanes 4a .. 4a+3 (16 agents per wave, single-wave workgroups): 4x the waves of mpc_kernel — at the
+// BASELINE batch 512 waves on 1,024 SIMDs, still one per SIMD.
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_portfolio_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+                     float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  const size_t agent = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const bool live = agent < (size_t)n;
+  const size_t ag = live ? agent : 0;
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + ag * (size_t)T;
+  const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
+  const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, true>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  if (!live || status < 0) return;                      // the winning lane of the quad reports
+  if (statusg) statusg[agent] = status;
+  if (costg) costg[agent] = J;
+}
+
+inline MpcP mpc_pack(const crx_mpc_params& q) {
+  MpcP p;
+  p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
+  p.max_speed = q.max_speed; p.min_speed = q.min_speed;
+  p.r_a = q.r_a; p.r_d = q.r_delta; p.rd_a = q.rd_a; p.rd_d = q.rd_delta;
+  p.qx = q.q_x; p.qy = q.q_y; p.qyaw = q.q_yaw; p.qv = q.q_v; p.tol = q.tol; p.max_iter = q.max_iter;
+  return p;
+}
+
+inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                       int* status, double* cost, hipStream_t stream) {
+  const MpcP p = mpc_pack(q);
+  const dim3 grid((unsigned)((4 * (size_t)n + 63) / 64)), block(64);
+  if (T <= 8)
+    hipLaunchKernelGGL((mpc_portfolio_kernel<8>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  else if (T <= 24)
+    hipLaunchKernelGGL((mpc_portfolio_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  else
+    hipLaunchKernelGGL((mpc_portfolio_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
 }
 
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,

@@ -19,7 +19,10 @@ def default_params():
     return p
 
 
-def mpc_solve(x0, xref, T, params=None, return_status=False):
+def mpc_solve(x0, xref, T, params=None, return_status=False, portfolio=False):
+    """mpc_solve(State, M_XREF) for n agents (device tensors).  portfolio=True: the four-variant portfolio solve
+    (crx_mpc_solve_portfolio_batch_dev): same NLP, every agent answered by the solver variant that converges in the fewest sweeps;
+    status bits 2-3 then carry the winning variant."""
     import torch
     L.require_cuda(x0, xref)
     n = x0.shape[0]
@@ -28,8 +31,9 @@ def mpc_solve(x0, xref, T, params=None, return_status=False):
     sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
     status = torch.empty((n,), dtype=torch.int32, device=x0.device)
     cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
-    L.check(L.lib().crx_mpc_solve_batch_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status),
-                                            L.ptr(cost), L.stream_ptr()), "crx_mpc_solve_batch_dev")
+    fn = L.lib().crx_mpc_solve_portfolio_batch_dev if portfolio else L.lib().crx_mpc_solve_batch_dev
+    L.check(fn(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost), L.stream_ptr()),
+            "crx_mpc_solve_portfolio_batch_dev" if portfolio else "crx_mpc_solve_batch_dev")
     if return_status:
         return sol, status, cost
     return sol

@@ -28,6 +28,7 @@ namespace {
 int p_n_gn = 2; double p_up = 10.0, p_down = 0.1;  // tuning knobs (set through oracle_mpc_tune)
 int p_trust_mode = 0;  // experiment knob (oracle_mpc_trust_mode): 0 = trust box on every Newton sweep (the engine), 1 = only after the first refused Newton step, 2 = doubled after every accepted full step, back to the base after a refused one
 thread_local double t_trust_scale = 1.0; thread_local bool t_trust_on = true;
+thread_local int t_variant_n_gn = -1; thread_local double t_variant_trust = 1.0;   // the variant of a portfolio solve (oracle_mpc_solve_portfolio)
 int p_warm = 0;       // experiment knob (oracle_mpc_warm): 0 = the reference's zero initial guess (:266-274), 1 / 2 = see solve_one
 
 struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the reference's #defines
@@ -245,7 +246,7 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     // whole tail of the iteration-count distribution (on the BASELINE batch: 50-iteration cap hit by 3 agents, 22+ by 8;
     // with the trust box every agent converges in <= 21, with the active set above in <= 16).  Gauss-Newton steps (positive definite) are not restricted.
     if (exact) {
-      const double tS = t_trust_on ? kTrustSteer * t_trust_scale : 1e9, tA = t_trust_on ? kTrustAccel * t_trust_scale : 1e9;
+      const double tS = t_trust_on ? kTrustSteer * t_variant_trust * t_trust_scale : 1e9, tA = t_trust_on ? kTrustAccel * t_variant_trust * t_trust_scale : 1e9;
       lo[0] = lo[0] < -tS ? -tS : lo[0]; hi[0] = hi[0] > tS ? tS : hi[0];
       if (lo[1] < -tA) { lo[1] = -tA; sp_lo = false; }     // that end of the box is no longer the speed bound's
       if (hi[1] > tA) { hi[1] = tA; sp_hi = false; }
@@ -342,7 +343,7 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
   double mu = 0.0;
   const double mu_min = 1e-6, mu_max = 1e10;
   int status = 0, it = 0;
-  const int n_gn = p_n_gn;
+  const int n_gn = t_variant_n_gn >= 0 ? t_variant_n_gn : p_n_gn;
   const double lb[2] = {-p.max_steer, -p.max_accel}, ub[2] = {p.max_steer, p.max_accel};
   t_trust_scale = 1.0; t_trust_on = (p_trust_mode != 1);
   int gn_left = n_gn;   // Gauss-Newton iterations still to do before the next exact (Newton) attempt
@@ -442,6 +443,37 @@ void oracle_mpc_solve(int n, int T, const float* x0, const float* xref, const do
     const int st = solve_one(p, T, x0 + 4 * k, xref + 4 * (size_t)T * k, sol + (size_t)nv * k, &J, &it);
     if (status) status[k] = st;
     if (cost) cost[k] = J;
+  }
+}
+
+// The four-variant portfolio of crx_mpc_solve_portfolio_batch_dev (csrc/mpc_kernels.hip.h: mpc_variant): variant r = (leading
+// Gauss-Newton sweeps, trust-box scale) = (2, 1) | (3, 1) | (2, 2) | (1, 2); the agent's answer is the converged variant with the
+// fewest sweeps (ties: lowest r), variant 0's iterate if none converges.  The kernel runs the variants in lockstep on a quad of lanes;
+// here they run one after the other.  status: as oracle_mpc_solve, plus the winning variant in bits 2-3.
+void oracle_mpc_solve_portfolio(int n, int T, const float* x0, const float* xref, const double* params, int max_iter,
+                                float* sol, int* status, double* cost, int a0, int a1) {
+  const MpcParams p = unpack(params, max_iter);
+  const int nv = 4 * T + 2 * (T - 1);
+  static const int kGn[4] = {2, 3, 2, 1};
+  static const double kTr[4] = {1.0, 1.0, 2.0, 2.0};
+  std::vector<float> cand(nv);
+  for (int k = a0; k < a1; ++k) {
+    int best_st = 0, best_it = 1 << 30; double best_J = 0.0; bool have = false;
+    for (int r = 0; r < 4; ++r) {
+      t_variant_n_gn = kGn[r]; t_variant_trust = kTr[r];
+      double J; int it;
+      const int st = solve_one(p, T, x0 + 4 * k, xref + 4 * (size_t)T * k, cand.data(), &J, &it);
+      const bool conv = (st & 1) != 0;
+      const bool take = conv ? (!have || it < best_it) : (r == 0);          // the first variant stands in until a converged one appears
+      if (take && (conv || !have)) {
+        std::memcpy(sol + (size_t)nv * k, cand.data(), sizeof(float) * nv);
+        best_st = (st & ~0xC) | (r << 2); best_J = J;
+        if (conv) { best_it = it; have = true; }
+      }
+    }
+    t_variant_n_gn = -1; t_variant_trust = 1.0;
+    if (status) status[k] = best_st;
+    if (cost) cost[k] = best_J;
   }
 }
 

@@ -192,6 +192,21 @@ def mpc_solve(x0, xref, T, params=None, max_iter=50, agents=None):
     return sol, status, cost
 
 
+def mpc_solve_portfolio(x0, xref, T, params=None, max_iter=50, agents=None):
+    """CPU twin of the engine's four-variant portfolio solve (crx_mpc_solve_portfolio_batch_dev).  Returns sol, status (winning variant
+    in bits 2-3), cost."""
+    x0, xref = _f32(x0), _f32(xref)
+    n = x0.shape[0]
+    nv = 4 * T + 2 * (T - 1)
+    sol = np.zeros((n, nv), dtype=np.float32)
+    status = np.zeros((n,), dtype=np.int32)
+    cost = np.zeros((n,), dtype=np.float64)
+    pp = _mpc_params(params)
+    a0, a1 = (0, n) if agents is None else agents
+    lib().oracle_mpc_solve_portfolio(_I(n), _I(T), _p(x0), _p(xref), _p(pp), _I(max_iter), _p(sol), _p(status), _p(cost), _I(a0), _I(a1))
+    return sol, status, cost
+
+
 def mpc_cost(x0, xref, T, U, params=None):
     """NLP objective of ONE agent for controls U [(T-1),2] (delta, a); returns (J, S [(T),6])."""
     x0, xref = _f32(x0), _f32(xref)

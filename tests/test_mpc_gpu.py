@@ -66,6 +66,58 @@ def test_mpc_speed_bounds_active(crx, oracle_mod, T, fast):
     assert (np.abs(v - bound) < 1e-5).sum(axis=1).min() >= 2
 
 
+def _portfolio_twin(oracle_mod, x0, xref, T):
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    n = len(x0)
+    k = max(1, min(len(os.sched_getaffinity(0)), n // 16 or 1))
+    cuts = [n * i // k for i in range(k + 1)]
+    with ThreadPoolExecutor(k) as ex:
+        parts = list(ex.map(lambda i: oracle_mod.mpc_solve_portfolio(x0[cuts[i]:cuts[i + 1]], xref[cuts[i]:cuts[i + 1]], T), range(k)))
+    return tuple(np.concatenate([p[j] for p in parts]) for j in range(3))
+
+
+@pytest.mark.parametrize("T", [6, 21, 30])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 700])
+def test_mpc_portfolio_matches_cpu_twin(crx, oracle_mod, n, T):
+    """crx_mpc_solve_portfolio_batch_dev — an agent on a quad of lanes, four variants of the solver's globalisation in lockstep, the
+    first to converge wins — against the twin that runs the four variants one after the other: the same winner, the same sweep count,
+    the same status bits on EVERY agent, the solution to 1e-6, the cost to 1e-9; never more sweeps than the engine's own solver
+    (variant 0), whose answer it is bit for bit wherever variant 0 wins; ragged last quad / wave."""
+    x0, xref = mpc_problem(n, T, seed=3 * n + T)
+    so, sto, co = _portfolio_twin(oracle_mod, x0, xref, T)
+    sd, std, cd = crx.mpc_solve(_t(x0), _t(xref), T, return_status=True, portfolio=True)
+    sd, std, cd = sd.cpu().numpy(), std.cpu().numpy(), cd.cpu().numpy()
+    assert np.array_equal(std & 0xF, sto & 0xF), f"status / winner differs for agents {np.flatnonzero((std & 0xF) != (sto & 0xF))[:8]}"
+    assert np.array_equal(std >> 8, sto >> 8)
+    conv = (sto & 1) == 1
+    assert conv.mean() >= (0.95 if n > 1 else 1.0)
+    assert floored_rel_err(sd[conv], so[conv], 1.0) <= TOL
+    crel = np.abs(cd - co) / np.maximum(np.abs(co), 1.0)
+    assert crel[conv].max(initial=0.0) <= 1e-9 and crel.max(initial=0.0) <= 1e-6
+    sb, stb, cb = crx.mpc_solve(_t(x0), _t(xref), T, return_status=True)
+    sb, stb, cb = sb.cpu().numpy(), stb.cpu().numpy(), cb.cpu().numpy()
+    bconv = (stb & 1) == 1
+    assert ((std >> 8)[bconv] <= (stb >> 8)[bconv]).all()                       # never slower than the engine's own solver
+    v0 = ((std >> 2) & 3) == 0
+    assert np.array_equal(sd[v0], sb[v0]) and np.array_equal(cd[v0], cb[v0])    # where variant 0 wins, it is that solver's answer
+    N = T - 1
+    assert np.all(np.abs(sd[:, 4 * T:4 * T + N]) <= np.float32(np.pi / 4) + 1e-6) and np.all(np.abs(sd[:, 4 * T + N:]) <= 1.0 + 1e-6)
+    assert np.array_equal(sd[:, [0, T, 2 * T, 3 * T]], x0)
+
+
+def test_mpc_portfolio_full_size_tail(crx, oracle_mod):
+    """BASELINE configs[3] through the portfolio: every agent converges and the slowest needs at most 14 sweeps (16 with the engine's
+    own solver; 13-14 against 16-28 on six seeds of the twin, profiles/r04/mpc_experiments.txt); twin parity on the first 1,024."""
+    x0, xref = mpc_problem(8192, 21, 4)
+    sd, std, cd = crx.mpc_solve(_t(x0), _t(xref), 21, return_status=True, portfolio=True)
+    std = std.cpu().numpy()
+    assert ((std & 1) == 1).all() and (std >> 8).max() <= 14
+    so, sto, co = _portfolio_twin(oracle_mod, x0[:1024], xref[:1024], 21)
+    assert np.array_equal(std[:1024] & 0xF, sto & 0xF) and np.array_equal(std[:1024] >> 8, sto >> 8)
+    assert floored_rel_err(sd.cpu().numpy()[:1024], so, 1.0) <= TOL
+
+
 def test_mpc_start_speed_outside_the_bounds(crx, oracle_mod):
     x0, xref = speed_bound_problems(70, 6, 90, True)
     x0[:, 3] = np.float32(17.0)                      # above MAX_SPEED: the acceleration limits win, status bit 1 says so

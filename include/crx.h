@@ -204,8 +204,9 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,
  * box of a Newton step x1 / x1 / x2 / x2; variant 0 is crx_mpc_solve_batch_dev's solver): an agent is a quad of lanes, the variants
  * run in lockstep and the first to converge — fewest sweeps, ties to the lowest variant — is the agent's answer.  Same NLP, same
  * tolerance, same layout of sol; never more sweeps than crx_mpc_solve_batch_dev and a far shorter tail (slowest agent of 8,192: 13-14
- * sweeps on six seeds against 16-28), at four times the lanes: for batches that leave the GPU idle (<= ~16 k agents), where the
- * launch lasts as long as its slowest agent.  In rare cases the winning variant settles in a different local optimum of the
+ * sweeps on six seeds against 16-28), at four times the lanes and a dearer sweep: for batches that leave the GPU idle (<= 8 k agents),
+ * where the launch lasts as long as its slowest agent — measured 1.01-1.53x at 8,192 agents x T = 21, < 1 at T = 6 and at 16,384
+ * agents without a straggler (profiles/r04/mpc_portfolio_ab.jsonl): an insurance against the tail, opt-in.  In rare cases the winning variant settles in a different local optimum of the
  * (non-convex) NLP than variant 0 would.  status: as crx_mpc_solve_batch, plus the winning variant in bits 2-3.  Reproduced by the CPU
  * twin (oracle_mpc_solve_portfolio).  Enqueue only, like every _dev entry point. */
 int crx_mpc_solve_portfolio_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,

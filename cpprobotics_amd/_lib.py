@@ -97,6 +97,7 @@ _SIGNATURES = {
     "crx_dare_from_v_batch": (_I, [_I, _I, _P, C.POINTER(LqrParams), _P, _P, _P]),
     "crx_dare_from_v_batch_dev": (_I, [_I, _I, _P, C.POINTER(LqrParams), _P, _P, _P, _P]),
     "crx_mpc_solve_batch": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P]),
+    "crx_mpc_solve_portfolio_batch": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P]),
     "crx_mpc_solve_batch_dev": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P, _P]),
     "crx_mpc_solve_portfolio_batch_dev": (_I, [_I, _I, _P, _P, C.POINTER(MpcParams), _P, _P, _P, _P]),
     "crx_vehicle_default_params": (None, [C.POINTER(VehicleParams), _I]),

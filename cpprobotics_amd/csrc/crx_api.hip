@@ -1066,9 +1066,8 @@ int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xre
   return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, waves_per_workgroup);
 }
 
-int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
-                        int* status, double* cost) {
-  CRX_TRACE();
+static int mpc_solve_host(bool portfolio, int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                          int* status, double* cost) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
   if (int rc = check_device()) return rc;
@@ -1081,10 +1080,24 @@ int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const 
     const int is = hc.add(nullptr, sol + nv * a0, 4 * nv * nl);
     const int it = hc.add(nullptr, status ? status + a0 : nullptr, 4 * nl), ic = hc.add(nullptr, cost ? cost + a0 : nullptr, 8 * nl);
     CRX_TRY(hc.commit());
-    CRX_TRY(crx_mpc_solve_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it), hc.p<double>(ic),
-                                    hc.stream()));
+    if (portfolio)
+      CRX_TRY(crx_mpc_solve_portfolio_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it),
+                                                hc.p<double>(ic), hc.stream()));
+    else
+      CRX_TRY(crx_mpc_solve_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it), hc.p<double>(ic),
+                                      hc.stream()));
     return hc.finish();
   });
+}
+int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                        int* status, double* cost) {
+  CRX_TRACE();
+  return mpc_solve_host(false, n, T, x0, xref, prm, sol, status, cost);
+}
+int crx_mpc_solve_portfolio_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                                  int* status, double* cost) {
+  CRX_TRACE();
+  return mpc_solve_host(true, n, T, x0, xref, prm, sol, status, cost);
 }
 
 }  // extern "C"

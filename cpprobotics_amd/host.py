@@ -124,14 +124,15 @@ def dare_from_v(v, dim=5, dt=0.1, L_wheelbase=0.5, eps=0.01, maxiter=150):
     return X, K, it
 
 
-def mpc_solve(x0, xref, T, params=None):
-    """crx_mpc_solve_batch -> sol [n, 4T + 2(T-1)], status, cost."""
+def mpc_solve(x0, xref, T, params=None, portfolio=False):
+    """crx_mpc_solve_batch (portfolio=True: crx_mpc_solve_portfolio_batch) -> sol [n, 4T + 2(T-1)], status, cost."""
     from .mpc import default_params, mpc_n_vars
     x0, xref = _f32(x0), _f32(xref)
     n = x0.shape[0]
     p = params if params is not None else default_params()
     sol = np.empty((n, mpc_n_vars(T)), np.float32); st = np.empty((n,), np.int32); cost = np.empty((n,), np.float64)
-    L.check(L.lib().crx_mpc_solve_batch(n, int(T), _p(x0), _p(xref), C.byref(p), _p(sol), _p(st), _p(cost)), "crx_mpc_solve_batch")
+    fn = L.lib().crx_mpc_solve_portfolio_batch if portfolio else L.lib().crx_mpc_solve_batch
+    L.check(fn(n, int(T), _p(x0), _p(xref), C.byref(p), _p(sol), _p(st), _p(cost)), "crx_mpc_solve_batch")
     return sol, st, cost
 
 

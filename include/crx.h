@@ -211,6 +211,8 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,
  * twin (oracle_mpc_solve_portfolio).  Enqueue only, like every _dev entry point. */
 int crx_mpc_solve_portfolio_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                                       float* sol, int* status, double* cost, void* stream);
+int crx_mpc_solve_portfolio_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                                  int* status, double* cost);   /* host pointers */
 
 
 /* ---- course tracking front-end, vehicle update, closed loops ------------------------------------

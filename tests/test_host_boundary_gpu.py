@@ -110,9 +110,11 @@ def test_sharded_solves_equal_unsharded(crx, oracle_mod, split3):
     v = lqr_speeds(n, seed=21)
     A, B, Q, R = oracle_mod.lqr_build(v, 5)
     x0, xref = mpc_problem(700, 6, seed=2)
-    sharded = (crx.host.dare_from_v(v, 5), crx.host.dare_from_v(v, 4), crx.host.dare(A, B, Q, R), crx.host.mpc_solve(x0, xref, 6))
+    sharded = (crx.host.dare_from_v(v, 5), crx.host.dare_from_v(v, 4), crx.host.dare(A, B, Q, R), crx.host.mpc_solve(x0, xref, 6),
+               crx.host.mpc_solve(x0, xref, 6, portfolio=True))
     crx.host.set_devices(None)
-    single = (crx.host.dare_from_v(v, 5), crx.host.dare_from_v(v, 4), crx.host.dare(A, B, Q, R), crx.host.mpc_solve(x0, xref, 6))
+    single = (crx.host.dare_from_v(v, 5), crx.host.dare_from_v(v, 4), crx.host.dare(A, B, Q, R), crx.host.mpc_solve(x0, xref, 6),
+              crx.host.mpc_solve(x0, xref, 6, portfolio=True))
     for a, b in zip(sharded, single):
         for s, t in zip(a, b):
             assert np.array_equal(s.view(np.uint8), t.view(np.uint8))

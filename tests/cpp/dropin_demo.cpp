@@ -35,6 +35,25 @@ int main() {
     dump("ekf_x", xEst.data(), 4);
     dump("ekf_P", PEst.data(), 16);
   }
+  {  // the same five steps for a fleet of 3,000 identical vehicles in ONE call, the fleet-sized arrays in pinned memory
+    const size_t n = 3000, T = 5;
+    std::vector<Mat<2, 1>, crx_dropin::pinned_allocator<Mat<2, 1>>> zf(T * n), uf(T * n);
+    std::vector<Mat<4, 1>, crx_dropin::pinned_allocator<Mat<4, 1>>> hx;
+    Mat<4, 1> xt;
+    for (size_t t = 0; t < T; ++t) {
+      Mat<2, 1> ud; ud(0) = u(0) + 0.05f * ((int)t - 2); ud(1) = u(1) - 0.01f * (int)t;
+      xt = motion_model(xt, u);
+      Mat<2, 1> z; z(0) = xt(0) + 0.1f * ((int)t % 3 - 1); z(1) = xt(1) - 0.07f * ((int)t % 2);
+      for (size_t a = 0; a < n; ++a) { zf[t * n + a] = z; uf[t * n + a] = ud; }
+    }
+    std::vector<Mat<4, 1>> xf(n);
+    std::vector<Mat<4, 4>> Pf(n, Mat<4, 4>::Identity());
+    crx_dropin::use_all_devices(1024);
+    crx_dropin::ekf_estimation_run(xf, Pf, zf, uf, Q, R, &hx);
+    for (size_t t = 0; t < T; ++t) dump("fleet_x", hx[t * n + (n - 1)].data(), 4);
+    dump("fleet_P", Pf[n / 2].data(), 16);
+    crx::dropin_check(crx_set_devices(nullptr, 0, 0), "crx_set_devices");
+  }
   dump("jacobF", jacobF(xEst, u).data(), 16);
   dump("obs", observation_model(xEst).data(), 2);
   dump("jacobH", jacobH().data(), 8);

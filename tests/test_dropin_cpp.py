@@ -66,6 +66,9 @@ def test_dropin_matches_oracle(demo, oracle_mod):
         z = np.array([[xt[0, 0] + f32(0.1) * f32(t % 3 - 1), xt[0, 1] - f32(0.07) * f32(t % 2)]], f32)
         x, P = oracle_mod.ekf_step(x, P, z, ud, Qc, Rc)
         assert np.array_equal(got["ekf_x"][t], x[0]) and np.array_equal(got["ekf_P"][t], P[0])
+        # the fleet run of the same steps (crx_dropin::ekf_estimation_run, pinned vectors, device set): the last vehicle's trajectory
+        assert np.array_equal(got["fleet_x"][t], x[0])
+    assert np.array_equal(got["fleet_P"][0], P[0])
     assert np.array_equal(got["jacobF"][0], oracle_mod.jacobF(x, u)[0])
     assert np.array_equal(got["obs"][0], x[0, :2]) and np.array_equal(got["jacobH"][0], oracle_mod.jacobH())
     v = np.array([2.5], f32)

@@ -52,6 +52,34 @@ def test_ekf_run_host_equals_device_path(crx, oracle_mod, n, T, want_P):
     assert bit_equal(x2, xr) and bit_equal(P2, Pr)
 
 
+def test_ekf_run_host_random_shapes(crx, oracle_mod):
+    """Thirty random (n, T, histories, device-set) combinations around the boundary's thresholds — the 256 KB zero-copy limit, one
+    chunk / several chunks, ragged last chunk, odd n (unaligned rows inside the rings), shards of a forced split: always the device
+    path's bits."""
+    rng = np.random.default_rng(2024)
+    Q, R = ekf_QR()
+    for case in range(30):
+        kind = case % 3
+        if kind == 0:      # around the zero-copy threshold: n * T * (32 or 96) + 80 n ~ 256 KB
+            T = int(rng.integers(1, 40)); want_P = bool(rng.integers(0, 2))
+            n = max(1, int(262144 / (T * (96 if want_P else 32) + 80)) + int(rng.integers(-3, 4)))
+        elif kind == 1:    # a few chunks with a ragged tail: chunk = 16 MB / (n * 16 or 80) steps
+            n = int(rng.integers(20000, 90000)) | 1; want_P = bool(rng.integers(0, 4) == 0)
+            tc = max(1, (16 << 20) // (n * (80 if want_P else 16)))
+            T = int(tc * rng.integers(1, 4) + rng.integers(0, tc + 1)); T = max(1, min(T, 60))
+        else:              # small and odd
+            n, T, want_P = int(rng.integers(1, 3000)), int(rng.integers(1, 25)), bool(rng.integers(0, 2))
+        split = int(rng.integers(0, 4))
+        x0, P0, z, ud = _ekf_inputs(oracle_mod, n, T, seed=1000 + case)
+        xr, Pr, hr, Phr = _ekf_dev(crx, x0, P0, z, ud, want_P)
+        crx.host.set_devices([0] * split if split else None, min_agents_per_device=1)
+        try:
+            x, P, h, Ph = crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R, want_hist=True, want_P_hist=want_P)
+        finally:
+            crx.host.set_devices(None)
+        assert bit_equal(x, xr) and bit_equal(P, Pr) and bit_equal(h, hr) and (not want_P or bit_equal(Ph, Phr)), (case, n, T, want_P, split)
+
+
 def test_ekf_run_host_pinned_arrays(crx, oracle_mod):
     """Caller memory from crx_host_alloc: DMA'd in place (strided 2-D copies straight between the caller's arrays and the rings)."""
     Q, R = ekf_QR()

@@ -22,6 +22,8 @@
 #include <sched.h>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -110,12 +112,32 @@ class CopyPool {
     std::lock_guard<std::mutex> l(p.t->m);
     if (p.t->left.fetch_sub(1) == 1) p.t->cv.notify_all();
   }
-  CopyPool() {
+  // hardware threads this process may use: the affinity mask, capped by the cgroup CPU quota (a container with a quota of 16 CPUs on
+  // a 256-thread host must not spin 128 copy threads)
+  static int usable_cores() {
     int cores = 1;
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = CPU_COUNT(&set);
     else cores = (int)std::thread::hardware_concurrency();
-    const int nthreads = std::max(1, std::min(8, cores / 2));     // copy threads: half the usable cores, at most 8
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {               // cgroup v2: "<quota> <period>" or "max <period>"
+      char q[32]; long period = 0;
+      if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0)
+        cores = std::min<long>(cores, std::max<long>(1, std::atol(q) / period));
+      std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+      long quota = -1, period = 0;
+      if (std::fscanf(g, "%ld", &quota) != 1) quota = -1;
+      std::fclose(g);
+      if (FILE* h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(h, "%ld", &period) != 1) period = 0;
+        std::fclose(h);
+      }
+      if (quota > 0 && period > 0) cores = std::min<long>(cores, std::max<long>(1, quota / period));
+    }
+    return std::max(1, cores);
+  }
+  CopyPool() {
+    const int nthreads = std::max(1, std::min(12, usable_cores() * 3 / 4));   // copy threads: three quarters of the usable cores, at most 12
     for (int i = 0; i < nthreads; ++i)
       workers_.emplace_back([this] {
         for (;;) {

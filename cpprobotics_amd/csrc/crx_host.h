@@ -137,7 +137,7 @@ class CopyPool {
     return std::max(1, cores);
   }
   CopyPool() {
-    const int nthreads = std::max(1, std::min(12, usable_cores() * 3 / 4));   // copy threads: three quarters of the usable cores, at most 12
+    const int nthreads = std::max(1, std::min(8, usable_cores() / 2));   // copy threads: half the usable cores, at most 8 (12 were measured: no gain)
     for (int i = 0; i < nthreads; ++i)
       workers_.emplace_back([this] {
         for (;;) {

@@ -12,7 +12,7 @@ bad = {}
 Q, R = ekf_QR()
 seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-from cpprobotics_amd.experimental import closed_loop_prediction_lanes, dlqr_from_v_lanes
+from cpprobotics_amd.experimental import closed_loop_prediction_lanes, dare_dense, dlqr_from_v_lanes
 sys.path.insert(0, 'tests')
 from test_oracle_pf import _scenario
 count = {}
@@ -33,6 +33,12 @@ for seed in range(seed0, seed0 + nseeds):
         K, X, it = crx.dlqr_from_v(t(v), dim=dim)
         Xd, itd = crx.solve_DARE(t(A), t(B), t(Qm), t(Rm))
         m = np.any(X.cpu().numpy() != Xo, axis=1) | np.any(K.cpu().numpy() != Ko, axis=1) | (it.cpu().numpy() != ito) | np.any(Xd.cpu().numpy() != Xo, axis=1) | (itd.cpu().numpy() != ito)
+        # round 4: solve_DARE above is served by the structured kernels (the matrices carry the reference's pattern); the dense kernel
+        # itself forced on them, and the host-pointer entry point (numpy arrays through the boundary)
+        Xf, Kf, itf = dare_dense(t(A), t(B), t(Qm), t(Rm))
+        Xh, Kh, ith = crx.host.dare(A, B, Qm, Rm)
+        m |= np.any(Xf.cpu().numpy() != Xo, axis=1) | np.any(Kf.cpu().numpy() != Ko, axis=1) | (itf.cpu().numpy() != ito)
+        m |= np.any(Xh != Xo, axis=1) | np.any(Kh != Ko, axis=1) | (ith != ito)
         for lanes in (1, 4):
             K2, X2, it2 = dlqr_from_v_lanes(t(v), dim, lanes)
             m |= np.any(X2.cpu().numpy() != Xo, axis=1) | np.any(K2.cpu().numpy() != Ko, axis=1) | (it2.cpu().numpy() != ito)

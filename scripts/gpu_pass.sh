@@ -10,7 +10,7 @@
 #     ab         the lanes-per-agent A/B scripts (DARE, MPC, closed loop) and the MPC closed-loop drift
 #     side       scripts/side_bench.py (DARE, MPC, tracking, PF, DWA, Frenet)
 #     swarm      scripts/swarm_bench.py, one GPU's shard of BASELINE configs[4]
-#     fuzz       scripts/gpu_fuzz_bitexact.py (SEEDS=n, default 20)
+#     fuzz       scripts/gpu_fuzz_bitexact.py (SEED0=first seed, default 300; SEEDS=how many, default 20)
 #     prof       scripts/gpu_prof.sh TAG/prof (rocprofv3 kernel stats + PMC passes, markers)
 # Everything lands in gpurun_out/TAG/; `python scripts/collect_profiles.py TAG rNN` copies the judged summaries into profiles/rNN/.
 # (Rounds 1-3 kept one copy of this script per round — gpu_round.sh, gpu_round2.sh, gpu_final2.sh, gpu_final3.sh — and one-off
@@ -39,7 +39,7 @@ for s in $STEPS; do
         timeout 200 python scripts/gpu_mpc_loop_err.py > $OUT/mpc_loop_err.jsonl 2>&1; cat $OUT/mpc_loop_err.jsonl ;;
     side) timeout 900 python scripts/side_bench.py > $OUT/side_bench.jsonl 2> $OUT/side_bench.err; cut -c1-300 $OUT/side_bench.jsonl ;;
     swarm) timeout 300 python scripts/swarm_bench.py --agents 131072 > $OUT/swarm_1gpu.json 2> $OUT/swarm.err; cut -c1-600 $OUT/swarm_1gpu.json; tail -2 $OUT/swarm.err ;;
-    fuzz) timeout 1500 python scripts/gpu_fuzz_bitexact.py ${SEEDS:-20} > $OUT/fuzz_bitexact.txt 2>&1; tail -12 $OUT/fuzz_bitexact.txt ;;
+    fuzz) timeout 1500 python scripts/gpu_fuzz_bitexact.py ${SEED0:-300} ${SEEDS:-20} > $OUT/fuzz_bitexact.txt 2>&1; tail -12 $OUT/fuzz_bitexact.txt ;;
     prof) timeout 2400 bash scripts/gpu_prof.sh $TAG/prof > $OUT/prof.log 2>&1; tail -40 $OUT/prof.log ;;
     *) echo "unknown step $s" ;;
   esac

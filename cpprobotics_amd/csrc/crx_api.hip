@@ -423,7 +423,7 @@ int crx_host_libm_check(void) {
 void* crx_host_alloc(size_t bytes) {
   if (check_device()) return nullptr;
   void* p = nullptr;
-  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+  const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable | hipHostMallocMapped);
   if (e != hipSuccess) { hip_fail(e, "hipHostMalloc"); return nullptr; }
   return p;
 }

@@ -174,7 +174,7 @@ struct Grow {                                      // grow-only buffer (device o
     if (bytes <= cap) return hipSuccess;
     release();
     const size_t want = align_up(bytes + bytes / 8);     // a little head-room: batches that creep up do not reallocate every call
-    const hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+    const hipError_t e = pinned ? hipHostMalloc(&p, want, hipHostMallocPortable | hipHostMallocMapped) : hipMalloc(&p, want);
     if (e != hipSuccess) { p = nullptr; cap = 0; return e; }
     cap = want;
     return hipSuccess;

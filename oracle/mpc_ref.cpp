@@ -28,7 +28,8 @@ namespace {
 int p_n_gn = 2; double p_up = 10.0, p_down = 0.1;  // tuning knobs (set through oracle_mpc_tune)
 int p_trust_mode = 0;  // experiment knob (oracle_mpc_trust_mode): 0 = trust box on every Newton sweep (the engine), 1 = only after the first refused Newton step, 2 = doubled after every accepted full step, back to the base after a refused one
 thread_local double t_trust_scale = 1.0; thread_local bool t_trust_on = true;
-thread_local int t_variant_n_gn = -1; thread_local double t_variant_trust = 1.0;   // the variant of a portfolio solve (oracle_mpc_solve_portfolio)
+thread_local int t_variant_n_gn = -1; thread_local double t_variant_trust = 1.0;
+thread_local int* t_ls_out = nullptr;   // experiment aid (oracle_mpc_ls_profile): candidate rollouts of every sweep   // the variant of a portfolio solve (oracle_mpc_solve_portfolio)
 int p_warm = 0;       // experiment knob (oracle_mpc_warm): 0 = the reference's zero initial guess (:266-274), 1 / 2 = see solve_one
 
 struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the reference's #defines
@@ -390,6 +391,7 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
     }
     if (p_trust_mode == 2 && exact) t_trust_scale = (accepted && alpha == 1.0) ? (t_trust_scale * 2.0 > 8.0 ? 8.0 : t_trust_scale * 2.0) : 1.0;
     if (p_trust_mode == 1 && exact && !accepted) t_trust_on = true;
+    if (t_ls_out) { int used = 0; double a_ = 1.0; while (a_ > alpha) { a_ *= 0.5; ++used; } t_ls_out[it] = accepted ? used + 1 : ls_max; }
     if (accepted) {
       if (gn_left > 0) gn_left--;
       mu = (alpha == 1.0) ? mu * p_down : mu;
@@ -479,6 +481,18 @@ void oracle_mpc_solve_portfolio(int n, int T, const float* x0, const float* xref
 
 void oracle_mpc_tune(int n_gn, double up, double down) { p_n_gn = n_gn; p_up = up; p_down = down; }
 void oracle_mpc_warm(int mode) { p_warm = mode; }
+// experiment aid: one agent with variant (n_gn, trust scale); ls[i] = candidate rollouts of sweep i (0 for a sweep that only checks
+// convergence); returns the status word
+int oracle_mpc_ls_profile(int T, const float* x0, const float* xref, const double* params, int max_iter, int n_gn, double trust, int* ls) {
+  const MpcParams p = unpack(params, max_iter);
+  std::vector<float> sol(4 * T + 2 * (T - 1));
+  for (int i = 0; i < max_iter; ++i) ls[i] = 0;
+  t_variant_n_gn = n_gn; t_variant_trust = trust; t_ls_out = ls;
+  double J; int it;
+  const int st = solve_one(p, T, x0, xref, sol.data(), &J, &it);
+  t_variant_n_gn = -1; t_variant_trust = 1.0; t_ls_out = nullptr;
+  return st;
+}
 void oracle_mpc_trust_mode(int mode) { p_trust_mode = mode; }
 void oracle_mpc_trust(double steer, double accel) { kTrustSteer = steer; kTrustAccel = accel; }
 

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
     ap.add_argument("--chunks", type=int, default=4, help="launches per round of the chunked trajectory gather")
+    ap.add_argument("--mpc-portfolio", action="store_true",
+                    help="the planners through crx_mpc_solve_portfolio_batch_dev (four solver variants per agent, the first to converge wins)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -86,7 +88,7 @@ def main():
                                      # noisy velocity input every step (F(3,3) = 1 and B(3,0) = 1, src/extended_kalman_filter.cpp:27,34)
         crx.calc_nearest_index(est, dc, tind)
         xref = crx.calc_ref_trajectory(est, dc, tind, Tm)
-        return crx.mpc_solve(est, xref, Tm)
+        return crx.mpc_solve(est, xref, Tm, portfolio=args.mpc_portfolio)
 
     rnd = swarm.MixedSwarmRound(n, T, 4, args.chunks, 8, dev, ekf_launch, lambda: x, plan_launch, gather=args.gather, n_total=n_total)
 
@@ -123,7 +125,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"mixed swarm: {n_total} agents over {world} GPU(s), {T} EKF steps for every agent + one MPC solve (T = 21) "
                                    f"for every eighth agent per round; gather = {args.gather if world > 1 else 'n/a'}",
-                       "agents_per_gpu": n, "ekf_steps_per_round": T, "mpc_agents_per_gpu": n_mpc, "chunks": args.chunks},
+                       "agents_per_gpu": n, "ekf_steps_per_round": T, "mpc_agents_per_gpu": n_mpc, "chunks": args.chunks,
+                       "mpc_solver": "four-variant portfolio" if args.mpc_portfolio else "single"},
             "secondary": {"metric": "MPC horizon solves/s (T = 21) of the same rounds", "value": n_mpc * world / dt, "unit": "solves/s"},
             "roofline": {"bound": "valu", "kernel": "crx::ekf_run_kernel (the round's EKF launches)", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "kernel_ms_per_round": ekf_ms, "algorithmic_bytes_per_round": algo_bytes,

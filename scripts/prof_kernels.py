@@ -71,6 +71,8 @@ except Exception:
 for lanes in layouts:
     for _ in range(reps):
         sol, st, cost = mpc_solve_lanes(x0, xref, 21, lanes)
+for _ in range(reps):                                   # the four-variant portfolio on the same batch (round 4)
+    solp, stp, costp = crx.mpc_solve(x0, xref, 21, return_status=True, portfolio=True)
 course, goal = lqr_course()
 dc = crx.Course.from_numpy(course)
 stl = torch.from_numpy(tracking_agents(16384, tuple(c[:200] for c in course), 5, spread=0.4)).cuda()
@@ -80,10 +82,12 @@ for lanes in (1, 4):
             closed_loop_prediction_lanes(stl.clone(), dc, goal, lanes, dim=dim, max_ticks=400)
 torch.cuda.synchronize()
 mit = (st.cpu().numpy() >> 8).astype(np.int64)
+pit = (stp.cpu().numpy() >> 8).astype(np.int64)
 wsum = lambda a, k: int(a.reshape(-1, k).max(axis=1).sum())
 print(json.dumps({"dare5": {"agents": 16384, "iters_sum": int(it5.sum()), "wave_max_iters_sum": wsum(it5, 64)},
                   "dare5_quad": {"agents": 16384, "iters_sum": int(it5.sum()), "wave_max_iters_sum": wsum(it5, 16)},
                   "dare5_dense_reference_matrices": {"agents": 16384, "iters_sum": int(itd.sum()), "wave_max_iters_sum": wsum(itd, 64)},
                   "dare5_dense_general_matrices": {"agents": 16384, "iters_sum": int(itg.sum()), "wave_max_iters_sum": wsum(itg, 64)},
                   "mpc_T21": {"agents": 8192, "iters_sum": int(mit.sum()), "iters_max": int(mit.max()), "wave_max_iters_sum": wsum(mit, 64)},
-                  "mpc_T21_quad": {"agents": 8192, "iters_sum": int(mit.sum()), "iters_max": int(mit.max()), "wave_max_iters_sum": wsum(mit, 16)}}))
+                  "mpc_T21_quad": {"agents": 8192, "iters_sum": int(mit.sum()), "iters_max": int(mit.max()), "wave_max_iters_sum": wsum(mit, 16)},
+                  "mpc_T21_portfolio": {"agents": 8192, "iters_sum": int(pit.sum()), "iters_max": int(pit.max()), "wave_max_iters_sum": wsum(pit, 16)}}))

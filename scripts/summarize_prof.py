@@ -74,7 +74,7 @@ side = {}
 for key, kern in (("dare5", "dare_from_v_kernel<5, crx::DareFromV"), ("dare5_quad", "dare_from_v_quad_kernel<5, crx::DareFromV"),
                   ("dare5_signature_quad", "dare_from_v_quad_kernel<5, crx::DareFromMats"),
                   ("dare5_dense_reference_matrices", "dare_dense_kernel<5, false"), ("dare5_dense_general_matrices", "dare_dense_kernel<5, true"),
-                  ("mpc_T21", "mpc_kernel<24"), ("mpc_T21_quad", "mpc_quad_kernel<24")):
+                  ("mpc_T21", "mpc_kernel<24"), ("mpc_T21_quad", "mpc_quad_kernel<24"), ("mpc_T21_portfolio", "mpc_portfolio_kernel<24")):
     c, n = counters("side_sq", kern)
     f, _ = counters("side_flop", kern)
     c2, _ = counters("side_sq2", kern)

@@ -86,6 +86,7 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
+constexpr int kDareDenseQuadMaxAgents = 16384;   // dense kernels: a quad per agent up to here (dare_dense_quad_kernel<5> is one 256-VGPR wave per SIMD: 1,024 waves)
 constexpr int kDareChainMaxAgents = 98304;   // one lane per agent: the unmasked two-evaluations-per-branch loop up to here (profiles/r03/dare_lanes_ab.txt)
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
@@ -861,20 +862,24 @@ int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const fl
 // DARE / dlqr
 // ---------------------------------------------------------------------------------------------
 // structured: 1 = detect the pattern lqr_steering_control builds (per agent) and serve those agents by the structured kernels, the
-// rest by the dense kernel (two launches, no workspace, no synchronisation); 0 = the dense kernel for everybody.
+// rest by a dense kernel (two launches, no workspace, no synchronisation); 0 = a dense kernel for everybody.
+// dense_lanes: 1 = dare_dense_kernel (one agent per lane), 4 = dare_dense_quad_kernel (one row of X per lane of a quad), 0 = by batch size.
 static int dare_batch_launch(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
-                             float eps, int maxiter, float* X, float* K, int* iters, void* stream, int structured) {
+                             float eps, int maxiter, float* X, float* K, int* iters, void* stream, int structured, int dense_lanes) {
   if (n < 0 || (dim != 4 && dim != 5) || (n && (!A || !B || !Q || !R)))
     return fail(CRX_ERR_INVALID, "dare: bad argument (dim must be 4 or 5)");
+  if (dense_lanes != 0 && dense_lanes != 1 && dense_lanes != 4) return fail(CRX_ERR_INVALID, "dare: lanes_per_agent must be 0 (auto), 1 or 4");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   hipStream_t s = (hipStream_t)stream;
   const unsigned bs = iter_block();
   const dim3 grid(blocks_for(n, bs)), block(bs);
+  const dim3 qgrid(blocks_for(4 * (size_t)n, 256)), qblock(256);
+  // a quad per agent while the batch leaves SIMDs without a wave of their own (the structured kernels' crossover)
+  if (dense_lanes == 0) dense_lanes = (n <= kDareDenseQuadMaxAgents) ? 4 : 1;
   if (structured) {
     const crx::DareFromMats src{A, B, Q, R};
     if (n <= kDareQuadMaxAgents) {
-      const dim3 qgrid(blocks_for(4 * (size_t)n, 256)), qblock(256);
       if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<5, crx::DareFromMats>), qgrid, qblock, 0, s, n, src, eps, maxiter, X, K, iters);
       else hipLaunchKernelGGL((crx::dare_from_v_quad_kernel<4, crx::DareFromMats>), qgrid, qblock, 0, s, n, src, eps, maxiter, X, K, iters);
     } else if (n <= kDareChainMaxAgents) {
@@ -885,12 +890,15 @@ static int dare_batch_launch(int n, int dim, const float* A, const float* B, con
       else hipLaunchKernelGGL((crx::dare_from_v_masked_kernel<4, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
     }
     CRX_HIP(hipGetLastError());
-    if (dim == 5) hipLaunchKernelGGL((crx::dare_dense_kernel<5, true>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
-    else hipLaunchKernelGGL((crx::dare_dense_kernel<4, true>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
-  } else {
-    if (dim == 5) hipLaunchKernelGGL((crx::dare_dense_kernel<5, false>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
-    else hipLaunchKernelGGL((crx::dare_dense_kernel<4, false>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);
   }
+#define CRX_LAUNCH_DENSE(DIM, SKIP)                                                                                                     \
+  do {                                                                                                                                  \
+    if (dense_lanes == 4) hipLaunchKernelGGL((crx::dare_dense_quad_kernel<DIM, SKIP>), qgrid, qblock, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters); \
+    else hipLaunchKernelGGL((crx::dare_dense_kernel<DIM, SKIP>), grid, block, 0, s, n, A, B, Q, R, eps, maxiter, X, K, iters);          \
+  } while (0)
+  if (structured) { if (dim == 5) CRX_LAUNCH_DENSE(5, true); else CRX_LAUNCH_DENSE(4, true); }
+  else { if (dim == 5) CRX_LAUNCH_DENSE(5, false); else CRX_LAUNCH_DENSE(4, false); }
+#undef CRX_LAUNCH_DENSE
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }
@@ -898,12 +906,12 @@ static int dare_batch_launch(int n, int dim, const float* A, const float* B, con
 int crx_dare_batch_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
                        float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
   CRX_TRACE();
-  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 1);
+  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 1, 0);
 }
 int crx_x_dare_batch_dense_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
-                               float eps, int maxiter, float* X, float* K, int* iters, void* stream) {
+                               float eps, int maxiter, float* X, float* K, int* iters, void* stream, int lanes_per_agent) {
   CRX_TRACE();
-  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 0);
+  return dare_batch_launch(n, dim, A, B, Q, R, eps, maxiter, X, K, iters, stream, 0, lanes_per_agent);
 }
 
 // lanes_per_agent: 1 = dare_from_v_kernel, 4 = dare_from_v_quad_kernel, 0 = chosen by batch size.

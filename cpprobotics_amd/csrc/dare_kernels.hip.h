@@ -23,141 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "dare_math.h"
+#include "dare_dense_math.h"
 
 namespace crx {
-
-// ---------- tiny register-matrix helpers (column-major, compile-time sizes) -------------------
-// Accumulation orders (see oracle/eigen_order.h for the derivation from Eigen's sources).
-enum { ORD_ASC = 0, ORD_TREE = 1, ORD_SSE4 = 2, ORD_SLICE = 3 };   // ORD_SLICE: per row, see mm
-
-// redux_novec_unroller: sum(start,len) = sum(start,len/2) + sum(start+len/2, len-len/2)
-template <int START, int LEN>
-struct TreeSum {
-  static __device__ __forceinline__ float run(const float* t) {
-    return TreeSum<START, LEN / 2>::run(t) + TreeSum<START + LEN / 2, LEN - LEN / 2>::run(t);
-  }
-};
-template <int START>
-struct TreeSum<START, 1> {
-  static __device__ __forceinline__ float run(const float* t) { return t[START]; }
-};
-
-template <int K, int ORD>
-__device__ __forceinline__ float sum_terms(const float (&t)[K]) {
-  if constexpr (ORD == ORD_SSE4 && K >= 4 && K < 8) {
-    // vectorised redux (redux_impl<LinearVectorizedTraversal, CompleteUnrolling>): SSE2 predux of the one product packet,
-    // then the K % 4 remaining terms (redux_novec_unroller) are added
-    const float v = (t[0] + t[2]) + (t[1] + t[3]);
-    if constexpr (K == 4) return v;
-    else return v + TreeSum<4, K - 4>::run(t);
-  } else if constexpr (ORD == ORD_TREE || ORD == ORD_SSE4) {
-    return TreeSum<0, K>::run(t);
-  } else {
-    float s = t[0];
-#pragma unroll
-    for (int k = 1; k < K; ++k) s = s + t[k];
-    return s;
-  }
-}
-
-// out(RxC) = A(RxK) * B(KxC);  TA/TB: read A/B through a transposed view of the stored matrix.
-// ORD_SLICE: a column-major left factor with R >= 4, R % 4 != 0 rows (SliceVectorizedTraversal with inner unrolling): the first
-// (R/4)*4 rows of every column are packet sums (ascending), the remaining rows coeff() reduxes (the unrolled tree).
-template <int R, int K, int C, bool TA, bool TB, int ORD>
-__device__ __forceinline__ void mm(const float* __restrict__ A, const float* __restrict__ B,
-                                   float* __restrict__ out) {
-#pragma unroll
-  for (int j = 0; j < C; ++j)
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      float t[K];
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const float a = TA ? A[k + K * i] : A[i + R * k];
-        const float b = TB ? B[j + C * k] : B[k + K * j];
-        t[k] = a * b;
-      }
-      if constexpr (ORD == ORD_SLICE) out[i + R * j] = (i < (R / 4) * 4) ? sum_terms<K, ORD_ASC>(t) : sum_terms<K, ORD_TREE>(t);
-      else out[i + R * j] = sum_terms<K, ORD>(t);
-    }
-}
-
-__device__ __forceinline__ void inverse2(const float* m, float* r) {
-  const float det = m[0] * m[3] - m[1] * m[2];
-  const float invdet = 1.0f / det;
-  r[0] = m[3] * invdet;
-  r[1] = -m[1] * invdet;
-  r[2] = -m[2] * invdet;
-  r[3] = m[0] * invdet;
-}
-
-// ---------- dense 5x5 ------------------------------------------------------------------------
-// Eigen order for 5-row shapes (oracle/eigen_order.h): a transposed left factor (A'*X, B'*X) puts the product on the coefficient
-// path with a vectorised redux (SSE4: one packet + the fifth term); a column-major 5-row left factor is assigned by slices —
-// rows 0-3 of each column by packets (ascending), row 4 by the unrolled-tree redux (SLICE); a 2-row left factor stays on the
-// coefficient path (TREE).  Inner size 2 has one order.
-__device__ __forceinline__ void dare5_dense_iter(const float* A, const float* B, const float* Q,
-                                                 const float* R, const float* X, float* Xn) {
-  float AtX[25], P1[25], BtX[10], G[4], Sg[4], Si[4], c1[10], c2[10], c3[25], c4[25], P2[25];
-  mm<5, 5, 5, true, false, ORD_SSE4>(A, X, AtX);
-  mm<5, 5, 5, false, false, ORD_SLICE>(AtX, A, P1);
-  mm<2, 5, 5, true, false, ORD_SSE4>(B, X, BtX);
-  mm<2, 5, 2, false, false, ORD_TREE>(BtX, B, G);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Sg[i] = R[i] + G[i];
-  inverse2(Sg, Si);
-  mm<5, 5, 2, false, false, ORD_SLICE>(AtX, B, c1);
-  mm<5, 2, 2, false, false, ORD_TREE>(c1, Si, c2);
-  mm<5, 2, 5, false, true, ORD_TREE>(c2, B, c3);
-  mm<5, 5, 5, false, false, ORD_SLICE>(c3, X, c4);
-  mm<5, 5, 5, false, false, ORD_SLICE>(c4, A, P2);
-#pragma unroll
-  for (int i = 0; i < 25; ++i) Xn[i] = (P1[i] - P2[i]) + Q[i];
-}
-
-__device__ __forceinline__ void dlqr5_dense_gain(const float* A, const float* B, const float* R,
-                                                 const float* X, float* Kout) {
-  float BtX[10], G[4], Sg[4], Si[4], BtXA[10];
-  mm<2, 5, 5, true, false, ORD_SSE4>(B, X, BtX);
-  mm<2, 5, 2, false, false, ORD_TREE>(BtX, B, G);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) Sg[i] = G[i] + R[i];
-  inverse2(Sg, Si);
-  mm<2, 5, 5, false, false, ORD_TREE>(BtX, A, BtXA);
-  mm<2, 2, 5, false, false, ORD_TREE>(Si, BtXA, Kout);
-}
-
-// ---------- dense 4x4 ------------------------------------------------------------------------
-// Eigen order for 4-row shapes: column-major left factor -> packet path (ASC); transposed /
-// row-vector left factor with inner size 4 -> vectorised redux (SSE4).
-__device__ __forceinline__ void dare4_dense_iter(const float* A, const float* B, const float* Q,
-                                                 float R, const float* X, float* Xn) {
-  float AtX[16], P1[16], BtX[4], g[1], c1[4], c2[4], c3[16], c4[16], P2[16];
-  mm<4, 4, 4, true, false, ORD_SSE4>(A, X, AtX);
-  mm<4, 4, 4, false, false, ORD_ASC>(AtX, A, P1);
-  mm<1, 4, 4, true, false, ORD_SSE4>(B, X, BtX);
-  mm<1, 4, 1, false, false, ORD_SSE4>(BtX, B, g);
-  const float s = R + g[0];
-  mm<4, 4, 1, false, false, ORD_ASC>(AtX, B, c1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) c2[i] = c1[i] / s;
-  mm<4, 1, 4, false, true, ORD_ASC>(c2, B, c3);
-  mm<4, 4, 4, false, false, ORD_ASC>(c3, X, c4);
-  mm<4, 4, 4, false, false, ORD_ASC>(c4, A, P2);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) Xn[i] = (P1[i] - P2[i]) + Q[i];
-}
-
-__device__ __forceinline__ void dlqr4_dense_gain(const float* A, const float* B, float R,
-                                                 const float* X, float* Kout) {
-  float BtX[4], g[1], BtXA[4];
-  mm<1, 4, 4, true, false, ORD_SSE4>(B, X, BtX);
-  mm<1, 4, 1, false, false, ORD_SSE4>(BtX, B, g);
-  const float inv = (float)(1.0 / (double)(g[0] + R));
-  mm<1, 4, 4, false, false, ORD_SSE4>(BtX, A, BtXA);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) Kout[j] = inv * BtXA[j];
-}
 
 // (Xn - X).cwiseAbs().maxCoeff(): a strict '>' scan from element 0 in which a NaN element never replaces the
 // running maximum, and a NaN FIRST element sticks.  v_max_f32 has exactly that behaviour for every element but the
@@ -253,6 +121,116 @@ dare_dense_kernel(int n, const float* __restrict__ Ag, const float* __restrict__
     for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
   }
   if (iters) iters[a] = it;
+}
+
+// ---------- dense, four lanes per agent (round 4) ----------------------------------------------------------------------------
+// BASELINE-sized batches of DENSE problems are the same latency chain on a quarter of the chip as the structured ones were (256
+// one-lane waves on 1,024 SIMDs, ~1,020 instructions per evaluation issued by one wave).  Here an agent is a quad: lane r holds row
+// r of X and (5x5) a copy of row 4, gathers the other rows once per evaluation as DPP quad_perm broadcasts and runs
+// dare_dense_quad_rows (dare_dense_math.h) — its own row and row 4 of every product of :91, 2/5 of the agent's evaluation (1/4 for
+// 4x4) — so the batch fills every SIMD and an evaluation is ~2.5x shorter.  Same accumulation order per coefficient, same bits
+// (tests/test_dare_host.py runs the lane code on the CPU against the oracle; tests/test_lqr_gpu.py the kernel).
+template <int DIM, bool SKIP_STRUCTURED>
+__global__ void __launch_bounds__(256)
+dare_dense_quad_kernel(int n, const float* __restrict__ Ag, const float* __restrict__ Bg, const float* __restrict__ Qg,
+                       const float* __restrict__ Rg, float eps, int maxiter, float* __restrict__ Xg, float* __restrict__ Kg,
+                       int* __restrict__ iters) {
+  constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  constexpr int NB = DIM * M;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t a = t >> 2;
+  const int r = (int)(threadIdx.x & 3);
+  bool live = a < (size_t)n;
+  const size_t ai = live ? a : 0;
+  const float* __restrict__ Aa = Ag + ai * NN;
+  const float* __restrict__ Ba = Bg + ai * NB;
+  const float* __restrict__ Qa = Qg + ai * NN;
+  const float* __restrict__ Ra = Rg + ai * M * M;
+  if constexpr (SKIP_STRUCTURED) {                            // the agents a structured kernel of this launch pair has served
+    bool st = live && dare_pattern_part_ok<DIM, 4>(Aa, Ba, Qa, Ra, r);
+    float p0, p1, p2, p3;
+    dare_pattern_params<DIM>(Aa, Ba, st, p0, p1, p2, p3);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(st);
+    st = ((m >> (threadIdx.x & 60)) & 0xFull) == 0xFull;
+    live = live && !st;
+    if (!__builtin_amdgcn_ballot_w64(live)) return;
+  }
+  float A[NN], B[NB], R[M * M], Acol_r[DIM], Acol_4[DIM], Qrow_r[DIM], Qrow_4[DIM], xr[DIM], x4[DIM];
+#pragma unroll
+  for (int i = 0; i < NN; ++i) A[i] = Aa[i];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) B[i] = Ba[i];
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) R[i] = Ra[i];
+#pragma unroll
+  for (int k = 0; k < DIM; ++k) {                             // this lane's column of A and row of Q, addressed by r in memory
+    Acol_r[k] = Aa[k + DIM * r]; Acol_4[k] = A[k + DIM * (DIM - 1)];
+    Qrow_r[k] = Qa[r + DIM * k]; Qrow_4[k] = Qa[(DIM - 1) + DIM * k];
+    xr[k] = Qrow_r[k]; x4[k] = Qrow_4[k];                     // X = Q
+  }
+  // the whole X, column-major, from the quad's rows (rows 0-3: one DPP broadcast each; row 4: every lane's own copy)
+  auto gather = [&](float* Xf) {
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      Xf[0 + DIM * j] = qperm<QP_0000>(xr[j]);
+      Xf[1 + DIM * j] = qperm<0x55>(xr[j]);
+      Xf[2 + DIM * j] = qperm<0xAA>(xr[j]);
+      Xf[3 + DIM * j] = qperm<QP_3333>(xr[j]);
+      if constexpr (DIM == 5) Xf[4 + DIM * j] = x4[j];
+    }
+  };
+  bool done = !live || maxiter <= 0;
+  int it = maxiter < 0 ? 0 : maxiter;
+  for (int i = 0; i < maxiter; ++i) {
+    if (!done) {                                              // (a quad's four lanes take every decision together)
+      float Xf[NN], yr[DIM], y4[DIM];
+      gather(Xf);
+      dare_dense_quad_rows<DIM>(Acol_r, Acol_4, A, B, Qrow_r, Qrow_4, R, Xf, yr, y4);
+      // (Xn - X).cwiseAbs().maxCoeff() with the reference's NaN rule: fmaxf drops a NaN operand — every element but the first
+      // behaves so in the reference's strict-'>' scan — and element (0,0), lane 0's, makes the result NaN when it is NaN or infinite
+      // (dare_quad_first: the maximum is not below eps then either)
+      const float d00 = yr[0] - xr[0];
+      float m = fabsf(d00);
+#pragma unroll
+      for (int j = 1; j < DIM; ++j) m = fmaxf(m, fabsf(yr[j] - xr[j]));
+      if constexpr (DIM == 5) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) m = fmaxf(m, fabsf(y4[j] - x4[j]));
+      }
+      m = fmaxf(m, qperm<QP_1032>(m));
+      m = fmaxf(m, qperm<QP_2301>(m));
+      m += qperm<QP_0000>(d00 - d00);
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) { xr[j] = yr[j]; x4[j] = y4[j]; }
+      if (m < eps) { done = true; it = i + 1; }
+    }
+    if (__all(done)) break;
+  }
+  float Xf[NN];
+  gather(Xf);                                                 // for the gain (every lane takes part in the broadcasts)
+  if (!live) return;
+  if (Xg) {
+    float* Xa = Xg + a * NN;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) Xa[r + DIM * j] = xr[j];
+    if constexpr (DIM == 5) {
+      if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) Xa[4 + DIM * j] = x4[j];
+      }
+    }
+  }
+  if (r == 0) {
+    if (Kg) {
+      float K[M * DIM];
+      if constexpr (DIM == 5) dlqr5_dense_gain(A, B, R, Xf, K);
+      else dlqr4_dense_gain(A, B, R[0], Xf, K);
+#pragma unroll
+      for (int j = 0; j < M * DIM; ++j) Kg[a * M * DIM + j] = K[j];
+    }
+    if (iters) iters[a] = it;
+  }
 }
 
 // ---------- structured: A, B from v; Q = I; R = I ----------------------------------------------

@@ -12,7 +12,7 @@ _X_SIGNATURES = {
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
                                              C.POINTER(L.LoopParams), _P, _P, _P, _I]),
-    "crx_x_dare_batch_dense_dev": (_I, [_I, _I, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P]),
+    "crx_x_dare_batch_dense_dev": (_I, [_I, _I, _P, _P, _P, _P, C.c_float, _I, _P, _P, _P, _P, _I]),
     "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
     "crx_x_datan2_dev": (_I, [_I, _P, _P, _P]),
     "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
@@ -86,9 +86,10 @@ def dlqr_from_v_lanes(v, dim=5, lanes_per_agent=0, dt=0.1, L_wheelbase=0.5, eps=
     return K, X, iters
 
 
-def dare_dense(A, B, Q, R, eps=0.01, maxiter=150):
-    """solve_DARE + dlqr through the DENSE kernel for every agent, whatever its matrices look like (the product entry point serves
-    agents that carry lqr_steering_control's pattern by the structured kernels).  -> X, K, iters."""
+def dare_dense(A, B, Q, R, eps=0.01, maxiter=150, lanes_per_agent=0):
+    """solve_DARE + dlqr through a DENSE kernel for every agent, whatever its matrices look like (the product entry point serves
+    agents that carry lqr_steering_control's pattern by the structured kernels); lanes_per_agent = 1 / 4 forces the dense kernel's
+    register layout (0: what the product picks for this batch size).  -> X, K, iters."""
     import torch
     from .lqr import _dims
     L.require_cuda(A, B, Q, R)
@@ -99,7 +100,7 @@ def dare_dense(A, B, Q, R, eps=0.01, maxiter=150):
     K = torch.empty((n, m * dim), dtype=torch.float32, device=A.device)
     iters = torch.empty((n,), dtype=torch.int32, device=A.device)
     L.check(xlib().crx_x_dare_batch_dense_dev(n, dim, L.ptr(A), L.ptr(B), L.ptr(Q), L.ptr(R), float(eps), int(maxiter),
-                                              L.ptr(X), L.ptr(K), L.ptr(iters), L.stream_ptr()), "crx_x_dare_batch_dense_dev")
+                                              L.ptr(X), L.ptr(K), L.ptr(iters), L.stream_ptr(), int(lanes_per_agent)), "crx_x_dare_batch_dense_dev")
     return X, K, iters
 
 

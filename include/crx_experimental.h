@@ -32,11 +32,13 @@ int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_cour
                                     const crx_lqr_params* prm, const crx_vehicle_params* veh, const crx_loop_params* loop,
                                     float* traj_hist, int* ticks_done, void* stream, int lanes_per_agent);
 
-/* crx_dare_batch_dev with the structure detection switched off: every agent through the dense kernel, whatever its matrices
- * look like (the product entry point serves agents whose arguments carry lqr_steering_control's pattern by the structured
- * kernels).  For the A/B of the two paths and for tests that want the dense kernel on the reference's own matrices. */
+/* crx_dare_batch_dev with the structure detection switched off: every agent through a DENSE kernel, whatever its matrices look
+ * like (the product entry point serves agents whose arguments carry lqr_steering_control's pattern by the structured kernels) —
+ * and with the dense kernel's register layout forced: lanes_per_agent = 1 (dare_dense_kernel: one agent per lane), 4
+ * (dare_dense_quad_kernel: one row of X per lane of a quad) or 0 (what the product picks for this n: 4 up to 16,384 agents).
+ * For the A/B of the paths and for tests that want the dense kernels on the reference's own matrices. */
 int crx_x_dare_batch_dense_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
-                               float eps, int maxiter, float* X, float* K, int* iters, void* stream);
+                               float eps, int maxiter, float* X, float* K, int* iters, void* stream, int lanes_per_agent);
 
 /* Probe of the device's double-precision sin / cos (csrc/crx_dsincos.h: glibc 2.35's sin() / cos() restated for the Frenet
  * planner's frenet_optimal_trajectory.cpp:111-112): s[i] = sin(x[i]), c[i] = cos(x[i]) for |x[i]| < 105414336 (NaN beyond). */

@@ -42,7 +42,17 @@ def host(tmp_path_factory):
                                                      C.c_int(maxiter), X.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p))
         assert rc == 0
         return X, it
+    def run_dense_quad(dim, A, B, Q, R, eps=0.01, maxiter=150):
+        n = len(A)
+        X = np.empty((n, dim * dim), dtype=np.float32)
+        it = np.empty(n, dtype=np.int32)
+        keep = [np.ascontiguousarray(a, dtype=np.float32) for a in (A, B, Q, R)]
+        rc = lib.dare_dense_quad_run(C.c_int(n), C.c_int(dim), *[k.ctypes.data_as(C.c_void_p) for k in keep], C.c_float(eps), C.c_int(maxiter),
+                                     X.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p))
+        assert rc == 0, "the lanes of a quad disagree on row 4"
+        return X, it
     run.params = run_params
+    run.dense_quad = run_dense_quad
     return run
 
 
@@ -105,6 +115,36 @@ def test_structured_iteration_over_the_accepted_box(host, oracle_mod, kind, dim)
         X, it = host.params(kind, dim, dt, v, bv, bd, maxiter=maxiter)
         assert np.array_equal(it, ito)
         assert bit_equal(X, Xo)
+
+
+@pytest.mark.parametrize("dim", [5, 4])
+def test_dense_quad_rows_equal_the_dense_oracle(host, oracle_mod, dim):
+    """dare_dense_quad_rows (csrc/dare_dense_math.h) — the dense iteration with one row of X per lane of a quad, row 4 on every lane
+    — run lane by lane on the CPU: the oracle's dense Eigen-order evaluation bit for bit, iteration counts included, on dense random
+    matrices (where the accumulation order of every product matters), on the reference's own matrices, and on matrices whose iterates
+    turn non-finite."""
+    rng = np.random.default_rng(dim)
+    n, m = 1500, (2 if dim == 5 else 1)
+    A = (np.eye(dim)[None] * 0.9 + 0.15 * rng.standard_normal((n, dim, dim))).astype(np.float32)
+    B = rng.standard_normal((n, dim, m)).astype(np.float32)
+    Qh = rng.standard_normal((n, dim, dim)).astype(np.float32)
+    Q = (np.einsum("nij,nkj->nik", Qh, Qh) * 0.2 + np.eye(dim)[None]).astype(np.float32)
+    Rh = rng.standard_normal((n, m, m)).astype(np.float32)
+    R = (np.einsum("nij,nkj->nik", Rh, Rh) + np.eye(m)[None]).astype(np.float32)
+    cm = lambda M: np.ascontiguousarray(np.transpose(M, (0, 2, 1))).reshape(n, -1)
+    for eps, maxiter in ((1e-3, 60), (0.01, 7), (1e9, 3), (0.01, 0)):
+        Xo, _, ito = oracle_mod.dare(cm(A), cm(B), cm(Q), cm(R), eps=eps, maxiter=maxiter)
+        X, it = host.dense_quad(dim, cm(A), cm(B), cm(Q), cm(R), eps=eps, maxiter=maxiter)
+        assert np.array_equal(it, ito)
+        assert np.array_equal(X.view(np.uint32), Xo.view(np.uint32))             # NaN / inf patterns included: the same operations
+    v = lqr_speeds(1000, seed=2)
+    v[:3] = [0.0, 1e30, np.nan]
+    Ar, Br, Qr, Rr = oracle_mod.lqr_build(v, dim)
+    Xo, _, ito = oracle_mod.dare(Ar, Br, Qr, Rr)
+    X, it = host.dense_quad(dim, Ar, Br, Qr, Rr)
+    nan = np.isnan(Xo)
+    assert np.array_equal(it, ito) and np.array_equal(np.isnan(X), nan)          # (a NaN's sign / payload is not part of the contract)
+    assert np.array_equal(X[~nan].view(np.uint32), Xo[~nan].view(np.uint32))
 
 
 def test_block_structure_of_the_reference_iterates(oracle_mod):

@@ -162,6 +162,39 @@ def test_dare_batch_mixed_structured_and_dense_agents(crx, oracle_mod, dim):
     assert np.array_equal(X[~ok].view(np.uint32), X3[~ok].view(np.uint32)) and np.array_equal(K[~ok].view(np.uint32), K3[~ok].view(np.uint32))
 
 
+@pytest.mark.parametrize("lanes", [1, 4])
+@pytest.mark.parametrize("dim", [5, 4])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 2500])
+def test_dare_dense_both_register_layouts(crx, oracle_mod, dim, n, lanes):
+    """The two dense kernels forced (one agent per lane / one row of X per lane of a quad) on dense random matrices — where every
+    product's accumulation order matters — and on the reference's matrices: the oracle's bits, iteration counts included; ragged last
+    quad / wave; caps 0 / 1 / odd / even; agents whose iterates turn non-finite stay non-finite (same NaN / inf positions)."""
+    from cpprobotics_amd.experimental import dare_dense
+    rng = np.random.default_rng(100 * dim + n)
+    m = 2 if dim == 5 else 1
+    A = (np.eye(dim)[None] * 0.9 + 0.15 * rng.standard_normal((n, dim, dim))).astype(np.float32)
+    B = rng.standard_normal((n, dim, m)).astype(np.float32)
+    Qh = rng.standard_normal((n, dim, dim)).astype(np.float32)
+    Q = (np.einsum("nij,nkj->nik", Qh, Qh) * 0.2 + np.eye(dim)[None]).astype(np.float32)
+    Rh = rng.standard_normal((n, m, m)).astype(np.float32)
+    R = (np.einsum("nij,nkj->nik", Rh, Rh) + np.eye(m)[None]).astype(np.float32)
+    cm = lambda M_: np.ascontiguousarray(np.transpose(M_, (0, 2, 1))).reshape(n, -1)
+    for eps, maxiter in ((1e-3, 60), (0.01, 7), (0.01, 1), (0.01, 0), (1e9, 4)):
+        Xo, Ko, ito = oracle_mod.dare(cm(A), cm(B), cm(Q), cm(R), eps=eps, maxiter=maxiter)
+        X, K, it = dare_dense(_t(cm(A)), _t(cm(B)), _t(cm(Q)), _t(cm(R)), eps=eps, maxiter=maxiter, lanes_per_agent=lanes)
+        X, K, it = X.cpu().numpy(), K.cpu().numpy(), it.cpu().numpy()
+        assert np.array_equal(it, ito)
+        fin = np.isfinite(Xo).all(axis=1) & np.isfinite(Ko).all(axis=1)
+        assert bit_equal(X[fin], Xo[fin]) and bit_equal(K[fin], Ko[fin])
+        assert np.array_equal(np.isfinite(X), np.isfinite(Xo))
+    v = lqr_speeds(n, seed=n)
+    v[0] = 0.0
+    Ar, Br, Qr, Rr = oracle_mod.lqr_build(v, dim)
+    Xo, Ko, ito = oracle_mod.dare(Ar, Br, Qr, Rr)
+    X, K, it = dare_dense(_t(Ar), _t(Br), _t(Qr), _t(Rr), lanes_per_agent=lanes)
+    assert np.array_equal(it.cpu().numpy(), ito) and bit_equal(X.cpu().numpy(), Xo) and bit_equal(K.cpu().numpy(), Ko)
+
+
 @pytest.mark.parametrize("dim", [5, 4])
 def test_dare_dense_general_matrices(crx, oracle_mod, dim):
     """Arbitrary (dense) A, B, Q, R: the order of accumulation matters here."""

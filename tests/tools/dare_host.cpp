@@ -3,8 +3,10 @@
 // lanes in lockstep) — can be checked bit for bit against the oracle without a GPU.
 // Built by tests/test_dare_host.py: g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC.  The loop around the iteration
 // mirrors the kernels': cold start X = I, stop at max|Xn - X| < eps, at most maxiter evaluations.
+#include <cmath>
 #include <cstring>
 #include "../../cpprobotics_amd/csrc/dare_math.h"
+#include "../../cpprobotics_amd/csrc/dare_dense_math.h"
 
 using namespace crx;
 
@@ -86,4 +88,42 @@ extern "C" int dare_quad_run(int n, int dim, const float* vs, double dt_d, doubl
 extern "C" int dare_quad_run_params(int n, int dim, const float* vs, const float* dts, const float* bvs, const float* bds, float eps, int maxiter,
                                     float* Xout, int* iters) {
   return quad_core(n, dim, vs, dts, bvs, bds, 0.0, 1.0, eps, maxiter, Xout, iters);
+}
+
+// The dense iteration in its four-lanes-per-agent form (dare_dense_quad_rows): lane r's code is run for r = 0..3 on the same gathered
+// X, the rows are assembled, and the loop of solve_DARE goes round as in the kernel.  Returns 1 if the lanes disagree on row 4.
+extern "C" int dare_dense_quad_run(int n, int dim, const float* Ag, const float* Bg, const float* Qg, const float* Rg, float eps, int maxiter,
+                                   float* Xout, int* iters) {
+  const int NN = dim * dim, M = dim == 5 ? 2 : 1;
+  for (int a = 0; a < n; ++a) {
+    const float *A = Ag + (size_t)a * NN, *B = Bg + (size_t)a * dim * M, *Q = Qg + (size_t)a * NN, *R = Rg + (size_t)a * M * M;
+    float X[25], Xn[25];
+    std::memcpy(X, Q, sizeof(float) * NN);
+    int it = maxiter < 0 ? 0 : maxiter;
+    for (int i = 0; i < maxiter; ++i) {
+      float row4_first[5];
+      for (int r = 0; r < 4; ++r) {
+        float Acol_r[5], Acol_4[5], Qrow_r[5], Qrow_4[5], xr[5], x4[5];
+        for (int k = 0; k < dim; ++k) { Acol_r[k] = A[k + dim * r]; Acol_4[k] = dim == 5 ? A[k + dim * 4] : 0.0f; }
+        for (int j = 0; j < dim; ++j) { Qrow_r[j] = Q[r + dim * j]; Qrow_4[j] = dim == 5 ? Q[4 + dim * j] : 0.0f; }
+        if (dim == 5) dare_dense_quad_rows<5>(Acol_r, Acol_4, A, B, Qrow_r, Qrow_4, R, X, xr, x4);
+        else dare_dense_quad_rows<4>(Acol_r, Acol_4, A, B, Qrow_r, Qrow_4, R, X, xr, x4);
+        for (int j = 0; j < dim; ++j) Xn[r + dim * j] = xr[j];
+        if (dim == 5) {
+          if (r == 0) std::memcpy(row4_first, x4, sizeof(x4));
+          else if (std::memcmp(row4_first, x4, sizeof(x4)) != 0) return 1;
+          for (int j = 0; j < 5; ++j) Xn[4 + 5 * j] = x4[j];
+        }
+      }
+      // (Xn - X).cwiseAbs().maxCoeff() with the reference's NaN rule (a NaN first element sticks, later NaNs are skipped)
+      float m = std::fabs(Xn[0] - X[0]);
+      const bool first_nan = m != m;
+      for (int e = 1; e < NN; ++e) { const float d = std::fabs(Xn[e] - X[e]); if (d > m) m = d; }
+      std::memcpy(X, Xn, sizeof(float) * NN);
+      if (!first_nan && m < eps) { it = i + 1; break; }
+    }
+    std::memcpy(Xout + (size_t)a * NN, X, sizeof(float) * NN);
+    iters[a] = it;
+  }
+  return 0;
 }

@@ -35,7 +35,7 @@ int crx_x_lqr_closed_loop_lanes_dev(int n, int dim, float* state, const crx_cour
 /* crx_dare_batch_dev with the structure detection switched off: every agent through a DENSE kernel, whatever its matrices look
  * like (the product entry point serves agents whose arguments carry lqr_steering_control's pattern by the structured kernels) —
  * and with the dense kernel's register layout forced: lanes_per_agent = 1 (dare_dense_kernel: one agent per lane), 4
- * (dare_dense_quad_kernel: one row of X per lane of a quad) or 0 (what the product picks for this n: 4 up to 16,384 agents).
+ * (dare_dense_quad_kernel: one row of X per lane of a quad) or 0 (what the product picks for this n: 4 up to 32,768 agents).
  * For the A/B of the paths and for tests that want the dense kernels on the reference's own matrices. */
 int crx_x_dare_batch_dense_dev(int n, int dim, const float* A, const float* B, const float* Q, const float* R,
                                float eps, int maxiter, float* X, float* K, int* iters, void* stream, int lanes_per_agent);

@@ -13,7 +13,7 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles",
 os.makedirs(dst, exist_ok=True)
 KEEP = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
         "Counter_Name", "Counter_Value"]
-SIDE = ["mpc_kernel", "mpc_quad_kernel", "mpc_portfolio_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "dare_from_v_masked_kernel", "dare_dense_kernel", "lqr_closed_loop"]
+SIDE = ["mpc_kernel", "mpc_quad_kernel", "mpc_portfolio_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "dare_from_v_masked_kernel", "dare_dense_kernel", "dare_dense_quad_kernel", "lqr_closed_loop"]
 done = []
 
 

@@ -56,7 +56,8 @@ Bg = torch.from_numpy(rng.standard_normal((16384, 10)).astype(np.float32)).cuda(
 for _ in range(reps):
     crx.solve_DARE(A, B, Qm, Rm)
 for _ in range(max(1, reps // 3)):
-    Xd, Kd, itd = dare_dense(A, B, Qm, Rm)
+    Xd, Kd, itd = dare_dense(A, B, Qm, Rm)                      # 16,384 agents: the quad layout (dare_dense_quad_kernel)
+    dare_dense(A, B, Qm, Rm, lanes_per_agent=1)                # and the one-lane layout beside it
     Xg, itg = crx.solve_DARE(Ag, Bg, Qm, Rm, eps=1e-3, maxiter=60)
 itd, itg = itd.cpu().numpy().astype(np.int64), itg.cpu().numpy().astype(np.int64)
 x0, xref = mpc_problem(8192, 21, 4)
@@ -86,8 +87,9 @@ pit = (stp.cpu().numpy() >> 8).astype(np.int64)
 wsum = lambda a, k: int(a.reshape(-1, k).max(axis=1).sum())
 print(json.dumps({"dare5": {"agents": 16384, "iters_sum": int(it5.sum()), "wave_max_iters_sum": wsum(it5, 64)},
                   "dare5_quad": {"agents": 16384, "iters_sum": int(it5.sum()), "wave_max_iters_sum": wsum(it5, 16)},
-                  "dare5_dense_reference_matrices": {"agents": 16384, "iters_sum": int(itd.sum()), "wave_max_iters_sum": wsum(itd, 64)},
-                  "dare5_dense_general_matrices": {"agents": 16384, "iters_sum": int(itg.sum()), "wave_max_iters_sum": wsum(itg, 64)},
+                  "dare5_dense_reference_matrices": {"agents": 16384, "iters_sum": int(itd.sum()), "wave_max_iters_sum": wsum(itd, 16)},
+                  "dare5_dense_reference_matrices_one_lane": {"agents": 16384, "iters_sum": int(itd.sum()), "wave_max_iters_sum": wsum(itd, 64)},
+                  "dare5_dense_general_matrices": {"agents": 16384, "iters_sum": int(itg.sum()), "wave_max_iters_sum": wsum(itg, 16)},
                   "mpc_T21": {"agents": 8192, "iters_sum": int(mit.sum()), "iters_max": int(mit.max()), "wave_max_iters_sum": wsum(mit, 64)},
                   "mpc_T21_quad": {"agents": 8192, "iters_sum": int(mit.sum()), "iters_max": int(mit.max()), "wave_max_iters_sum": wsum(mit, 16)},
                   "mpc_T21_portfolio": {"agents": 8192, "iters_sum": int(pit.sum()), "iters_max": int(pit.max()), "wave_max_iters_sum": wsum(pit, 16)}}))

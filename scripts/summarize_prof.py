@@ -69,11 +69,13 @@ for log in ("side_flop.log", "side_sq.log", "side_stats.log"):
             if line.startswith('{"dare5"'):
                 info = json.loads(line)
 side = {}
-# the dense kernel runs twice in prof_kernels.py — forced on the reference's matrices (SKIP_STRUCTURED = false) and behind the product
-# entry point on general matrices (SKIP_STRUCTURED = true): two instantiations, told apart by their template argument
+# the dense kernels in prof_kernels.py — forced on the reference's matrices (SKIP_STRUCTURED = false; the quad layout a batch of 16,384
+# gets, and the one-lane layout beside it) and behind the product entry point on general matrices (SKIP_STRUCTURED = true): told apart
+# by name and template argument
 for key, kern in (("dare5", "dare_from_v_kernel<5, crx::DareFromV"), ("dare5_quad", "dare_from_v_quad_kernel<5, crx::DareFromV"),
                   ("dare5_signature_quad", "dare_from_v_quad_kernel<5, crx::DareFromMats"),
-                  ("dare5_dense_reference_matrices", "dare_dense_kernel<5, false"), ("dare5_dense_general_matrices", "dare_dense_kernel<5, true"),
+                  ("dare5_dense_reference_matrices", "dare_dense_quad_kernel<5, false"), ("dare5_dense_reference_matrices_one_lane", "dare_dense_kernel<5, false"),
+                  ("dare5_dense_general_matrices", "dare_dense_quad_kernel<5, true"),
                   ("mpc_T21", "mpc_kernel<24"), ("mpc_T21_quad", "mpc_quad_kernel<24"), ("mpc_T21_portfolio", "mpc_portfolio_kernel<24")):
     c, n = counters("side_sq", kern)
     f, _ = counters("side_flop", kern)

@@ -506,8 +506,13 @@ int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const floa
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   const crx::EkfConsts k = make_consts(Q, R, prm);
-  hipLaunchKernelGGL(crx::ekf_step_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     n, x, P, z, u, k);
+  const dim3 grid(blocks_for(n, CRX_EKF_STEP_BLOCK)), block(CRX_EKF_STEP_BLOCK);
+#ifdef CRX_EKF_STEP_NT_FORCE     // A/B builds only (scripts/experiments/gpu_ekf_step_ab.sh)
+  hipLaunchKernelGGL(crx::ekf_step_kernel<(CRX_EKF_STEP_NT_FORCE != 0)>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+#else
+  if (n >= crx::kEkfStepNtMinN) hipLaunchKernelGGL(crx::ekf_step_kernel<true>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+  else hipLaunchKernelGGL(crx::ekf_step_kernel<false>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+#endif
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }
@@ -1862,6 +1867,38 @@ int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long lon
   if (ocml_diff) CRX_HIP(hipMemsetAsync(ocml_diff, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
   if (diff_k) CRX_HIP(hipMemsetAsync(diff_k, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
   hipLaunchKernelGGL(crx::datan2_sweep_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, L, sums, ocml_diff, diff_k);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// HBM calibration (scripts/gpu_hbm_calib.py): what a plain streaming kernel reaches on this box, next to the 8 TB/s the rooflines are
+// priced against.  mode 0: dst = src (read + write), 1: read only (a word per workgroup written), 2: write only, 3: dst += 1 in place
+// (read and write of the same lines: the single-step EKF's traffic shape).  16 bytes per lane per access, grid-stride.
+namespace crx {
+__global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v4f* __restrict__ dst, const v4f* __restrict__ src) {
+  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (mode == 0) {
+    for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+  } else if (mode == 1) {
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = i0; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[blockIdx.x] = acc;     // keeps the loads alive; practically never true
+  } else if (mode == 2) {
+    for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(v4f{1.f, 2.f, 3.f, 4.f}, dst + i);
+  } else {
+    for (size_t i = i0; i < n16; i += stride) dst[i] = dst[i] + v4f{1.f, 1.f, 1.f, 1.f};
+  }
+}
+}  // namespace crx
+int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream) {
+  CRX_TRACE();
+  if (mode < 0 || mode > 3 || !dst || ((mode == 0 || mode == 1) && !src) || bytes % 16 || workgroups < 1)
+    return fail(CRX_ERR_INVALID, "hbm_stream: bad arguments (bytes a multiple of 16)");
+  if (int rc = check_device()) return rc;
+  const size_t n16 = bytes / 16;
+  auto* d = (crx::v4f*)dst; auto* sp = (const crx::v4f*)src;
+  const dim3 g((unsigned)workgroups), b(256);
+  hipLaunchKernelGGL(crx::hbm_stream_kernel, g, b, 0, (hipStream_t)stream, mode, n16, d, sp);
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -61,26 +61,38 @@ __device__ __forceinline__ void store_P(const EkfState& s, float* __restrict__ P
 // per-lane registers, each 16-byte access lands in a different 64-byte block (32 cache lines per instruction).  Full
 // waves therefore move the span in four 1-KiB row pieces (16 contiguous bytes per lane) and transpose through a
 // wave-private LDS tile (lane stride 80 B: conflict-free b128 accesses); a ragged last wave uses the direct form.
-#ifndef CRX_EKF_STEP_LDS
-#define CRX_EKF_STEP_LDS 1
+// The step itself is the fused kernel's packed fast step (ekf_math.h) since round 4; a wave with a lane outside its domain
+// (yaw = +-0, |yaw| >= 120, extreme determinant) reloads its input — nothing has been stored yet — and takes the general step:
+// the same bits either way.
+// NT: how the covariance rows pass the caches.  When a filter loop launches step after step on a batch whose state (160 B per
+// vehicle) is well beyond the 256-MB Infinity Cache, the dirty lines the previous launch left behind are in the way of the next
+// one; nontemporal loads / stores of the 4-KiB covariance rows avoid that — back-to-back launches, 4 M vehicles 0.145 -> 0.118 ms,
+// 8 M 0.277 -> 0.217 ms (6.8 TB/s) — while batches the cache holds lose 1-2 % (crossover measured at ~3 M vehicles;
+// x, z, u nontemporal as well: slower everywhere; profiles/r04/ekf_step_ab.jsonl).  The host picks by batch size (kEkfStepNtMinN).
+#ifndef CRX_EKF_STEP_BLOCK
+#define CRX_EKF_STEP_BLOCK 256      // lanes per workgroup (a multiple of 64); the LDS tile is private to a wave
 #endif
-__global__ void __launch_bounds__(256)
+constexpr int kEkfStepNtMinN = 3 << 20;    // 3 M vehicles: 503 MB of state
+template <bool NT>
+__global__ void __launch_bounds__(CRX_EKF_STEP_BLOCK)
 ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float* __restrict__ z,
                 const float* __restrict__ u, EkfConsts k) {
-  __shared__ v4f s_pt[CRX_EKF_STEP_LDS ? 4 * 64 * 5 : 1];
+  __shared__ v4f s_pt[(CRX_EKF_STEP_BLOCK / 64) * 64 * 5];
   const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const size_t wave0 = a - lane;                       // first vehicle of this wave
-  const bool full_wave = CRX_EKF_STEP_LDS && wave0 + 64 <= (size_t)n;
+  const bool full_wave = wave0 + 64 <= (size_t)n;
   if (a >= (size_t)n) return;
   EkfState s;
   v4f* __restrict__ tile = s_pt + wv * (64 * 5);
+  v4f* __restrict__ xp = reinterpret_cast<v4f*>(x) + a;
   if (full_wave) {
-    const float4 xv = reinterpret_cast<const float4*>(x)[a];
+    const v4f xv = *xp;
     s.x0 = xv.x; s.x1 = xv.y; s.x2 = xv.z; s.x3 = xv.w;
     const v4f* __restrict__ row = reinterpret_cast<const v4f*>(P) + 4 * wave0;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)] = row[64 * kk + lane];
+    for (int kk = 0; kk < 4; ++kk)
+      tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)] = NT ? __builtin_nontemporal_load(row + 64 * kk + lane) : row[64 * kk + lane];
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -90,10 +102,22 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
   } else {
     load_state(s, x, P, a);
   }
-  const float2 zv = reinterpret_cast<const float2*>(z)[a];
-  const float2 uv = reinterpret_cast<const float2*>(u)[a];
-  ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);
-  reinterpret_cast<float4*>(x)[a] = make_float4(s.x0, s.x1, s.x2, s.x3);
+  const v2f* __restrict__ zp = reinterpret_cast<const v2f*>(z) + a;
+  const v2f* __restrict__ up = reinterpret_cast<const v2f*>(u) + a;
+  const v2f zv = *zp, uv = *up;
+  {
+    EkfStateP sp;
+    pack_state(sp, s);
+    FastDomain dom = fast_domain_init();
+    ekf_step_packed(sp, zv, uv, pack_consts(k), dom);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_domain_ok(dom)) != 0, 0)) {
+      load_state(s, x, P, a);
+      ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);
+    } else {
+      unpack_state(s, sp);
+    }
+  }
+  *xp = v4f{s.x0, s.x1, s.x2, s.x3};
   if (full_wave) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -101,7 +125,10 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
     __builtin_amdgcn_wave_barrier();
     v4f* __restrict__ row = reinterpret_cast<v4f*>(P) + 4 * wave0;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) row[64 * kk + lane] = tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)];
+    for (int kk = 0; kk < 4; ++kk) {
+      const v4f po = tile[(16u * kk + (lane >> 2)) * 5u + (lane & 3u)];
+      if (NT) __builtin_nontemporal_store(po, row + 64 * kk + lane); else row[64 * kk + lane] = po;
+    }
   } else {
     store_P(s, P, a);
   }

@@ -16,6 +16,7 @@ _X_SIGNATURES = {
     "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
     "crx_x_datan2_dev": (_I, [_I, _P, _P, _P]),
     "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
+    "crx_x_hbm_stream_dev": (_I, [_I, _P, _P, C.c_size_t, _I, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
@@ -205,6 +206,14 @@ def datan2_sweep(wheelbase=0.5, device="cuda"):
     L.check(xlib().crx_x_datan2_sweep_dev(float(wheelbase), L.ptr(sums), L.ptr(diff), L.ptr(ks), L.stream_ptr()), "crx_x_datan2_sweep_dev")
     m = int(min(64, diff[1].item()))
     return sums, diff[:2], ks[:m].view(torch.float32)
+
+
+def hbm_stream(mode, dst, src=None, workgroups=8192):
+    """The calibration kernel over dst's bytes: mode 0 dst = src, 1 read src, 2 write dst, 3 dst += 1 in place."""
+    L.require_cuda(dst, src)
+    nbytes = dst.numel() * dst.element_size()
+    L.check(xlib().crx_x_hbm_stream_dev(int(mode), L.ptr(dst), L.ptr(src) if src is not None else None, nbytes, int(workgroups), L.stream_ptr()),
+            "crx_x_hbm_stream_dev")
 
 
 def closed_loop_prediction_lanes(state, course, goal, lanes_per_agent, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L_wheelbase=0.5, eps=0.01,

@@ -5,6 +5,7 @@
  * cpprobotics_amd/ outside `cpprobotics_amd/experimental.py`; results are the same bits as the product path's. */
 #ifndef CRX_EXPERIMENTAL_H
 #define CRX_EXPERIMENTAL_H
+#include <stddef.h>
 #include "crx.h"
 #ifdef __cplusplus
 extern "C" {
@@ -55,6 +56,12 @@ int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream
  * adversarial inputs of tests/test_track_gpu.py. */
 int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
 int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
+
+/* HBM calibration: a plain streaming kernel over `bytes` (a multiple of 16) with `workgroups` workgroups of 256 lanes, 16 bytes per
+ * lane per access.  mode 0: dst = src, 1: read src only, 2: write dst only, 3: dst += 1 in place (the single-step EKF's traffic
+ * shape: every line read, then written).  scripts/gpu_hbm_calib.py and bench.py (`extra.hbm_calibration`) time it next to the
+ * HBM-bound EKF launches. */
+int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream);
 
 /* crx_ekf_run_batch_dev through the 64-bit-address instantiations of the fused kernel whatever n is (the product entry point
  * switches to them above 4 M vehicles). */

@@ -43,6 +43,64 @@ def test_ekf_single_step_bit_exact(crx, oracle_mod, n):
         assert bit_equal(Pd.cpu().numpy(), P), f"P differs at step {t}"
 
 
+def test_ekf_single_step_outside_the_fast_domain(crx, oracle_mod):
+    """The single-step kernel runs the packed fast step (round 4) and sends a wave to the general step when one of its lanes has
+    yaw = +-0, |yaw| >= 120, a non-finite state or an extreme determinant: wide-range fuzz in which waves of every mix occur, a
+    ragged last wave included.  Vehicles whose reference step is finite must agree bit for bit."""
+    rng = np.random.default_rng(77)
+    n = 64 * 11 + 5
+    def wide(shape, lo, hi):
+        return (rng.choice([-1.0, 1.0], shape) * np.exp(rng.uniform(lo, hi, shape) * np.log(10.0))).astype(np.float32)
+    x0 = wide((n, 4), -20, 8)
+    x0[:, 2] = wide(n, -45, 3)                       # yaw from denormal to 1000 rad
+    x0[: 64 * 4, 2] = rng.uniform(-3, 3, 64 * 4).astype(np.float32)          # four waves wholly inside the domain ...
+    x0[64 * 2 + 5, 2] = 0.0; x0[64 * 3 + 9, 2] = 121.0                       # ... two of them with a single lane outside
+    A = rng.standard_normal((n, 4, 4)).astype(np.float32)
+    P0 = (np.einsum("nij,nkj->nik", A, A) * wide((n, 1, 1), -30, 30)).astype(np.float32).reshape(n, 16)
+    P0[: 64 * 4] = (np.einsum("nij,nkj->nik", A[:256], A[:256]) + np.eye(4, dtype=np.float32)).reshape(256, 16)
+    z, ud = wide((n, 2), -10, 6), wide((n, 2), -10, 2)
+    z[: 64 * 4], ud[: 64 * 4] = rng.uniform(-5, 5, (256, 2)), rng.uniform(-1, 1, (256, 2))
+    x0[300, 2] = np.inf; x0[370, 0] = np.nan; P0[430, 5] = np.inf; z[500, 0] = np.nan; ud[600, 1] = np.inf
+    for qs, rs in ((1.0, 1.0), (1e-10, 1e-8), (1e18, 1e20)):
+        Q0, R0 = ekf_QR()
+        Q, R = (Q0 * np.float32(qs)).astype(np.float32), (R0 * np.float32(rs)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            xo, Po = oracle_mod.ekf_step(x0, P0, z, ud, Q, R)
+        xd, Pd = _t(x0), _t(P0)
+        crx.ekf_estimation(xd, Pd, _t(z), _t(ud), Q, R)
+        ok = np.isfinite(xo).all(axis=1) & np.isfinite(Po).all(axis=1)
+        assert ok.sum() > 300 and ok[:256].sum() >= 250
+        # IEEE equality (SURVEY.md A.4: skipping the products by literal 0 / 1 entries can flip the sign of an exact zero, nothing else)
+        assert bit_equal(xd.cpu().numpy()[ok], xo[ok]) and bit_equal(Pd.cpu().numpy()[ok], Po[ok])
+        assert not (np.isfinite(xd.cpu().numpy()[~ok]).all(axis=1) & np.isfinite(Pd.cpu().numpy()[~ok]).all(axis=1)).any()
+
+
+def test_ekf_single_step_streaming_variant_equals_the_plain_one(crx):
+    """From 3 M vehicles on the covariance rows go past the caches (nontemporal loads / stores, ekf_step_kernel<true>): the same
+    arithmetic — the first vehicles of a 3 M + 70 batch end with the bits a small batch (plain accesses) gives them, three steps."""
+    import torch
+    Q, R = ekf_QR()
+    n, m = (3 << 20) + 70, 64 * 40 + 70
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    x = torch.zeros((n, 4), dtype=torch.float32, device="cuda"); x[:, 2] = torch.rand(n, device="cuda", generator=g) * 6 - 3
+    A = torch.randn((n, 4, 4), device="cuda", generator=g)
+    P = (A @ A.transpose(1, 2) + torch.eye(4, device="cuda")).reshape(n, 16).contiguous()
+    del A
+    z = torch.rand((3, n, 2), device="cuda", generator=g) * 4; u = torch.rand((3, n, 2), device="cuda", generator=g)
+    tail = slice(n - m, n)                                   # the ragged last wave is in here
+    xs, Ps = x[tail].clone(), P[tail].clone()
+    xh, Ph = x[:m].clone(), P[:m].clone()
+    for t in range(3):
+        crx.ekf_estimation(x, P, z[t], u[t], Q, R)
+        crx.ekf_estimation(xs, Ps, z[t, tail].contiguous(), u[t, tail].contiguous(), Q, R)
+        crx.ekf_estimation(xh, Ph, z[t, :m].contiguous(), u[t, :m].contiguous(), Q, R)
+    assert torch.equal(x[:m].view(torch.int32), xh.view(torch.int32)) and torch.equal(P[:m].view(torch.int32), Ph.view(torch.int32))
+    # the tail batch starts at a vehicle index that is not a multiple of 64, so wave membership differs there: the fast path and its
+    # general-step fallback agree bit for bit, hence so do the two runs
+    assert torch.equal(x[tail].view(torch.int32), xs.view(torch.int32)) and torch.equal(P[tail].view(torch.int32), Ps.view(torch.int32))
+    assert torch.isfinite(x).all() and torch.isfinite(P).all()
+
+
 @pytest.mark.parametrize("n,T", [(1, 1000), (64, 1), (65, 7), (100, 8), (257, 9), (1024, 200), (300, 17)])
 def test_ekf_fused_run_bit_exact(crx, oracle_mod, n, T):
     import torch

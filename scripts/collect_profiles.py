@@ -13,7 +13,7 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles",
 os.makedirs(dst, exist_ok=True)
 KEEP = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
         "Counter_Name", "Counter_Value"]
-SIDE = ["mpc_kernel", "mpc_quad_kernel", "mpc_portfolio_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "dare_from_v_masked_kernel", "dare_dense_kernel", "dare_dense_quad_kernel", "lqr_closed_loop"]
+SIDE = ["mpc_kernel", "mpc_quad_kernel", "mpc_portfolio_kernel", "dare_from_v_kernel", "dare_from_v_quad_kernel", "dare_from_v_masked_kernel", "dare_dense_kernel", "dare_dense_quad_kernel", "ekf_step_kernel", "lqr_closed_loop"]
 done = []
 
 
@@ -77,7 +77,8 @@ stats("side_stats", "side_kernel_stats.csv", SIDE)
 stats("swarm_stats", "swarm_kernel_stats.csv", ["crx::"])
 for name in ("fetch", "write", "sq"):
     counters(f"pmc_{name}", f"pmc_{name}_ekf_run_kernel.csv", ["ekf_run_kernel"])
-for name, o in (("side_sq", "side_pmc_sq.csv"), ("side_flop", "side_pmc_flop.csv"), ("side_sq2", "side_pmc_sq2.csv")):
+for name, o in (("side_sq", "side_pmc_sq.csv"), ("side_flop", "side_pmc_flop.csv"), ("side_sq2", "side_pmc_sq2.csv"),
+                ("side_fetch", "side_pmc_fetch.csv"), ("side_write", "side_pmc_write.csv")):
     counters(name, o, SIDE)
 p = os.path.join(src, "prof")
 for f in ("summary.txt", "traffic.json", "side_counters.json"):

@@ -2,7 +2,8 @@
 # rocprofv3 passes on one MI355X: kernel stats and PMC counters — always in separate runs, never combined with tracing domains — for
 #   ekf    the fused EKF launch of bench.py (kernel stats; FETCH_SIZE / WRITE_SIZE / SQ_* counter passes -> traffic.json)
 #   side   the DARE (structured in both layouts, dense-signature, dense kernel) and MPC launches of scripts/prof_kernels.py
-#          (kernel stats; SQ_* / flop / scalar-memory counter passes -> side_counters.json)
+#          and the single-step EKF update at 4 M / 1 M vehicles (kernel stats; SQ_* / flop / scalar-memory / FETCH_SIZE / WRITE_SIZE
+#          counter passes -> side_counters.json)
 #   swarm  one shard of the mixed swarm round (kernel stats)
 #   marks  a --marker-trace + --kernel-trace pass of a few host-pointer calls: the roctx ranges crx puts around every entry point
 # Usage (through gpurun): bash scripts/gpu_prof.sh TAG [ekf side swarm marks]     (default: ekf side marks)
@@ -28,6 +29,8 @@ for w in $WHAT; do
       timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/side_stats -o side -- $K 10 > $OUT/side_stats.log 2>&1
       timeout 300 rocprofv3 --output-format csv --pmc $SQ -d $OUT/side_sq -o side -- $K 3 > $OUT/side_sq.log 2>&1
       timeout 300 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 -d $OUT/side_flop -o side -- $K 3 > $OUT/side_flop.log 2>&1
+      timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/side_fetch -o side -- $K 2 > $OUT/side_fetch.log 2>&1
+      timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/side_write -o side -- $K 2 > $OUT/side_write.log 2>&1
       timeout 300 rocprofv3 --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM -d $OUT/side_sq2 -o side -- $K 3 > $OUT/side_sq2.log 2>&1 ;;
     swarm)
       timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/swarm_stats -o swarm -- python $REPO/scripts/swarm_bench.py --agents 131072 --steps 10 > $OUT/swarm.json 2> $OUT/swarm.err ;;

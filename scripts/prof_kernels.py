@@ -81,6 +81,17 @@ for lanes in (1, 4):
     for dim in (5, 4):
         for _ in range(max(1, reps // 3)):
             closed_loop_prediction_lanes(stl.clone(), dc, goal, lanes, dim=dim, max_ticks=400)
+# the single-step EKF update in its HBM-bound regime: 4 M vehicles (ekf_step_kernel<true>, covariance rows past the caches) and 1 M
+# (ekf_step_kernel<false>), back-to-back launches; the FETCH_SIZE / WRITE_SIZE passes of gpu_prof.sh give their HBM traffic per launch
+Qe, Re = ekf_QR()
+for nstep in (1 << 22, 1 << 20):
+    xs_ = torch.zeros((nstep, 4), dtype=torch.float32, device="cuda")
+    Ps_ = torch.eye(4, dtype=torch.float32, device="cuda").reshape(1, 16).repeat(nstep, 1).contiguous()
+    zs_ = torch.randn((nstep, 2), dtype=torch.float32, device="cuda")
+    us_ = torch.tensor([1.0, 0.1], dtype=torch.float32, device="cuda").repeat(nstep, 1).contiguous()
+    for _ in range(reps + 2):
+        crx.ekf_estimation(xs_, Ps_, zs_, us_, Qe, Re)
+    del xs_, Ps_, zs_, us_
 torch.cuda.synchronize()
 mit = (st.cpu().numpy() >> 8).astype(np.int64)
 pit = (stp.cpu().numpy() >> 8).astype(np.int64)

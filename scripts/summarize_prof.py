@@ -69,6 +69,19 @@ for log in ("side_flop.log", "side_sq.log", "side_stats.log"):
             if line.startswith('{"dare5"'):
                 info = json.loads(line)
 side = {}
+# single-step EKF update: HBM traffic per launch against its 176 algorithmic bytes per update (the two batch sizes are two template
+# instantiations; the FETCH_SIZE correction as for the fused launch above)
+for key, kern, nveh in (("ekf_step_4M_streaming_rows", "ekf_step_kernel<true>", 1 << 22), ("ekf_step_1M", "ekf_step_kernel<false>", 1 << 20)):
+    f, _ = counters("side_fetch", kern)
+    w, _ = counters("side_write", kern)
+    c, _ = counters("side_sq", kern)
+    if f and w:
+        fb, wb = f["FETCH_SIZE"] * 1024 * 2, w["WRITE_SIZE"] * 1024
+        side[key] = {"kernel": "crx::" + kern, "vehicles": nveh, "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
+                     "algorithmic_bytes_per_launch": 176.0 * nveh, "traffic_over_algorithmic": (fb + wb) / (176.0 * nveh),
+                     "read_over_algorithmic_read": fb / (96.0 * nveh), "write_over_algorithmic_write": wb / (80.0 * nveh),
+                     "sq_counters_per_launch": c}
+        print(key, side[key])
 # the dense kernels in prof_kernels.py — forced on the reference's matrices (SKIP_STRUCTURED = false; the quad layout a batch of 16,384
 # gets, and the one-lane layout beside it) and behind the product entry point on general matrices (SKIP_STRUCTURED = true): told apart
 # by name and template argument

@@ -128,7 +128,8 @@ dare_dense_kernel(int n, const float* __restrict__ Ag, const float* __restrict__
 // one-lane waves on 1,024 SIMDs, ~1,020 instructions per evaluation issued by one wave).  Here an agent is a quad: lane r holds row
 // r of X and (5x5) a copy of row 4, gathers the other rows once per evaluation as DPP quad_perm broadcasts and runs
 // dare_dense_quad_rows (dare_dense_math.h) — its own row and row 4 of every product of :91, 2/5 of the agent's evaluation (1/4 for
-// 4x4) — so the batch fills every SIMD and an evaluation is ~2.5x shorter.  Same accumulation order per coefficient, same bits
+// 4x4) — so the batch fills every SIMD and an evaluation is ~2x shorter (5x5: 256 VGPRs + 26 AGPRs, one wave per SIMD; capped at
+// 256 registers for two waves per SIMD it spills 96 B and gains nothing at 32,768 agents: two waves share one VALU).  Same accumulation order per coefficient, same bits
 // (tests/test_dare_host.py runs the lane code on the CPU against the oracle; tests/test_lqr_gpu.py the kernel).
 template <int DIM, bool SKIP_STRUCTURED>
 __global__ void __launch_bounds__(256)

@@ -87,6 +87,14 @@ inline unsigned blocks_for(size_t n, unsigned bs) { return (unsigned)((n + bs - 
 // Largest batch the four-lanes-per-agent Riccati kernel is selected for (measured crossover: profiles/r03/dare_lanes_ab.txt).
 constexpr int kDareQuadMaxAgents = 32768;
 constexpr int kDareDenseQuadMaxAgents = 32768;   // dense kernels: a quad per agent up to here (measured crossover: profiles/r04/dare_dense_lanes_ab.jsonl: 1.9-2.2x at 16,384, 1.1-1.6x at 32,768, 0.5-0.9x at 65,536)
+constexpr int kDareRefillMinAgents = 262144;  // one lane per agent, lanes refilled (dare_from_v_refill_kernel) above this: 1.04x there, 1.55x at 1 M, 1.70x at 4 M agents (profiles/r04/dare_refill_ab.jsonl)
+constexpr int kDareRefillHold = 16;           // finished lanes a wave collects before it hands their agents back in one pass (8-16 measured best)
+// agents per wave of the refilling kernel: two waves per SIMD, 256 .. 1,024 agents (a multiple of 64); 0 = the batch is too small
+inline int dare_refill_chunk(int n) {
+  if (n <= kDareRefillMinAgents) return 0;
+  const int per = ((n / 2048 + 63) / 64) * 64;
+  return per < 256 ? 256 : (per > 1024 ? 1024 : per);
+}
 constexpr int kDareChainMaxAgents = 98304;   // one lane per agent: the unmasked two-evaluations-per-branch loop up to here (profiles/r03/dare_lanes_ab.txt)
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower
@@ -890,6 +898,11 @@ static int dare_batch_launch(int n, int dim, const float* A, const float* B, con
     } else if (n <= kDareChainMaxAgents) {
       if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_kernel<5, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
       else hipLaunchKernelGGL((crx::dare_from_v_kernel<4, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
+    } else if (maxiter > 0 && dare_refill_chunk(n)) {
+      const int chunk = dare_refill_chunk(n);
+      const dim3 rgrid(blocks_for(n, chunk));
+      if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_refill_kernel<5, crx::DareFromMats>), rgrid, block, 0, s, n, chunk, kDareRefillHold, src, eps, maxiter, X, K, iters);
+      else hipLaunchKernelGGL((crx::dare_from_v_refill_kernel<4, crx::DareFromMats>), rgrid, block, 0, s, n, chunk, kDareRefillHold, src, eps, maxiter, X, K, iters);
     } else {
       if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_masked_kernel<5, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
       else hipLaunchKernelGGL((crx::dare_from_v_masked_kernel<4, crx::DareFromMats>), grid, block, 0, s, n, src, eps, maxiter, X, K, iters);
@@ -920,8 +933,10 @@ int crx_x_dare_batch_dense_dev(int n, int dim, const float* A, const float* B, c
 }
 
 // lanes_per_agent: 1 = dare_from_v_kernel, 4 = dare_from_v_quad_kernel, 0 = chosen by batch size.
+// refill_chunk: agents per wave of the lane-refilling kernel; 0 = the product's choice (dare_refill_chunk: above 262,144 agents,
+// no refilling below), -1 = never (the masked kernel: rounds 2-3's throughput-regime kernel, kept for the A/B)
 static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
-                              int* iters, void* stream, int lanes_per_agent) {
+                              int* iters, void* stream, int lanes_per_agent, int refill_chunk = 0, int refill_hold = kDareRefillHold) {
   if (n < 0 || (dim != 4 && dim != 5) || (n && !v))
     return fail(CRX_ERR_INVALID, "dare_from_v: bad argument (dim must be 4 or 5)");
   if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
@@ -945,6 +960,14 @@ static int dare_from_v_launch(int n, int dim, const float* v, const crx_lqr_para
     // up to ~1.5 waves per SIMD the launch is a latency chain: nobody masked off, two evaluations per branch (89 VGPRs); beyond,
     // the masked loop at eight waves per SIMD (60 VGPRs)
     const bool chain = n <= kDareChainMaxAgents;
+    if (refill_chunk == 0) refill_chunk = dare_refill_chunk(n) ? dare_refill_chunk(n) : -1;
+    if (refill_chunk > 0 && p.maxiter > 0) {
+      const dim3 rgrid(blocks_for(n, refill_chunk));
+      if (dim == 5) hipLaunchKernelGGL((crx::dare_from_v_refill_kernel<5, crx::DareFromV>), rgrid, block, 0, (hipStream_t)stream, n, refill_chunk, refill_hold, src, p.eps, p.maxiter, X, K, iters);
+      else hipLaunchKernelGGL((crx::dare_from_v_refill_kernel<4, crx::DareFromV>), rgrid, block, 0, (hipStream_t)stream, n, refill_chunk, refill_hold, src, p.eps, p.maxiter, X, K, iters);
+      CRX_HIP(hipGetLastError());
+      return CRX_OK;
+    }
 #define CRX_LAUNCH_DV(KERNEL, DIM) \
     hipLaunchKernelGGL((crx::KERNEL<DIM, crx::DareFromV>), grid, block, 0, (hipStream_t)stream, n, src, p.eps, p.maxiter, X, K, iters)
     if (dim == 5) { if (chain) CRX_LAUNCH_DV(dare_from_v_kernel, 5); else CRX_LAUNCH_DV(dare_from_v_masked_kernel, 5); }
@@ -965,6 +988,15 @@ int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_pa
                                 int* iters, void* stream, int lanes_per_agent) {
   CRX_TRACE();
   return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, lanes_per_agent);
+}
+
+int crx_x_dare_from_v_refill_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                                 int* iters, void* stream, int agents_per_wave, int hold_lanes) {
+  CRX_TRACE();
+  if (agents_per_wave != -1 && (agents_per_wave < 64 || agents_per_wave > (1 << 20)))
+    return fail(CRX_ERR_INVALID, "dare_from_v_refill: agents_per_wave must be -1 (the masked kernel) or 64 .. 2^20");
+  if (hold_lanes < 1 || hold_lanes > 64) return fail(CRX_ERR_INVALID, "dare_from_v_refill: hold_lanes must be 1 .. 64");
+  return dare_from_v_launch(n, dim, v, prm, X, K, iters, stream, 1, agents_per_wave, hold_lanes);
 }
 
 int crx_dare_batch(int n, int dim, const float* A, const float* B, const float* Q, const float* R, float eps,

@@ -507,6 +507,112 @@ dare_from_v_kernel(int n, const Src src, float eps, int maxiter,
   riccati_from_v_emit<DIM>(dt, v, bv, bd, eps, maxiter, __builtin_amdgcn_ballot_w64(live), emit);
 }
 
+// ---------- one lane per agent, lanes refilled (throughput regime) -------------------------------------------------------------
+// With several waves queued on every SIMD what is lost is not latency but lanes: an agent needs 41-150 evaluations (mean 59 at
+// BASELINE configs[2]'s speed distribution) and a wave of the masked kernel lasts as long as its slowest lane — 150 evaluations for
+// 96 % of the waves, 39 % of the lane-evaluations useful.  Here a wave owns a contiguous range of `chunk` agents; a lane whose agent
+// is done holds the result (its evaluations are masked off, as in the masked kernel) until `hold` lanes of the wave hold one — or
+// nobody is iterating — then all of them hand their agents back in one pass (gain, X, K, iteration count to memory) and take the
+// next agents of the range: index = the wave's scalar cursor + the lane's rank among the lanes asking — no atomics, no workspace.
+// (Handing back at once, lane by lane, costs more than it saves: some lane finishes in nine passes out of ten, and the whole wave
+// would walk through the ~200 instructions of the gain and the 36 scattered stores for two lanes each time — measured, 1.2-1.4x
+// instead of the 1.9x of the batched form.)  The wave ends when its range is exhausted and its last agents are done; only that tail
+// and the held lanes idle.  Per agent the same evaluations in the same order as every other kernel of this file (same bits, same
+// iteration counts); the cap is the lane's own count.  Agents whose matrices do not carry the structured pattern (Src =
+// DareFromMats) are skipped: the dense kernel of the launch pair serves them.
+template <int DIM, class Src>
+__global__ void __launch_bounds__(64)
+dare_from_v_refill_kernel(int n, int chunk, int hold, const Src src, float eps, int maxiter,
+                          float* __restrict__ Xg, float* __restrict__ Kg, int* __restrict__ iters) {
+  constexpr int NN = DIM * DIM;
+  constexpr int M = (DIM == 5) ? 2 : 1;
+  const int lo = (int)blockIdx.x * chunk;
+  const int hi = (n - lo < chunk) ? n : lo + chunk;                 // this wave's agents: [lo, hi)
+  const unsigned lane = threadIdx.x;
+  int a = lo + (int)lane;                                          // the lane's current agent
+  int next = lo + 64;                                              // wave-uniform cursor: the first agent nobody has taken yet
+  float dt, v, bv, bd;
+  bool active = src.template load<DIM, 1>((size_t)a, 0, a < hi, dt, v, bv, bd);
+  bool holding = false, in_y = false;
+  dare_mask_t want = ~__builtin_amdgcn_ballot_w64(active);         // lanes without an agent
+  Row4 X[4], Y[4];
+  float x44 = 1.0f, y44 = 1.0f;
+  auto reset = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      X[i].a = (v2f){i == 0 ? 1.0f : 0.0f, i == 1 ? 1.0f : 0.0f};
+      X[i].b = (v2f){i == 2 ? 1.0f : 0.0f, i == 3 ? 1.0f : 0.0f};
+    }
+    x44 = 1.0f;
+  };
+  reset();
+  int count = 0;                                                    // evaluations of the lane's current agent
+  auto iter = [&](const Row4* Xi, const float& xi44, Row4* Xo, float& xo44) -> float {
+    if constexpr (DIM == 5) { dare5_v_iter_pk(dt, v, bv, bd, Xi, xi44, Xo, xo44); return dare_max_abs_diff(Xo, xo44, Xi, xi44); }
+    else { dare4_v_iter_pk(dt, v, bv, Xi, Xo); return dare_max_abs_diff(Xo, Xi); }
+  };
+  for (;;) {
+    const dare_mask_t todo = __builtin_amdgcn_ballot_w64(active);
+    const dare_mask_t held = __builtin_amdgcn_ballot_w64(holding);
+    if (held && (!todo || __builtin_popcountll(held) >= hold)) {    // hand the finished agents back, all at once
+      if (holding) {
+        float Xo[NN];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const Row4& r = in_y ? Y[i] : X[i];
+          Xo[i + DIM * 0] = r.a.x; Xo[i + DIM * 1] = r.a.y; Xo[i + DIM * 2] = r.b.x; Xo[i + DIM * 3] = r.b.y;
+          if constexpr (DIM == 5) { Xo[i + DIM * 4] = 0.0f; Xo[4 + DIM * i] = 0.0f; }
+        }
+        if constexpr (DIM == 5) Xo[24] = in_y ? y44 : x44;
+        const size_t as = (size_t)a;
+        if (Xg) {
+#pragma unroll
+          for (int j = 0; j < NN; ++j) Xg[as * NN + j] = Xo[j];
+        }
+        if (Kg) {
+          float K[M * DIM];
+          if (DIM == 5) dlqr5_v_gain(dt, v, bv, bd, Xo, K);
+          else dlqr4_v_gain(dt, v, bv, Xo, K);
+#pragma unroll
+          for (int j = 0; j < M * DIM; ++j) Kg[as * M * DIM + j] = K[j];
+        }
+        if (iters) iters[as] = count;
+        holding = false;
+      }
+      want |= held;
+    }
+    if (want && next < hi) {                                        // the lanes without an agent take the next ones, in lane order
+      const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+      const bool wants = (want >> lane) & 1;
+      const int mine = next + (int)rank;
+      next += __builtin_popcountll(want);
+      bool got = false;
+      if (wants && mine < hi) {
+        a = mine;
+        got = src.template load<DIM, 1>((size_t)a, 0, true, dt, v, bv, bd);
+        reset();
+        count = 0;
+        active = got;
+      }
+      want &= ~__builtin_amdgcn_ballot_w64(got);
+      continue;                                                     // (the lane of a skipped agent asks again at once)
+    }
+    if (!todo) break;                                               // nothing iterating, nothing held, nothing left to take
+    if (active) {
+      const float m = iter(X, x44, Y, y44);
+      in_y = true;
+      ++count;
+      if (m < eps || count >= maxiter) { active = false; holding = true; }
+    }
+    if (active) {
+      const float m = iter(Y, y44, X, x44);
+      in_y = false;
+      ++count;
+      if (m < eps || count >= maxiter) { active = false; holding = true; }
+    }
+  }
+}
+
 // ---------- four lanes per agent ---------------------------------------------------------------------------------------------
 // BASELINE-sized batches (configs[2]: 16,384 agents) are 256 waves of the kernel above on 1,024 SIMDs, and the launch lasts as
 // long as one wave needs for the 150 evaluations of an agent at the iteration cap: a latency chain on a quarter of the chip.

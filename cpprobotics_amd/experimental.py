@@ -16,6 +16,7 @@ _X_SIGNATURES = {
     "crx_x_dsincos_dev": (_I, [_I, _P, _P, _P, _P]),
     "crx_x_datan2_dev": (_I, [_I, _P, _P, _P]),
     "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
+    "crx_x_dare_from_v_refill_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_hbm_stream_dev": (_I, [_I, _P, _P, C.c_size_t, _I, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
@@ -84,6 +85,24 @@ def dlqr_from_v_lanes(v, dim=5, lanes_per_agent=0, dt=0.1, L_wheelbase=0.5, eps=
     p = _params(dt, L_wheelbase, eps, maxiter)
     L.check(xlib().crx_x_dare_from_v_lanes_dev(n, dim, L.ptr(v), C.byref(p), L.ptr(X), L.ptr(K), L.ptr(iters),
                                                L.stream_ptr(), int(lanes_per_agent)), "crx_x_dare_from_v_lanes_dev")
+    return K, X, iters
+
+
+def dlqr_from_v_refill(v, dim=5, agents_per_wave=512, hold_lanes=16, dt=0.1, L_wheelbase=0.5, eps=0.01, maxiter=150):
+    """dlqr_from_v, one agent per lane, through the lane-refilling kernel with `agents_per_wave` agents per wave, handed back
+    `hold_lanes` at a time — or, with agents_per_wave = -1, through the masked kernel (no refilling).  -> K, X, iters."""
+    import torch
+    from .lqr import _params
+    L.require_cuda(v)
+    n = v.shape[0]
+    L.expect("v", v, "f", n)
+    m = 2 if dim == 5 else 1
+    X = torch.empty((n, dim * dim), dtype=torch.float32, device=v.device)
+    K = torch.empty((n, m * dim), dtype=torch.float32, device=v.device)
+    iters = torch.empty((n,), dtype=torch.int32, device=v.device)
+    p = _params(dt, L_wheelbase, eps, maxiter)
+    L.check(xlib().crx_x_dare_from_v_refill_dev(n, dim, L.ptr(v), C.byref(p), L.ptr(X), L.ptr(K), L.ptr(iters),
+                                                L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_dare_from_v_refill_dev")
     return K, X, iters
 
 

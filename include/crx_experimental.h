@@ -57,6 +57,13 @@ int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream
 int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
 int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
 
+/* crx_dare_from_v_batch_dev with one agent per lane and the lane-refilling kernel forced (dare_from_v_refill_kernel: a wave owns
+ * `agents_per_wave` consecutive agents; once `hold_lanes` of its lanes hold a finished agent they hand them back in one pass and
+ * take the next agents of the range; what the product uses above 262,144 agents), or with agents_per_wave = -1 the masked kernel
+ * of rounds 2-3 (lanes idle behind their wave's slowest agent).  scripts/gpu_dare_refill_ab.py. */
+int crx_x_dare_from_v_refill_dev(int n, int dim, const float* v, const crx_lqr_params* prm, float* X, float* K,
+                                 int* iters, void* stream, int agents_per_wave, int hold_lanes);
+
 /* HBM calibration: a plain streaming kernel over `bytes` (a multiple of 16) with `workgroups` workgroups of 256 lanes, 16 bytes per
  * lane per access.  mode 0: dst = src, 1: read src only, 2: write dst only, 3: dst += 1 in place (the single-step EKF's traffic
  * shape: every line read, then written).  scripts/gpu_hbm_calib.py and bench.py (`extra.hbm_calibration`) time it next to the

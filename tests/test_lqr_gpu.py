@@ -245,6 +245,48 @@ def test_dare_from_v_every_kernel_variant(crx, oracle_mod, n):
             assert bit_equal(K.cpu().numpy(), Ko)
 
 
+@pytest.mark.parametrize("dim", [5, 4])
+def test_dare_lane_refilling_kernel(crx, oracle_mod, dim):
+    """dare_from_v_refill_kernel (one agent per lane; a lane whose agent is done takes the next agent of its wave's range — what the
+    product uses above 262,144 agents): forced on small batches with odd range lengths and hand-back thresholds, ragged sizes, every
+    kind of cap — the oracle's bits and iteration counts on every agent."""
+    from cpprobotics_amd.experimental import dlqr_from_v_refill
+    for n, chunk, hold, maxiter, eps in ((5000, 64, 1, 150, 0.01), (5001, 100, 7, 150, 0.01), (20000, 777, 16, 150, 0.01), (3000, 4096, 64, 150, 0.01),
+                                         (4000, 128, 16, 7, 0.01), (4000, 320, 3, 1, 0.01), (4000, 320, 16, 2, 0.01), (4000, 256, 16, 150, 1e9),
+                                         (63, 64, 16, 150, 0.01), (1, 64, 1, 150, 0.01)):
+        v = lqr_speeds(n, seed=n + chunk)
+        v[0] = 0.0
+        A, B, Q, R = oracle_mod.lqr_build(v, dim)
+        Xo, Ko, ito = oracle_mod.dare(A, B, Q, R, eps=eps, maxiter=maxiter)
+        K, X, it = dlqr_from_v_refill(_t(v), dim, chunk, hold, eps=eps, maxiter=maxiter)
+        assert np.array_equal(it.cpu().numpy(), ito), (n, chunk, hold, maxiter)
+        assert bit_equal(X.cpu().numpy(), Xo) and bit_equal(K.cpu().numpy(), Ko), (n, chunk, hold, maxiter)
+
+
+def test_dare_throughput_regime_entry_points(crx, oracle_mod):
+    """Above 262,144 agents both entry points — crx_dare_from_v_batch and the solve_DARE(A, B, Q, R) signature on matrices that carry
+    the pattern, with other agents interleaved — run the lane-refilling kernel: equal to the masked kernel (rounds 2-3) on every agent,
+    and to the oracle on a sample."""
+    import torch
+    from cpprobotics_amd.experimental import dlqr_from_v_refill
+    n = 300007
+    v = lqr_speeds(n, seed=12)
+    for dim in (5, 4):
+        K, X, it = crx.dlqr_from_v(_t(v), dim=dim)
+        Km, Xm, itm = dlqr_from_v_refill(_t(v), dim, -1)
+        assert torch.equal(it, itm) and torch.equal(X.view(torch.int32), Xm.view(torch.int32)) and torch.equal(K.view(torch.int32), Km.view(torch.int32))
+        idx = np.r_[0:3000, n - 3000:n]
+        A, B, Q, R = oracle_mod.lqr_build(v[idx], dim)
+        Xo, Ko, ito = oracle_mod.dare(A, B, Q, R)
+        assert np.array_equal(it.cpu().numpy()[idx], ito) and bit_equal(X.cpu().numpy()[idx], Xo) and bit_equal(K.cpu().numpy()[idx], Ko)
+        # the dense signature: every 7th agent's matrices spoilt (a -0.0f where the pattern has +0.0f): those go to the dense kernel
+        A, B, Q, R = oracle_mod.lqr_build(v, dim)
+        A[::7, 1] = -0.0
+        X2, it2 = crx.solve_DARE(_t(A), _t(B), _t(Q), _t(R))
+        assert torch.equal(it2, it) and torch.equal(X2, X)          # (-0.0 where the reference multiplies by it changes no value)
+        del A, B, Q, R
+
+
 def test_dare_edge_cases(crx, oracle_mod):
     import torch
     v = np.array([1.0, 2.0], dtype=np.float32)

@@ -1908,7 +1908,11 @@ int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long lon
 // (read and write of the same lines: the single-step EKF's traffic shape).  16 bytes per lane per access, grid-stride.
 namespace crx {
 __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v4f* __restrict__ dst, const v4f* __restrict__ src) {
-  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  // mode + 8: workgroup b works where workgroup (b % 8) * (gridDim / 8) + b / 8 would — consecutive workgroups go to the eight XCDs
+  // in turn, so this hands every XCD one contiguous eighth of the buffer instead of every eighth 4-KiB piece
+  unsigned b = blockIdx.x;
+  if (mode >= 8) { mode -= 8; b = (b & 7u) * (gridDim.x >> 3) + (b >> 3); }
+  const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)b * 256 + threadIdx.x;
   if (mode == 0) {
     for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
   } else if (mode == 1) {
@@ -1924,8 +1928,9 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
 }  // namespace crx
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream) {
   CRX_TRACE();
-  if (mode < 0 || mode > 3 || !dst || ((mode == 0 || mode == 1) && !src) || bytes % 16 || workgroups < 1)
-    return fail(CRX_ERR_INVALID, "hbm_stream: bad arguments (bytes a multiple of 16)");
+  if (mode < 0 || (mode & 7) > 3 || mode > 11 || !dst || (((mode & 7) == 0 || (mode & 7) == 1) && !src) || bytes % 16 || workgroups < 1 ||
+      (mode >= 8 && workgroups % 8))
+    return fail(CRX_ERR_INVALID, "hbm_stream: bad arguments (bytes a multiple of 16; mode + 8 needs a multiple of 8 workgroups)");
   if (int rc = check_device()) return rc;
   const size_t n16 = bytes / 16;
   auto* d = (crx::v4f*)dst; auto* sp = (const crx::v4f*)src;

@@ -37,6 +37,23 @@ namespace crx {
 // native 4-wide vector type (the nontemporal builtins do not take HIP's float4 wrapper); v2f: ekf_math.h
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// XCD-aware workgroup order.  The hardware hands consecutive workgroups of a launch to the eight XCDs in turn (workgroup b runs on
+// XCD b % 8), so with the identity mapping every XCD streams every eighth 512-byte .. 4-KiB piece of each row of the time-major
+// arrays.  Long-lived streaming writers do measurably better when every XCD owns ONE contiguous eighth of the row (plain streaming
+// kernel, write only, 2,048 persistent workgroups: 4.3 -> 5.9 TB/s; profiles/r04/hbm_xcd_order.jsonl): workgroup b therefore
+// works on block  start(b % 8) + b / 8,  start(k) = k * (nb / 8) + min(k, nb % 8)  — a permutation of [0, nb) for any nb.
+#ifndef CRX_XCD_ORDER
+#define CRX_XCD_ORDER 1
+#endif
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
+#if CRX_XCD_ORDER
+  const unsigned k = b & 7u, q = nb >> 3, r = nb & 7u;
+  return k * q + (k < r ? k : r) + (b >> 3);
+#else
+  return b;
+#endif
+}
+
 __device__ __forceinline__ void load_state(EkfState& s, const float* __restrict__ x,
                                            const float* __restrict__ P, size_t a) {
   const float4 xv = reinterpret_cast<const float4*>(x)[a];
@@ -78,7 +95,7 @@ __global__ void __launch_bounds__(CRX_EKF_STEP_BLOCK)
 ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float* __restrict__ z,
                 const float* __restrict__ u, EkfConsts k) {
   __shared__ v4f s_pt[(CRX_EKF_STEP_BLOCK / 64) * 64 * 5];
-  const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t a = (size_t)xcd_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const unsigned lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   const size_t wave0 = a - lane;                       // first vehicle of this wave
   const bool full_wave = wave0 + 64 <= (size_t)n;
@@ -166,7 +183,7 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
                const float* __restrict__ z, const float* __restrict__ u,
                float* __restrict__ x_hist, float* __restrict__ P_hist, EkfConsts k) {
   __shared__ v4f s_pt[(PHIST && BUF && CRX_EKF_PHIST_LDS) ? CRX_EKF_RUN_BLOCK * 5 : 1];   // P_hist transpose staging (one wave)
-  const size_t blk = (size_t)blockIdx.x * CRX_EKF_RUN_BLOCK;
+  const size_t blk = (size_t)xcd_block(blockIdx.x, gridDim.x) * CRX_EKF_RUN_BLOCK;
   const unsigned lane = threadIdx.x;
   const size_t a = blk + lane;
   if (a >= (size_t)n) return;

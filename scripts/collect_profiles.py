@@ -70,7 +70,7 @@ first_json_line("bench_forcedist.json", "bench_forcedist_1rank.json")
 first_json_line("bench_oversub2.json", "bench_oversubscribed_2ranks_dry_run.json")
 copy("swarm_1gpu.json", "swarm_shard_1gpu.json")
 for f in ("side_bench.jsonl", "dare_lanes_ab.jsonl", "mpc_lanes_ab.jsonl", "loop_lanes_ab.jsonl", "mpc_loop_err.jsonl", "tests.log", "smoke.log", "host.txt",
-          "fuzz_bitexact.txt"):
+          "fuzz_bitexact.txt", "dare_dense_lanes_ab.jsonl", "dare_refill_ab.jsonl", "hbm_calibration.jsonl"):
     copy(f)
 stats("prof_stats", "ekf_kernel_stats.csv", ["ekf_run_kernel", "ekf_simulate_inputs"])
 stats("side_stats", "side_kernel_stats.csv", SIDE)

@@ -7,7 +7,8 @@
 #     bench      python bench.py                       -> bench.json
 #     forcedist  bench.py --force-dist (N > 1 code path, one rank)
 #     oversub    bench.py --gpus 2 --oversubscribe (self-launched ranks sharing the GPU: dry run of the N > 1 launch path)
-#     ab         the lanes-per-agent A/B scripts (DARE, MPC, closed loop) and the MPC closed-loop drift
+#     ab         the lanes-per-agent A/B scripts (DARE structured / dense, MPC, closed loop), the MPC closed-loop drift, the lane-refilling
+#                Riccati kernel against the masked one, the HBM calibration
 #     side       scripts/side_bench.py (DARE, MPC, tracking, PF, DWA, Frenet)
 #     swarm      scripts/swarm_bench.py, one GPU's shard of BASELINE configs[4]
 #     fuzz       scripts/gpu_fuzz_bitexact.py (SEED0=first seed, default 300; SEEDS=how many, default 20)
@@ -36,7 +37,10 @@ for s in $STEPS; do
     ab) timeout 200 python scripts/gpu_dare_lanes_ab.py > $OUT/dare_lanes_ab.jsonl 2> $OUT/dare_ab.err; cut -c1-200 $OUT/dare_lanes_ab.jsonl
         timeout 300 python scripts/gpu_mpc_lanes_ab.py > $OUT/mpc_lanes_ab.jsonl 2> $OUT/mpc_ab.err; cut -c1-200 $OUT/mpc_lanes_ab.jsonl
         timeout 300 python scripts/gpu_loop_lanes_ab.py 2> $OUT/loop_ab.err | grep -v amdgpu > $OUT/loop_lanes_ab.jsonl; cut -c1-250 $OUT/loop_lanes_ab.jsonl
-        timeout 200 python scripts/gpu_mpc_loop_err.py > $OUT/mpc_loop_err.jsonl 2>&1; cat $OUT/mpc_loop_err.jsonl ;;
+        timeout 200 python scripts/gpu_mpc_loop_err.py > $OUT/mpc_loop_err.jsonl 2>&1; cat $OUT/mpc_loop_err.jsonl
+        timeout 300 python scripts/gpu_dare_dense_ab.py > $OUT/dare_dense_lanes_ab.jsonl 2> $OUT/dare_dense_ab.err; cut -c1-200 $OUT/dare_dense_lanes_ab.jsonl
+        timeout 600 python scripts/gpu_dare_refill_ab.py > $OUT/dare_refill_ab.jsonl 2> $OUT/dare_refill_ab.err; cut -c1-200 $OUT/dare_refill_ab.jsonl
+        timeout 300 python scripts/gpu_hbm_calib.py > $OUT/hbm_calibration.jsonl 2> $OUT/hbm_calib.err; tail -4 $OUT/hbm_calibration.jsonl | cut -c1-200 ;;
     side) timeout 900 python scripts/side_bench.py > $OUT/side_bench.jsonl 2> $OUT/side_bench.err; cut -c1-300 $OUT/side_bench.jsonl ;;
     swarm) timeout 300 python scripts/swarm_bench.py --agents 131072 > $OUT/swarm_1gpu.json 2> $OUT/swarm.err; cut -c1-600 $OUT/swarm_1gpu.json; tail -2 $OUT/swarm.err ;;
     fuzz) timeout 1500 python scripts/gpu_fuzz_bitexact.py ${SEED0:-300} ${SEEDS:-20} > $OUT/fuzz_bitexact.txt 2>&1; tail -12 $OUT/fuzz_bitexact.txt ;;

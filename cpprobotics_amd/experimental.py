@@ -97,9 +97,10 @@ def dlqr_from_v_refill(v, dim=5, agents_per_wave=512, hold_lanes=16, dt=0.1, L_w
     n = v.shape[0]
     L.expect("v", v, "f", n)
     m = 2 if dim == 5 else 1
-    X = torch.empty((n, dim * dim), dtype=torch.float32, device=v.device)
-    K = torch.empty((n, m * dim), dtype=torch.float32, device=v.device)
-    iters = torch.empty((n,), dtype=torch.int32, device=v.device)
+    # poisoned outputs: an agent the kernel's range bookkeeping skipped would show (this entry point exists for tests and A/B scripts)
+    X = torch.full((n, dim * dim), float("nan"), dtype=torch.float32, device=v.device)
+    K = torch.full((n, m * dim), float("nan"), dtype=torch.float32, device=v.device)
+    iters = torch.full((n,), -1, dtype=torch.int32, device=v.device)
     p = _params(dt, L_wheelbase, eps, maxiter)
     L.check(xlib().crx_x_dare_from_v_refill_dev(n, dim, L.ptr(v), C.byref(p), L.ptr(X), L.ptr(K), L.ptr(iters),
                                                 L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_dare_from_v_refill_dev")

@@ -33,10 +33,10 @@ for dim in (5, 4):
         v = torch.from_numpy(lqr_speeds(n, 3)).cuda()
         Km, Xm, itm = dlqr_from_v_refill(v, dim, -1)
         row = {"dim": dim, "agents": n, "mean_iters": float(itm.float().mean()), "mean_of_wave_max": float(itm.view(-1, 64).max(dim=1).values.float().mean()),
-               "ms_masked": timeit(lambda: dlqr_from_v_refill(v, dim, -1))}
+               "ms_masked": timeit(lambda: dlqr_from_v_refill(v, dim, -1, poison=False))}
         ok = True
         for chunk, hold in ((256, 16), (512, 1), (512, 4), (512, 8), (512, 16), (512, 32), (1024, 8), (1024, 16), (1024, 32), (2048, 16)):
-            row[f"ms_refill_{chunk}_{hold}"] = timeit(lambda: dlqr_from_v_refill(v, dim, chunk, hold))
+            row[f"ms_refill_{chunk}_{hold}"] = timeit(lambda: dlqr_from_v_refill(v, dim, chunk, hold, poison=False))
             K, X, it = dlqr_from_v_refill(v, dim, chunk, hold)
             ok = ok and torch.equal(X.view(torch.int32), Xm.view(torch.int32)) and torch.equal(K.view(torch.int32), Km.view(torch.int32)) and torch.equal(it, itm)
         best = min((row[k], k) for k in row if k.startswith("ms_refill_"))

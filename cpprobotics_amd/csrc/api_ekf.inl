@@ -1,0 +1,416 @@
+// api_ekf.inl — part of the single translation unit crx_api.hip (#included there, in this order: api_internal, api_core, api_ekf,
+// api_lqr, api_mpc, api_track, api_planners, api_frenet, api_probes); the EKF entry points (src/extended_kalman_filter.cpp): small functions, single step, fused run, input simulation, and the
+// host-pointer pipeline.
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// EKF
+// ---------------------------------------------------------------------------------------------
+int crx_motion_model_batch_dev(int n, const float* x, const float* u, float* x_out,
+                               const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::motion_model_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, x, u, x_out, prm ? prm->dt : 0.1);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_jacobF_batch_dev(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm,
+                         void* stream) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::jacobF_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     n, x, u, jF, prm ? prm->dt : 0.1);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_observation_model_batch_dev(int n, const float* x, float* z_out, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::observation_model_kernel, dim3(blocks_for(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, n, x, z_out);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_jacobH(float* jH_out) {
+  if (!jH_out) return fail(CRX_ERR_INVALID, "jacobH: NULL output");
+  // column-major 2x4: [[1,0,0,0],[0,1,0,0]]  — a constant; no arithmetic involved
+  const float h[8] = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+  std::memcpy(jH_out, h, sizeof(h));
+  return CRX_OK;
+}
+
+int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const float* u, const float* Q,
+                           const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || !Q || !R || (n && (!x || !P || !z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_step: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  const dim3 grid(blocks_for(n, CRX_EKF_STEP_BLOCK)), block(CRX_EKF_STEP_BLOCK);
+#ifdef CRX_EKF_STEP_NT_FORCE     // A/B builds only (scripts/experiments/gpu_ekf_step_ab.sh)
+  hipLaunchKernelGGL(crx::ekf_step_kernel<(CRX_EKF_STEP_NT_FORCE != 0)>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+#else
+  if (n >= crx::kEkfStepNtMinN) hipLaunchKernelGGL(crx::ekf_step_kernel<true>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+  else hipLaunchKernelGGL(crx::ekf_step_kernel<false>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+#endif
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, const float* u,
+                          float* x_hist, float* P_hist, const float* Q, const float* R,
+                          const crx_ekf_params* prm, void* stream, bool force_addr64) {
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  const dim3 grid(blocks_for(n, CRX_EKF_RUN_BLOCK)), block(CRX_EKF_RUN_BLOCK);
+  hipStream_t s = (hipStream_t)stream;
+#ifndef CRX_EKF_PREFETCH
+#define CRX_EKF_PREFETCH 4
+#endif
+  constexpr int D = CRX_EKF_PREFETCH;
+#ifndef CRX_EKF_BUFFER_ADDRESSING
+#define CRX_EKF_BUFFER_ADDRESSING 1
+#endif
+  // 32-bit buffer offsets (ekf_kernels.hip.h) up to kEkfBufMaxN vehicles, the 64-bit-address kernels above (tests force the
+  // latter on small inputs through crx_x_ekf_run_addr64_dev)
+  const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !force_addr64;
+#define CRX_LAUNCH_RUN(XH, PH)                                                                          \
+  do {                                                                                                  \
+    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
+    else hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
+  } while (0)
+  if (x_hist && P_hist) CRX_LAUNCH_RUN(true, true);
+  else if (x_hist) CRX_LAUNCH_RUN(true, false);
+  else if (P_hist) CRX_LAUNCH_RUN(false, true);
+  else CRX_LAUNCH_RUN(false, false);
+#undef CRX_LAUNCH_RUN
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+int crx_ekf_run_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                          const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
+  return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, false);
+}
+int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,
+                             const float* Q, const float* R, const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
+  return ekf_run_launch(n, T, x, P, z, u, x_hist, P_hist, Q, R, prm, stream, true);
+}
+
+#ifdef CRX_EKF_TIMING
+// debug builds only: copies out the per-workgroup {shader-clock ticks, 100 MHz real-time ticks} of the last fused launch
+int crx_debug_ekf_timing(long long* out, int nblocks) {
+  CRX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(crx::g_ekf_timing), sizeof(long long) * 2 * (size_t)nblocks));
+  return CRX_OK;
+}
+#endif
+
+int crx_ekf_simulate_inputs_dev(int n, int T, const float* u_true, float* xTrue, float* xDR,
+                                const float* w, float* z, float* ud, float* xTrue_hist,
+                                float* xDR_hist, const float qsim[2], const float rsim[2],
+                                const crx_ekf_params* prm, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || T < 0 || !qsim || !rsim || (n && (!u_true || !xTrue || !xDR)) || (n && T && (!w || !z || !ud)))
+    return fail(CRX_ERR_INVALID, "ekf_simulate_inputs: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const dim3 grid(blocks_for(n, 64)), block(64);
+  const double dt = prm ? prm->dt : 0.1;
+  if (xTrue_hist || xDR_hist)
+    hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<true>), grid, block, 0, (hipStream_t)stream, n, T,
+                       u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  else
+    hipLaunchKernelGGL((crx::ekf_simulate_inputs_kernel<false>), grid, block, 0, (hipStream_t)stream, n, T,
+                       u_true, xTrue, xDR, w, z, ud, xTrue_hist, xDR_hist, qsim[0], qsim[1], rsim[0], rsim[1], dt);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// The two-lanes-per-vehicle A/B variant of the fused launch (ekf_wave2_kernels.hip.h): measured 0.61-0.73x of the production
+// kernel (profiles/r02/ekf_wave_ab.txt).  Measurement only (include/crx_experimental.h); it has no general-step fallback: when
+// *left_domain comes back non-zero, xEst / PEst / x_hist of this call are not valid.
+int crx_x_ekf_run_pair_batch_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, const float Q[16],
+                               const float R[4], const crx_ekf_params* prm, int* left_domain, void* stream) {
+  CRX_TRACE();
+#if !CRX_EXPERIMENTAL_KERNELS
+  (void)x_hist; (void)prm; (void)left_domain; (void)stream;
+  return fail(CRX_ERR_INVALID, "ekf_run_pair: this libcrx.so was built without the experimental kernels (CRX_EXPERIMENTAL_KERNELS=0)");
+#else
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run_pair: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  const crx::EkfConsts k = make_consts(Q, R, prm);
+  hipLaunchKernelGGL((crx::ekf_run_pair_kernel<4>), dim3(blocks_for(2 * (size_t)n, 64)), dim3(64), 0, (hipStream_t)stream, n, T, x, P, z, u,
+                     x_hist, k, left_domain);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+#endif
+}
+
+// w[t][a][0..3] = the four N(0,1) draws of (seed, stream, global agent id agent0 + a, step t): see crx_philox.h
+namespace crx {
+__global__ void __launch_bounds__(256) normal_draws_kernel(int n, int T, unsigned long long agent0, unsigned long long seed,
+                                                           unsigned stream_id, float4* __restrict__ w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one (step, agent) pair per lane, agent fastest
+  if (i >= (size_t)n * T) return;
+  const unsigned step = (unsigned)(i / n);
+  const unsigned long long a = agent0 + (i % n);
+  float o[4];
+  philox_normal4(seed, stream_id, a, step, o);
+  w[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace crx
+
+int crx_normal_draws_dev(int n, int T, long long agent0, unsigned long long seed, unsigned stream_id, float* w, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || T < 0 || agent0 < 0 || ((size_t)n * T && !w)) return fail(CRX_ERR_INVALID, "normal_draws: bad argument");
+  if (int rc = check_device()) return rc;
+  if ((size_t)n * T == 0) return CRX_OK;
+  hipLaunchKernelGGL(crx::normal_draws_kernel, dim3(blocks_for((size_t)n * T, 256)), dim3(256), 0, (hipStream_t)stream, n, T,
+                     (unsigned long long)agent0, seed, stream_id, reinterpret_cast<float4*>(w));
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
+// ---- host-pointer variants --------------------------------------------------------------------------
+// Arguments are marshalled by HostCall (zero-copy for small calls, workspace + staged DMA otherwise) and the agents are split
+// over the device set (crx_set_devices) — every array here is per agent, so a shard is a pointer offset.
+int crx_motion_model_batch(int n, const float* x, const float* u, float* x_out, const crx_ekf_params* prm) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !u || !x_out))) return fail(CRX_ERR_INVALID, "motion_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, x_out + 4 * a0, 16 * nl), iu = hc.add(u + 2 * a0, nullptr, 8 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_motion_model_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iu), hc.p<float>(ix), prm, hc.stream()));
+    return hc.finish();
+  });
+}
+
+int crx_jacobF_batch(int n, const float* x, const float* u, float* jF, const crx_ekf_params* prm) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !u || !jF))) return fail(CRX_ERR_INVALID, "jacobF: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, nullptr, 16 * nl), iu = hc.add(u + 2 * a0, nullptr, 8 * nl), ij = hc.add(nullptr, jF + 16 * a0, 64 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_jacobF_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iu), hc.p<float>(ij), prm, hc.stream()));
+    return hc.finish();
+  });
+}
+
+int crx_observation_model_batch(int n, const float* x, float* z_out) {
+  CRX_TRACE();
+  if (n < 0 || (n && (!x || !z_out))) return fail(CRX_ERR_INVALID, "observation_model: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0;
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, nullptr, 16 * nl), iz = hc.add(nullptr, z_out + 2 * a0, 8 * nl);
+    CRX_TRY(hc.commit());
+    CRX_TRY(crx_observation_model_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iz), hc.stream()));
+    return hc.finish();
+  });
+}
+
+int crx_ekf_step_batch(int n, float* x, float* P, const float* z, const float* u, const float* Q,
+                       const float* R, const crx_ekf_params* prm) {
+  return crx_ekf_run_batch(n, 1, x, P, z, u, nullptr, nullptr, Q, R, prm);
+}
+
+}  // extern "C"
+
+namespace {
+
+// The fused EKF run for the agents [a0, a1) of an n-agent batch, host pointers, on the current device: a three-stream pipeline
+// over time chunks.  z, u are [T][n][2], x_hist [T][n][4], P_hist [T][n][16] (time-major: a shard's columns of a chunk are
+// `rows` of nl agents, n agents apart).  Chunk k: its z,u rows are gathered into a pinned slot by the copy threads (or DMA'd
+// straight from the caller's memory when that is pinned), go to the device on s_in, the kernel runs its steps on s_cmp — the
+// filter state x, P staying in the workspace from chunk to chunk, so the results are those of ONE T-step launch bit for bit —
+// and the chunk's history rows return on s_out, scattered into the caller's arrays by the copy threads.  While the device works
+// on chunk k the host fills chunk k+1 and drains chunk k-1.  Rings of kRing slots; reuse is fenced by events.
+int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
+                       float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
+  using crxh::kRing;
+  crxh::DeviceCtx* c = nullptr;
+  std::unique_lock<std::mutex> lock;
+  CRX_TRY(ctx_open(&c, lock));
+  const size_t nl = (size_t)(a1 - a0), nn = (size_t)n;
+  const size_t per_step_in = 16 * nl, per_step_out = (x_hist ? 16 * nl : 0) + (P_hist ? 64 * nl : 0);
+  const bool direct_in = crxh::is_pinned(z) && crxh::is_pinned(u);
+  const bool direct_out = (!x_hist || crxh::is_pinned(x_hist)) && (!P_hist || crxh::is_pinned(P_hist));
+  // steps per chunk: ~16 MB of the larger direction when the chunk is staged by the copy threads (short enough to overlap, long
+  // enough to amortise the trip), ~64 MB when both directions are DMA'd in place; at least 1, at most T
+  const size_t per_step = std::max(per_step_in, per_step_out);
+  size_t Tc = std::max<size_t>(1, ((direct_in && direct_out) ? (64u << 20) : (16u << 20)) / per_step);
+  Tc = std::min<size_t>(Tc, (size_t)T);
+  const int C = (int)(((size_t)T + Tc - 1) / Tc);
+  // a slot of the input ring is [z rows | u rows], of the output ring [x_hist rows | P_hist rows]; every part 256-byte aligned
+  const size_t zb = crxh::align_up(8 * nl * Tc), inb = 2 * zb, hx = crxh::align_up(16 * nl * Tc);
+  const size_t outb = (x_hist ? hx : 0) + (P_hist ? crxh::align_up(64 * nl * Tc) : 0);
+  const size_t xb = crxh::align_up(16 * nl), Pb = crxh::align_up(64 * nl);
+  const bool whole = nl == nn;                       // the shard is the whole batch: a chunk's rows are one contiguous block
+  hipError_t e = c->dws.reserve(xb + Pb + kRing * (inb + outb));
+  if (e == hipSuccess) e = c->pws.reserve(xb + Pb + (direct_in ? 0 : kRing * inb) + (direct_out ? 0 : kRing * outb));
+  if (e != hipSuccess) { hip_fail(e, "workspace (ekf_run)"); return CRX_ERR_ALLOC; }
+  char* dbase = static_cast<char*>(c->dws.p);
+  float* dx = reinterpret_cast<float*>(dbase);
+  float* dP = reinterpret_cast<float*>(dbase + xb);
+  char* din = dbase + xb + Pb;                         // ring: [z rows | u rows] of a chunk
+  char* dout = din + kRing * inb;                      // ring: [x_hist rows | P_hist rows] of a chunk
+  char* pbase = static_cast<char*>(c->pws.p);
+  char* pxP = pbase;
+  char* pin_in = pbase + xb + Pb;
+  char* pin_out = pin_in + (direct_in ? 0 : kRing * inb);
+  crxh::CopyPool& pool = crxh::CopyPool::get();
+
+  // initial state: through the pinned block, on the compute stream
+  std::memcpy(pxP, x + 4 * (size_t)a0, 16 * nl);
+  std::memcpy(pxP + xb, P + 16 * (size_t)a0, 64 * nl);
+  CRX_HIP(hipMemcpyAsync(dx, pxP, 16 * nl, hipMemcpyHostToDevice, c->s_cmp));
+  CRX_HIP(hipMemcpyAsync(dP, pxP + xb, 64 * nl, hipMemcpyHostToDevice, c->s_cmp));
+
+  auto steps_of = [&](int k) { return std::min(Tc, (size_t)T - (size_t)k * Tc); };
+  // rows of chunk k in the caller's time-major arrays
+  auto zrow = [&](int k) { return reinterpret_cast<const char*>(z) + ((size_t)k * Tc * nn + (size_t)a0) * 8; };
+  auto urow = [&](int k) { return reinterpret_cast<const char*>(u) + ((size_t)k * Tc * nn + (size_t)a0) * 8; };
+  auto xhrow = [&](int k) { return reinterpret_cast<char*>(x_hist) + ((size_t)k * Tc * nn + (size_t)a0) * 16; };
+  auto Phrow = [&](int k) { return reinterpret_cast<char*>(P_hist) + ((size_t)k * Tc * nn + (size_t)a0) * 64; };
+
+  for (int it = 0; it <= C + 1; ++it) {
+    // (a) device work of chunk k = it - 1 (its inputs were staged during the previous trip)
+    const int k = it - 1;
+    if (k >= 0 && k < C) {
+      const int sl = k % kRing;
+      const size_t tc = steps_of(k);
+      char* dz = din + (size_t)sl * inb;
+      char* du = dz + zb;
+      if (k >= kRing) CRX_HIP(hipStreamWaitEvent(c->s_in, c->ev_cmp[sl], 0));          // the kernel of chunk k - kRing has read this slot
+      if (direct_in && whole) {
+        CRX_HIP(hipMemcpyAsync(dz, zrow(k), 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));
+        CRX_HIP(hipMemcpyAsync(du, urow(k), 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));
+      } else if (direct_in) {
+        CRX_HIP(hipMemcpy2DAsync(dz, 8 * nl, zrow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
+        CRX_HIP(hipMemcpy2DAsync(du, 8 * nl, urow(k), 8 * nn, 8 * nl, tc, hipMemcpyHostToDevice, c->s_in));
+      } else {
+        CRX_HIP(hipMemcpyAsync(dz, pin_in + (size_t)sl * inb, zb + 8 * nl * tc, hipMemcpyHostToDevice, c->s_in));   // z rows, padding, u rows
+      }
+      CRX_HIP(hipEventRecord(c->ev_in[sl], c->s_in));
+      CRX_HIP(hipStreamWaitEvent(c->s_cmp, c->ev_in[sl], 0));
+      if (k >= kRing) CRX_HIP(hipStreamWaitEvent(c->s_cmp, c->ev_out[sl], 0));         // the D2H of chunk k - kRing has left this slot
+      float* dxh = x_hist ? reinterpret_cast<float*>(dout + (size_t)sl * outb) : nullptr;
+      float* dPh = P_hist ? reinterpret_cast<float*>(dout + (size_t)sl * outb + (x_hist ? hx : 0)) : nullptr;
+      int rc;
+      if (T == 1 && !x_hist && !P_hist)
+        rc = crx_ekf_step_batch_dev((int)nl, dx, dP, reinterpret_cast<float*>(dz), reinterpret_cast<float*>(du), Q, R, prm, c->s_cmp);
+      else
+        rc = crx_ekf_run_batch_dev((int)nl, (int)tc, dx, dP, reinterpret_cast<float*>(dz), reinterpret_cast<float*>(du), dxh, dPh, Q, R, prm, c->s_cmp);
+      if (rc) return rc;
+      CRX_HIP(hipEventRecord(c->ev_cmp[sl], c->s_cmp));
+      if (per_step_out) {
+        CRX_HIP(hipStreamWaitEvent(c->s_out, c->ev_cmp[sl], 0));
+        if (direct_out && whole) {
+          if (x_hist) CRX_HIP(hipMemcpyAsync(xhrow(k), dxh, 16 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpyAsync(Phrow(k), dPh, 64 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+        } else if (direct_out) {
+          if (x_hist) CRX_HIP(hipMemcpy2DAsync(xhrow(k), 16 * nn, dxh, 16 * nl, 16 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpy2DAsync(Phrow(k), 64 * nn, dPh, 64 * nl, 64 * nl, tc, hipMemcpyDeviceToHost, c->s_out));
+        } else {
+          char* po = pin_out + (size_t)sl * outb;
+          if (x_hist) CRX_HIP(hipMemcpyAsync(po, dxh, 16 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+          if (P_hist) CRX_HIP(hipMemcpyAsync(po + (x_hist ? hx : 0), dPh, 64 * nl * tc, hipMemcpyDeviceToHost, c->s_out));
+        }
+        CRX_HIP(hipEventRecord(c->ev_out[sl], c->s_out));
+      }
+    }
+    // (b) stage the inputs of chunk `it` into its pinned slot (free once the H2D of chunk it - kRing has completed)
+    crxh::CopyPool::Joined jin, jout;             // joined at the end of the trip — and on every early return
+    crxh::CopyPool::Ticket &tin = jin.t, &tout = jout.t;
+    if (it < C && !direct_in) {
+      const int sl = it % kRing;
+      const size_t tc = steps_of(it);
+      if (it >= kRing) CRX_HIP(hipEventSynchronize(c->ev_in[sl]));
+      char* pz = pin_in + (size_t)sl * inb;
+      pool.submit(crxh::CopyPool::Job{pz, zrow(it), 8 * nl, tc, 8 * nl, 8 * nn}, &tin);
+      pool.submit(crxh::CopyPool::Job{pz + zb, urow(it), 8 * nl, tc, 8 * nl, 8 * nn}, &tin);
+    }
+    // (c) drain the history rows of chunk it - 2 into the caller's arrays
+    const int d = it - 2;
+    if (d >= 0 && d < C && per_step_out && !direct_out) {
+      const int sl = d % kRing;
+      const size_t tc = steps_of(d);
+      CRX_HIP(hipEventSynchronize(c->ev_out[sl]));
+      char* po = pin_out + (size_t)sl * outb;
+      if (x_hist) pool.submit(crxh::CopyPool::Job{xhrow(d), po, 16 * nl, tc, 16 * nn, 16 * nl}, &tout);
+      if (P_hist) pool.submit(crxh::CopyPool::Job{Phrow(d), po + (x_hist ? hx : 0), 64 * nl, tc, 64 * nn, 64 * nl}, &tout);
+    }
+  }
+  // final state (the compute stream is behind the last kernel); every history row has left the device before we return
+  CRX_HIP(hipMemcpyAsync(pxP, dx, 16 * nl, hipMemcpyDeviceToHost, c->s_cmp));
+  CRX_HIP(hipMemcpyAsync(pxP + xb, dP, 64 * nl, hipMemcpyDeviceToHost, c->s_cmp));
+  CRX_HIP(hipStreamSynchronize(c->s_cmp));
+  if (per_step_out) CRX_HIP(hipStreamSynchronize(c->s_out));
+  std::memcpy(x + 4 * (size_t)a0, pxP, 16 * nl);
+  std::memcpy(P + 16 * (size_t)a0, pxP + xb, 64 * nl);
+  return CRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
+                      float* P_hist, const float* Q, const float* R, const crx_ekf_params* prm) {
+  CRX_TRACE();
+  if (n < 0 || T < 0 || !Q || !R || (n && (!x || !P)) || (n && T && (!z || !u)))
+    return fail(CRX_ERR_INVALID, "ekf_run: bad argument");
+  if (int rc = check_device()) return rc;
+  if (n == 0 || T == 0) return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nn = (size_t)n, tt = (size_t)T;
+    if (nl * tt * (32 + (P_hist ? 64 : 0)) + 80 * nl > crxh::kZeroCopyBytes)
+      return ekf_run_host_shard(n, sh.a0, sh.a1, T, x, P, z, u, x_hist, P_hist, Q, R, prm);
+    // a small call — the literal drop-in, ekf_estimation() for one vehicle — is zero-copy: one pinned block, one launch
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x + 4 * a0, x + 4 * a0, 16 * nl), iP = hc.add(P + 16 * a0, P + 16 * a0, 64 * nl);
+    const int iz = hc.add2d(z + 2 * a0, nullptr, 8 * nl, tt, 8 * nn), iu = hc.add2d(u + 2 * a0, nullptr, 8 * nl, tt, 8 * nn);
+    const int ih = x_hist ? hc.add2d(nullptr, x_hist + 4 * a0, 16 * nl, tt, 16 * nn) : -1;
+    const int iH = P_hist ? hc.add2d(nullptr, P_hist + 16 * a0, 64 * nl, tt, 64 * nn) : -1;
+    CRX_TRY(hc.commit());
+    if (T == 1 && !x_hist && !P_hist)
+      CRX_TRY(crx_ekf_step_batch_dev((int)nl, hc.p<float>(ix), hc.p<float>(iP), hc.p<float>(iz), hc.p<float>(iu), Q, R, prm, hc.stream()));
+    else
+      CRX_TRY(crx_ekf_run_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(iP), hc.p<float>(iz), hc.p<float>(iu),
+                                    ih >= 0 ? hc.p<float>(ih) : nullptr, iH >= 0 ? hc.p<float>(iH) : nullptr, Q, R, prm, hc.stream()));
+    return hc.finish();
+  });
+}
+}  // extern "C"

@@ -1,0 +1,108 @@
+// api_mpc.inl — part of the single translation unit crx_api.hip (#included there, in this order: api_internal, api_core, api_ekf,
+// api_lqr, api_mpc, api_track, api_planners, api_frenet, api_probes); mpc_solve (src/model_predictive_control.cpp:255-346).
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// MPC
+// ---------------------------------------------------------------------------------------------
+// agents_per_wave (1..64) and waves_per_workgroup (1..4): the launch geometry; the product entry point uses full waves in
+// single-wave workgroups (every emptier or stacked geometry measured slower: profiles/r02/mpc_tail.txt).
+static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
+  if (agents_per_wave < 1 || agents_per_wave > 64 || waves_per_workgroup < 1 || waves_per_workgroup > 4)
+    return fail(CRX_ERR_INVALID, "mpc_solve: launch geometry out of range (1..64 agents per wave, 1..4 waves per workgroup)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
+}
+// lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
+// measured 0.95x at BASELINE configs[3] and less beyond, never selected), 0 = what the product entry point uses (= 1).
+static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                           double* cost, void* stream, int lanes_per_agent) {
+  if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
+    return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
+  if (lanes_per_agent == 0) lanes_per_agent = 1;     // the quad variant lost its A/B at every batch size (profiles/r03/mpc_lanes_ab.txt)
+  if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
+#if !CRX_EXPERIMENTAL_KERNELS
+  return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): this libcrx.so was built without the experimental kernels");
+#else
+  if (n < 0 || T < 2 || T > 24 || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): bad argument (2 <= T <= 24)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_quad_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
+#endif
+}
+int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                            float* sol, int* status, double* cost, void* stream) {
+  CRX_TRACE();
+  return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, 0);
+}
+// mpc_solve for n agents with the four-variant portfolio (mpc_kernels.hip.h: mpc_variant): the same NLP, every agent answered by the
+// variant of the solver that converges in the fewest sweeps.
+int crx_mpc_solve_portfolio_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
+                                      float* sol, int* status, double* cost, void* stream) {
+  CRX_TRACE();
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (portfolio): bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_portfolio_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc portfolio launch");
+}
+int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                              double* cost, void* stream, int lanes_per_agent) {
+  CRX_TRACE();
+  return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, lanes_per_agent);
+}
+int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                 double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
+  CRX_TRACE();
+  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, waves_per_workgroup);
+}
+
+static int mpc_solve_host(bool portfolio, int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                          int* status, double* cost) {
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  return run_sharded(n, [&](const crxh::Shard& sh) -> int {
+    const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+    HostCall hc;
+    CRX_TRY(hc.open());
+    const int ix = hc.add(x0 + 4 * a0, nullptr, 16 * nl), ir = hc.add(xref + 4 * (size_t)T * a0, nullptr, 16 * (size_t)T * nl);
+    const int is = hc.add(nullptr, sol + nv * a0, 4 * nv * nl);
+    const int it = hc.add(nullptr, status ? status + a0 : nullptr, 4 * nl), ic = hc.add(nullptr, cost ? cost + a0 : nullptr, 8 * nl);
+    CRX_TRY(hc.commit());
+    if (portfolio)
+      CRX_TRY(crx_mpc_solve_portfolio_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it),
+                                                hc.p<double>(ic), hc.stream()));
+    else
+      CRX_TRY(crx_mpc_solve_batch_dev((int)nl, T, hc.p<float>(ix), hc.p<float>(ir), prm, hc.p<float>(is), hc.p<int>(it), hc.p<double>(ic),
+                                      hc.stream()));
+    return hc.finish();
+  });
+}
+int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                        int* status, double* cost) {
+  CRX_TRACE();
+  return mpc_solve_host(false, n, T, x0, xref, prm, sol, status, cost);
+}
+int crx_mpc_solve_portfolio_batch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol,
+                                  int* status, double* cost) {
+  CRX_TRACE();
+  return mpc_solve_host(true, n, T, x0, xref, prm, sol, status, cost);
+}
+
+}  // extern "C"

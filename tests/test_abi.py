@@ -36,8 +36,12 @@ def test_experimental_entry_points_are_separate(crx):
     assert xs and all(n.startswith("crx_x_") for n in xs) and sorted(X.EXPERIMENTAL_SYMBOLS) == xs
     assert not [n for n in _declared_functions() if n.startswith("crx_x_")]
     X.xlib()
-    api = open(os.path.join(ROOT, "cpprobotics_amd", "csrc", "crx_api.hip")).read()
-    assert "getenv" not in api
+    import glob
+    csrc = os.path.join(ROOT, "cpprobotics_amd", "csrc")
+    parts = [os.path.join(csrc, "crx_api.hip"), os.path.join(csrc, "crx_host.h")] + sorted(glob.glob(os.path.join(csrc, "api_*.inl")))
+    assert len(parts) >= 10
+    for f in parts:
+        assert "getenv" not in open(f).read(), f
 
 
 def test_product_library_does_not_carry_the_rejected_variants(crx):

@@ -84,6 +84,8 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
   // mode + 8: workgroup b works where workgroup (b % 8) * (gridDim / 8) + b / 8 would — consecutive workgroups go to the eight XCDs
   // in turn, so this hands every XCD one contiguous eighth of the buffer instead of every eighth 4-KiB piece
   unsigned b = blockIdx.x;
+  const bool plain = mode >= 16;                       // mode + 16: plain (cached) stores / loads instead of nontemporal ones
+  if (plain) mode -= 16;
   if (mode >= 8) { mode -= 8; b = (b & 7u) * (gridDim.x >> 3) + (b >> 3); }
   const size_t stride = (size_t)gridDim.x * 256, i0 = (size_t)b * 256 + threadIdx.x;
   if (mode == 0) {
@@ -93,7 +95,8 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
     for (size_t i = i0; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[blockIdx.x] = acc;     // keeps the loads alive; practically never true
   } else if (mode == 2) {
-    for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(v4f{1.f, 2.f, 3.f, 4.f}, dst + i);
+    if (plain) { for (size_t i = i0; i < n16; i += stride) dst[i] = v4f{1.f, 2.f, 3.f, 4.f}; }
+    else for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(v4f{1.f, 2.f, 3.f, 4.f}, dst + i);
   } else {
     for (size_t i = i0; i < n16; i += stride) dst[i] = dst[i] + v4f{1.f, 1.f, 1.f, 1.f};
   }
@@ -101,8 +104,8 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
 }  // namespace crx
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream) {
   CRX_TRACE();
-  if (mode < 0 || (mode & 7) > 3 || mode > 11 || !dst || (((mode & 7) == 0 || (mode & 7) == 1) && !src) || bytes % 16 || workgroups < 1 ||
-      (mode >= 8 && workgroups % 8))
+  if (mode < 0 || (mode & 7) > 3 || mode > 27 || (mode >= 16 && (mode & 7) != 2) || !dst || (((mode & 7) == 0 || (mode & 7) == 1) && !src) || bytes % 16 || workgroups < 1 ||
+      ((mode & 8) && workgroups % 8))
     return fail(CRX_ERR_INVALID, "hbm_stream: bad arguments (bytes a multiple of 16; mode + 8 needs a multiple of 8 workgroups)");
   if (int rc = check_device()) return rc;
   const size_t n16 = bytes / 16;

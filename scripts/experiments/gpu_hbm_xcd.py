@@ -35,3 +35,9 @@ for mode, name, moved in ((0, "copy", 2), (1, "read", 1), (2, "write", 1), (3, "
         a = timeit(lambda: hbm_stream(mode, dst, src, workgroups=wgs))
         b = timeit(lambda: hbm_stream(mode + 8, dst, src, workgroups=wgs))
         print(json.dumps({"mode": name, "workgroups": wgs, "TB_per_s_default_order": moved * nbytes / a / 1e9, "TB_per_s_xcd_contiguous": moved * nbytes / b / 1e9}), flush=True)
+# write-only once more: nontemporal against plain stores, both orders
+for wgs in (1024, 2048, 8192, nbytes // 4096):
+    row = {"mode": "write", "workgroups": wgs}
+    for label, m in (("nt_default", 2), ("nt_xcd", 10), ("plain_default", 18), ("plain_xcd", 26)):
+        row["TB_per_s_" + label] = nbytes / timeit(lambda: hbm_stream(m, dst, src, workgroups=wgs)) / 1e9
+    print(json.dumps(row), flush=True)

@@ -65,6 +65,25 @@ int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, 
   CRX_TRACE();
   return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, lanes_per_agent);
 }
+int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                               double* cost, void* stream, int agents_per_wave, int hold_lanes) {
+  CRX_TRACE();
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (refill): bad argument (2 <= T <= 64)");
+  if (agents_per_wave < 64 || agents_per_wave > (1 << 20) || hold_lanes < 1 || hold_lanes > 64)
+    return fail(CRX_ERR_INVALID, "mpc_solve (refill): agents_per_wave 64 .. 2^20, hold_lanes 1 .. 64");
+#if !CRX_EXPERIMENTAL_KERNELS
+  return fail(CRX_ERR_INVALID, "mpc_solve (refill): this libcrx.so was built without the experimental kernels (CRX_EXPERIMENTAL_KERNELS=0)");
+#else
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  if (p.max_iter < 1) return fail(CRX_ERR_INVALID, "mpc_solve (refill): max_iter must be at least 1");
+  const hipError_t e = crx::mpc_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc refill launch");
+#endif
+}
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
   CRX_TRACE();

@@ -40,6 +40,10 @@
 // mul/add per stage, which fma contraction cuts by a third.  Restored to `off` at the end of the file.
 #pragma clang fp contract(fast)
 
+#ifndef CRX_EXPERIMENTAL_KERNELS
+#define CRX_EXPERIMENTAL_KERNELS 0
+#endif
+
 namespace crx {
 
 // Selects.  The compiler's idiom for `c ? a : b` on doubles is v_cmp -> VCC and two VOP2 v_cndmask_b32_e32 reading VCC
@@ -232,9 +236,24 @@ __device__ __forceinline__ MpcVariant mpc_variant(int r) {
 // Wave-synchronous: every lane of the wave must call it (finished / padding lanes with live = false).
 // PORTFOLIO: the four lanes of a quad solve the same problem with mpc_variant(lane & 3); `so` and the outputs are valid on the
 // winning lane only (status_out < 0 on the others).
-template <int MAXT, bool PORTFOLIO = false>
-__device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, const float4 xi, const float4* __restrict__ xr4, const MpcP& p,
-                                               float* __restrict__ so, int& status_out, double& cost_out, float& a0_out, float& d0_out) {
+// REFILL (mpc_refill_kernel, the throughput regime): the wave owns the agents [feed.lo, feed.hi); a lane whose agent is done holds it
+// until feed.hold lanes of the wave hold one (or nobody is sweeping), then they write their solutions and take the next agents of the
+// range — cursor + rank among the lanes asking, as dare_from_v_refill_kernel does.  The arguments live, xi, xr4, so and the four
+// outputs are unused then: problems come from and results go to the feed's arrays.  Per agent the same sweeps in the same order.
+struct MpcFeed {
+  int lo, hi, hold;
+  const float* __restrict__ x0g; const float* __restrict__ xrefg;
+  float* __restrict__ solg; int* __restrict__ statusg; double* __restrict__ costg;
+};
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false>
+__device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
+                                               float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
+                                               const MpcFeed feed = MpcFeed{}) {
+  static_assert(!(PORTFOLIO && REFILL), "the portfolio runs in the latency regime");
+  bool live = live_in;
+  float4 xi = xi_in;
+  const float4* __restrict__ xr4 = xr4_in;
+  float* __restrict__ so = so_in;
   const int N = T - 1;
   const int quad_lane = (int)(threadIdx.x & 3);
   const MpcVariant var = PORTFOLIO ? mpc_variant(quad_lane) : MpcVariant{2, 1.0};
@@ -297,33 +316,60 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
     return q;
   };
 
-  const float4 rN = xr4[N];   // terminal reference: used by every sweep and every rollout
+  float4 rN = REFILL ? float4{0.f, 0.f, 0.f, 0.f} : xr4[N];   // terminal reference: used by every sweep and every rollout
 
   int cur = 0;
-  {
-    S[0][0][0] = S[1][0][0] = (double)xi.x;
-    S[0][0][1] = S[1][0][1] = (double)xi.y;
-    S[0][0][2] = S[1][0][2] = (double)xi.z;
-    S[0][0][3] = S[1][0][3] = (double)xi.w;
-  }
   double J = 0.0;
-  for (int i = 0; i < N; ++i) {          // zero initial guess (:266-269), rolled out; projected on the acceleration box of each
-                                         // knot (which moves it only if the start speed violates the speed bounds)
-    const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
-    const double a0 = clampd(0.0, ab.lo, ab.hi);
-    U[0][i][0] = 0.0; U[0][i][1] = a0;
-    J += ctrl(0, i);
-    if (i >= 1) J += track(S[0][i], i);
-    step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
-  }
-  J += track(S[0][N], N);
-
   double mu = 0.0;
   const double mu_min = 1e-6, mu_max = 1e10;
   const int n_gn = var.n_gn;
   int gn_left = n_gn, gn_run = n_gn;
   int status = 0, it = 0;
-  bool done = !live;
+  // the start of a solve from (xi, xr4): zero initial guess (:266-269), rolled out; projected on the acceleration box of each knot
+  // (which moves it only if the start speed violates the speed bounds)
+  auto start = [&]() {
+    cur = 0;
+    S[0][0][0] = S[1][0][0] = (double)xi.x;
+    S[0][0][1] = S[1][0][1] = (double)xi.y;
+    S[0][0][2] = S[1][0][2] = (double)xi.z;
+    S[0][0][3] = S[1][0][3] = (double)xi.w;
+    J = 0.0;
+    for (int i = 0; i < N; ++i) {
+      const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
+      const double a0 = clampd(0.0, ab.lo, ab.hi);
+      U[0][i][0] = 0.0; U[0][i][1] = a0;
+      J += ctrl(0, i);
+      if (i >= 1) J += track(S[0][i], i);
+      step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
+    }
+    J += track(S[0][N], N);
+    mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
+  };
+  if (!REFILL) start();
+  bool done = REFILL ? true : !live;
+  // REFILL bookkeeping: the lane's agent (-1: none; a done lane with an agent holds a finished solve), the trip of the loop below at
+  // which that agent started, the wave's cursor into its range, the lanes asking for an agent
+  int agent_l = -1, it_base = 0, next = feed.lo;
+  lanemask_t want = ~lanemask_t(0);
+  const size_t nv_ = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  // the agent's answer in the reference's layout (:341-345) and the speed-bound check of every knot
+  auto write_solution = [&](float* __restrict__ so_) {
+    for (int i = 0; i < T; ++i) {
+      const double v = S[cur][i][3];
+      if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
+      if (so_) {
+        so_[i] = (float)S[cur][i][0];
+        so_[T + i] = (float)S[cur][i][1];
+        so_[2 * T + i] = (float)S[cur][i][2];
+        so_[3 * T + i] = (float)v;
+      }
+    }
+    if (so_)
+      for (int i = 0; i < N; ++i) {
+        so_[4 * T + i] = (float)U[cur][i][0];
+        so_[4 * T + N + i] = (float)U[cur][i][1];
+      }
+  };
   auto quad_converged = [&]() -> unsigned {       // which lanes of this lane's quad have converged (bit r = variant r)
     const lanemask_t cm = lanes_where(live && (status & 1));
     return (unsigned)(cm >> (threadIdx.x & 60)) & 0xFu;
@@ -332,11 +378,43 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
 #ifdef CRX_MPC_TICKS
   long long tk_b = 0, tk_f = 0, tk_nb = 0, tk_nf = 0; const long long tk_0 = clock64();
 #endif
-  for (int iter = 0; iter < p.max_iter; ++iter) {
+  for (int iter = 0; REFILL || iter < p.max_iter; ++iter) {
     if (PORTFOLIO) { if (quad_converged()) done = true; }      // a sibling variant has the answer: every lane of the quad stops
-    if (__all(done)) break;
+    if constexpr (REFILL) {
+      const lanemask_t sweeping = lanes_where(!done);
+      const lanemask_t held = lanes_where(done && agent_l >= 0);
+      if (held && (!sweeping || __builtin_popcountll(held) >= feed.hold)) {        // hand the finished agents back, all at once
+        if (done && agent_l >= 0) {
+          write_solution(feed.solg ? feed.solg + (size_t)agent_l * nv_ : nullptr);
+          if (feed.statusg) feed.statusg[agent_l] = status | (it << 8);
+          if (feed.costg) feed.costg[agent_l] = J;
+          agent_l = -1;
+        }
+        want |= held;
+      }
+      if (want && next < feed.hi) {                                                 // the lanes without an agent take the next ones
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        const int mine = next + (int)rank;
+        next += __builtin_popcountll(want);
+        const bool got = ((want >> (threadIdx.x & 63)) & 1) && mine < feed.hi;
+        if (got) {
+          agent_l = mine;
+          xi = reinterpret_cast<const float4*>(feed.x0g)[mine];
+          xr4 = reinterpret_cast<const float4*>(feed.xrefg) + (size_t)mine * (size_t)T;
+          rN = xr4[N];
+          start();
+          it_base = iter;
+          done = false;
+        }
+        want &= ~lanes_where(got);
+      }
+      if (!lanes_where(!done)) break;                          // nobody sweeping: every held agent was handed back above
+    } else {
+      if (__all(done)) break;
+    }
     if (done) continue;
-    it = iter;
+    const int li = REFILL ? iter - it_base : iter;             // the sweep index of the lane's own agent
+    it = li;
     const bool exact = gn_left <= 0;
     // ------------------------------------------------------------------ backward sweep
     double lx[4], lp0, lp1;          // V_s
@@ -657,9 +735,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
       mu = (mu * 10.0 > 1e-3) ? mu * 10.0 : 1e-3;
       if (mu > mu_max) done = true;
     }
-    if (iter == p.max_iter - 1) it = p.max_iter;
+    if (li == p.max_iter - 1) { it = p.max_iter; if (REFILL) done = true; }
   }
   status_out = 0; cost_out = 0.0; a0_out = 0.0f; d0_out = 0.0f;
+  if (REFILL) return;                                        // every agent of the range has been written from inside the loop
   if (PORTFOLIO) {
     // the agent's answer: the converged variant of lowest index; if none converged within max_iter sweeps, variant 0's iterate
     const unsigned q = quad_converged();
@@ -670,21 +749,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live, const int T, con
   }
   if (!live) return;
   if (!(status & 1) && !done) it = p.max_iter;
-  for (int i = 0; i < T; ++i) {
-    const double v = S[cur][i][3];
-    if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
-    if (so) {
-      so[i] = (float)S[cur][i][0];
-      so[T + i] = (float)S[cur][i][1];
-      so[2 * T + i] = (float)S[cur][i][2];
-      so[3 * T + i] = (float)v;
-    }
-  }
-  if (so)
-    for (int i = 0; i < N; ++i) {
-      so[4 * T + i] = (float)U[cur][i][0];
-      so[4 * T + N + i] = (float)U[cur][i][1];
-    }
+  write_solution(so);
   status_out = status | (it << 8);
   cost_out = J;
 #ifdef CRX_MPC_TICKS
@@ -726,6 +791,21 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   if (costg) costg[agent] = J;
 }
 
+// The throughput-regime launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>).
+// MEASURED AND REJECTED (profiles/r04/mpc_refill_ab.jsonl: 1.14x at 65,536 agents, 1.16x at 262,144, 0.99x at 1 M against mpc_kernel,
+// bit-identical): compiled into the A/B build only (CRX_EXPERIMENTAL_KERNELS), reachable through crx_x_mpc_solve_refill_dev.
+#if CRX_EXPERIMENTAL_KERNELS
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+                  float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  const int lo = (int)blockIdx.x * chunk;
+  const MpcFeed feed{lo, (n - lo < chunk) ? n : lo + chunk, hold, x0g, xrefg, solg, statusg, costg};
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, false, true>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
+}
+#endif
+
 // The portfolio launch: agent a on lanes 4a .. 4a+3 (16 agents per wave, single-wave workgroups): 4x the waves of mpc_kernel — at the
 // BASELINE batch 512 waves on 1,024 SIMDs, still one per SIMD.
 template <int MAXT>
@@ -766,6 +846,22 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
     hipLaunchKernelGGL((mpc_portfolio_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
+
+#if CRX_EXPERIMENTAL_KERNELS
+// lanes refilled: `chunk` agents per wave, hand-back in batches of `hold` lanes (max_iter >= 1)
+inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                    int* status, double* cost, hipStream_t stream, int chunk, int hold) {
+  const MpcP p = mpc_pack(q);
+  const dim3 grid((unsigned)(((size_t)n + chunk - 1) / chunk)), block(64);
+  if (T <= 8)
+    hipLaunchKernelGGL((mpc_refill_kernel<8>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+  else if (T <= 24)
+    hipLaunchKernelGGL((mpc_refill_kernel<24>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+  else
+    hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
+}
+#endif
 
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                              int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1) {

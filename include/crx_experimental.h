@@ -57,6 +57,12 @@ int crx_x_dsincos_dev(int n, const double* x, double* s, double* c, void* stream
 int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
 int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
 
+/* crx_mpc_solve_batch_dev through the lane-refilling kernel (mpc_refill_kernel: a wave owns `agents_per_wave` consecutive agents;
+ * once `hold_lanes` of its lanes hold a finished solve they write their solutions and take the next agents of the range).  Built to
+ * MEASURE what refilling buys the MPC solve in its throughput regime; scripts/gpu_mpc_refill_ab.py. */
+int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                               double* cost, void* stream, int agents_per_wave, int hold_lanes);
+
 /* crx_dare_from_v_batch_dev with one agent per lane and the lane-refilling kernel forced (dare_from_v_refill_kernel: a wave owns
  * `agents_per_wave` consecutive agents; once `hold_lanes` of its lanes hold a finished agent they hand them back in one pass and
  * take the next agents of the range; what the product uses above 262,144 agents), or with agents_per_wave = -1 the masked kernel

@@ -49,12 +49,12 @@ def test_product_library_does_not_carry_the_rejected_variants(crx):
     libcrx_x.so only; the product libcrx.so neither contains their code objects nor runs them."""
     from cpprobotics_amd import experimental as X
     prod = open(crx.lib_path(), "rb").read()
-    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel"):
+    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel", b"mpc_refill_kernel"):
         assert k not in prod, k
     ab = X.ab_lib_path()
     assert os.path.exists(ab), "libcrx_x.so missing: make -C cpprobotics_amd/csrc all"
     abb = open(ab, "rb").read()
-    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel", b"ekf_run_kernel", b"mpc_kernel"):
+    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel", b"mpc_refill_kernel", b"ekf_run_kernel", b"mpc_kernel"):
         assert k in abb, k
     raw = C.CDLL(ab)
     for name in _declared_functions() + _declared_functions("crx_experimental.h"):

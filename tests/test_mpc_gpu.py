@@ -225,3 +225,21 @@ def test_mpc_edge_cases(crx):
         crx.mpc_solve(torch.zeros((2, 4), device="cuda"), torch.zeros((2, 4), device="cuda"), 1)   # T < 2
     with pytest.raises(crx.CrxError):
         crx.mpc_solve(torch.zeros((2, 4), device="cuda"), torch.zeros((2, 4 * 65), device="cuda"), 65)  # T > 64
+
+
+def test_mpc_lane_refilling_variant_equals_the_production_kernel(crx):
+    """mpc_refill_kernel (measured and rejected, A/B build only: a wave owns a range of agents and refills its lanes) — the same sweeps
+    per agent in the same order: solutions, status words (sweep counts included) and costs equal mpc_kernel's bit for bit, for odd
+    range lengths, hand-back thresholds, ragged sizes, both horizons and a small sweep cap."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_refill
+    from cpprobotics_amd.mpc import default_params
+    for n, T, chunk, hold, cap in ((3000, 21, 64, 1, 50), (5001, 21, 320, 16, 50), (4000, 6, 1024, 64, 50), (2000, 21, 128, 7, 3), (70, 21, 64, 16, 50)):
+        x0, xref = mpc_problem(n, T, 40 + n % 7)
+        x0, xref = _t(x0), _t(xref)
+        p = default_params(); p.max_iter = cap
+        sol0, st0, c0 = crx.mpc_solve(x0, xref, T, return_status=True, params=p)
+        sol, st, c = mpc_solve_refill(x0, xref, T, chunk, hold, params=p)
+        assert torch.equal(st, st0), (n, T, chunk, hold)
+        assert torch.equal(sol.view(torch.int32), sol0.view(torch.int32)) and torch.equal(c.view(torch.int64), c0.view(torch.int64))
+

@@ -92,7 +92,8 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
     for (size_t i = i0; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
   } else if (mode == 1) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
-    for (size_t i = i0; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
+    if (plain) { for (size_t i = i0; i < n16; i += stride) acc += src[i]; }
+    else for (size_t i = i0; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
     if (acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[blockIdx.x] = acc;     // keeps the loads alive; practically never true
   } else if (mode == 2) {
     if (plain) { for (size_t i = i0; i < n16; i += stride) dst[i] = v4f{1.f, 2.f, 3.f, 4.f}; }
@@ -104,7 +105,7 @@ __global__ void __launch_bounds__(256) hbm_stream_kernel(int mode, size_t n16, v
 }  // namespace crx
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream) {
   CRX_TRACE();
-  if (mode < 0 || (mode & 7) > 3 || mode > 27 || (mode >= 16 && (mode & 7) != 2) || !dst || (((mode & 7) == 0 || (mode & 7) == 1) && !src) || bytes % 16 || workgroups < 1 ||
+  if (mode < 0 || (mode & 7) > 3 || mode > 27 || (mode >= 16 && (mode & 7) != 2 && (mode & 7) != 1) || !dst || (((mode & 7) == 0 || (mode & 7) == 1) && !src) || bytes % 16 || workgroups < 1 ||
       ((mode & 8) && workgroups % 8))
     return fail(CRX_ERR_INVALID, "hbm_stream: bad arguments (bytes a multiple of 16; mode + 8 needs a multiple of 8 workgroups)");
   if (int rc = check_device()) return rc;

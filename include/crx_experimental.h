@@ -73,7 +73,7 @@ int crx_x_dare_from_v_refill_dev(int n, int dim, const float* v, const crx_lqr_p
 /* HBM calibration: a plain streaming kernel over `bytes` (a multiple of 16) with `workgroups` workgroups of 256 lanes, 16 bytes per
  * lane per access.  mode 0: dst = src, 1: read src only, 2: write dst only, 3: dst += 1 in place (the single-step EKF's traffic
  * shape: every line read, then written); mode + 8: the same with an XCD-contiguous workgroup order (every XCD one contiguous eighth
- * of the buffer; `workgroups` a multiple of 8); mode 2 + 16 (+ 8): the write-only kernel with plain instead of nontemporal stores.
+ * of the buffer; `workgroups` a multiple of 8); mode 1 / 2 + 16 (+ 8): the read-only / write-only kernel with plain instead of nontemporal accesses.
  * scripts/gpu_hbm_calib.py and bench.py (`extra.hbm_calibration`) time it next to the
  * HBM-bound EKF launches. */
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream);

@@ -142,3 +142,26 @@ def test_product_does_not_reference_the_oracle():
                     "oracle/eigen_order.h", "").replace("oracle/mpc_ref.cpp", "").replace("oracle/eigen_qr.h", ""), f"{f} references the oracle"
                 # comments may name those three oracle files; no line may include or import anything of the oracle
                 assert not [l for l in txt.splitlines() if ("#include" in l or l.strip().startswith(("import ", "from "))) and "oracle" in l], f
+
+
+@pytest.mark.parametrize("n", [-1, 1])
+def test_every_batch_entry_point_refuses_null_arguments(n):
+    """No GPU needed: argument validation comes before anything touches a device.  Every entry point whose first argument is the batch
+    size, product and measurement-only alike, called with that size and NULL / zero for everything else, reports an error
+    (CRX_ERR_INVALID, or CRX_ERR_NO_DEVICE on a box without a GPU) — it neither accepts the call nor dereferences a NULL."""
+    from cpprobotics_amd import _lib as L
+    from cpprobotics_amd import experimental as X
+    lib = C.CDLL(L.lib_path())
+    sigs = dict(L._SIGNATURES); sigs.update(X._X_SIGNATURES)
+    called = 0
+    for name, (res, args) in sorted(sigs.items()):
+        if not args or args[0] is not C.c_int or res is not C.c_int or name == "crx_set_device":
+            continue
+        fn = getattr(lib, name); fn.restype, fn.argtypes = res, args
+        vals = [(n if i == 0 else 0) if a is C.c_int else (0.0 if a in (C.c_float, C.c_double) else (None if a is C.c_void_p or hasattr(a, "contents") else 0))
+                for i, a in enumerate(args)]
+        rc = fn(*vals)
+        assert rc in (-1, -2), (name, rc)
+        called += 1
+    assert called >= 45
+

@@ -38,6 +38,7 @@ struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the re
   int max_iter;
 };
 
+int p_switch_at = -1, p_switch_n_gn = 2; double p_switch_trust = 1.0;   // experiment knob: oracle_mpc_late_switch
 double kTrustSteer = 0.4, kTrustAccel = 0.5;   // trust box of a Newton step, see backward() (variables only for the round-4 portfolio experiment: oracle_mpc_trust)
 constexpr int NS = 6;  // x, y, yaw, v, previous delta, previous a
 constexpr int NU = 2;  // delta, a
@@ -349,7 +350,9 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
   t_trust_scale = 1.0; t_trust_on = (p_trust_mode != 1);
   int gn_left = n_gn;   // Gauss-Newton iterations still to do before the next exact (Newton) attempt
   int gn_run = n_gn;    // ... and how many follow a failed one: doubles (up to 16) with every failure
+  const double variant_trust_in = t_variant_trust;
   for (it = 0; it < p.max_iter; ++it) {
+    if (it == p_switch_at) { gn_left = gn_run = p_switch_n_gn; t_variant_trust = p_switch_trust; }
     const bool exact = gn_left <= 0;
     double dV1, dV2, gnorm, deficit = 0.0;
     bool ok = backward(p, T, xref, w, exact, mu, w.kff.data(), w.Kfb.data(), &dV1, &dV2, &gnorm, &deficit);
@@ -404,6 +407,7 @@ int solve_one(const MpcParams& p, int T, const float* x0, const float* xref, flo
       if (mu > mu_max) break;
     }
   }
+  t_variant_trust = variant_trust_in;
   for (int i = 0; i < T; ++i) {
     const double v = w.S[NS * i + 3];
     if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
@@ -494,6 +498,9 @@ int oracle_mpc_ls_profile(int T, const float* x0, const float* xref, const doubl
   return st;
 }
 void oracle_mpc_trust_mode(int mode) { p_trust_mode = mode; }
+// experiment (scripts/experiments/mpc_twin_late_switch.py): from sweep `at` on the solve continues as variant (n_gn, trust) — what an
+// idle lane adopting a straggler's iterate would run; at < 0: off
+void oracle_mpc_late_switch(int at, int n_gn, double trust) { p_switch_at = at; p_switch_n_gn = n_gn; p_switch_trust = trust; }
 void oracle_mpc_trust(double steer, double accel) { kTrustSteer = steer; kTrustAccel = accel; }
 
 // Debug aid for the tests: per-iteration (J, max|k|, mu, accepted alpha), 4 doubles x max_iter.

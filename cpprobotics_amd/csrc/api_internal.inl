@@ -63,6 +63,14 @@ inline int dare_refill_chunk(int n) {
   const int per = ((n / 2048 + 63) / 64) * 64;
   return per < 256 ? 256 : (per > 1024 ? 1024 : per);
 }
+// MPC: mpc_refill_kernel from this batch on (agents per wave: a multiple of 64).  Measured: profiles/r04/mpc_refill_ab.jsonl,
+// profiles/r05/mpc_variants_ab.jsonl.  0 = mpc_kernel.
+constexpr int kMpcRefillMinAgents = 65536;
+constexpr int kMpcRefillHold = 16;
+inline int mpc_refill_chunk(int n) {
+  if (n < kMpcRefillMinAgents) return 0;
+  return n < 262144 ? 256 : 512;
+}
 constexpr int kDareChainMaxAgents = 98304;   // one lane per agent: the unmasked two-evaluations-per-branch loop up to here (profiles/r03/dare_lanes_ab.txt)
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower

@@ -19,18 +19,26 @@ def default_params():
     return p
 
 
-def mpc_solve(x0, xref, T, params=None, return_status=False, portfolio=False):
+def mpc_solve(x0, xref, T, params=None, return_status=False, portfolio=False, out=None):
     """mpc_solve(State, M_XREF) for n agents (device tensors).  portfolio=True: the four-variant portfolio solve
     (crx_mpc_solve_portfolio_batch_dev): same NLP, every agent answered by the solver variant that converges in the fewest sweeps;
-    status bits 2-3 then carry the winning variant."""
+    status bits 2-3 then carry the winning variant.  out = (sol, status, cost): write into the caller's tensors (a pipelined caller
+    keeps one set per launch in flight)."""
     import torch
     L.require_cuda(x0, xref)
     n = x0.shape[0]
     L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
     p = params if params is not None else default_params()
-    sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
-    status = torch.empty((n,), dtype=torch.int32, device=x0.device)
-    cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    if out is not None:
+        sol, status, cost = out
+        L.require_cuda(sol, status, cost)
+        L.expect("sol", sol, "f", n, mpc_n_vars(T)); L.expect("status", status, "i", n)
+        if tuple(cost.shape) != (n,) or cost.dtype != torch.float64 or not cost.is_contiguous():
+            raise ValueError("cost must be a contiguous float64 tensor of shape (n,)")
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
     fn = L.lib().crx_mpc_solve_portfolio_batch_dev if portfolio else L.lib().crx_mpc_solve_batch_dev
     L.check(fn(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost), L.stream_ptr()),
             "crx_mpc_solve_portfolio_batch_dev" if portfolio else "crx_mpc_solve_batch_dev")

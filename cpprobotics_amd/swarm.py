@@ -147,63 +147,91 @@ class ChunkedTrajectoryGather:
 
 
 class MixedSwarmRound:
-    """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (scripts/swarm_bench.py runs it on the
-    GPUs, tests/test_dist_cpu.py with gloo and the CPU oracle standing in for the launches):
+    """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (bench.py and scripts/swarm_bench.py run it
+    on the GPUs, tests/test_swarm_gpu.py checks it there against the oracle, tests/test_dist_cpu.py with gloo and the CPU oracle
+    standing in for the launches):
 
-      1. the shard's vehicles run T fused EKF steps — cut into `chunks` launches whose histories are all-gathered one by one while
-         the next chunk computes (ChunkedTrajectoryGather; `gather="final"` gathers the final estimates only, "none" nothing);
-      2. every `plan_every`-th vehicle plans from its final estimate: plan_launch(est) — on a second stream on GPUs, so that the
-         planners of round r overlap the EKF launches of round r + 1 (they only read `est`, which the next round refills after
-         waiting for them).
+      1. the shard's vehicles run T fused EKF steps — when the trajectories are gathered over more than one rank, cut into `chunks`
+         launches whose histories are all-gathered one by one while the next chunk computes (ChunkedTrajectoryGather); ONE launch
+         otherwise (nothing to overlap: every extra launch pays the kernel's start-up and drain again — round 4 ran the 1-GPU shard at
+         0.285 of 8 TB/s in four launches of 25 steps).  `gather="final"` gathers the final estimates only, "none" nothing;
+      2. every `plan_every`-th vehicle plans from its final estimate: plan_launch(est, slot) — on the slot's own stream on GPUs.  The
+         round keeps `depth` planner slots (estimate buffer, stream, events) and uses them round-robin, so the planners of rounds
+         r - depth + 1 .. r are in flight together and overlap the EKF launches of the following rounds: one planner launch is a
+         latency chain (its slowest agent's sweeps) on a quarter of the SIMDs, `depth` of them fill the chip.  A slot's
+         estimate buffer is refilled only after the planners that read it have finished (an event, not a stream join).
 
     ekf_launch(c, t0, t1, hist): enqueue EKF steps [t0, t1) of this shard, history into hist [t1 - t0, n_local, C]; it owns the
     filter state and must reset it when c == 0.  final_state(): the shard's [n_local, C] estimate after the last chunk.
-    plan_launch(est): enqueue the planners on est [n_plan, C] (a buffer owned by this object); its return value is `plans`."""
+    plan_launch(est, slot): enqueue the planners on est [n_plan, C] (a buffer owned by this object); every buffer it writes must
+    belong to `slot` (0 .. depth-1) — the planners of the other slots are running.  Its return value is plans_of(round)."""
 
-    def __init__(self, n_local, T, C, chunks, plan_every, device, ekf_launch, final_state, plan_launch, gather="traj", n_total=None, group=None):
+    def __init__(self, n_local, T, C, chunks, plan_every, device, ekf_launch, final_state, plan_launch, gather="traj", n_total=None, group=None,
+                 depth=1):
         self.nl, self.T, self.C, self.every, self.gather_kind, self.group = n_local, T, C, int(plan_every), gather, group
         self.ekf_launch, self.final_state, self.plan_launch = ekf_launch, final_state, plan_launch
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_total = n_total if n_total is not None else n_local * self.world
         self.cuda = torch.device(device).type == "cuda"
-        self.chunks = chunks
+        self.depth = max(1, int(depth))
         assert T % chunks == 0, "the chunk count must divide the number of steps"
-        self.cg = ChunkedTrajectoryGather(T, n_local, C, chunks, device, group=group) if (gather == "traj" and dist.is_initialized()) else None
-        self.local_hist = None if self.cg is not None else torch.empty((chunks, T // chunks, n_local, C), dtype=torch.float32, device=device)
-        self.est = torch.empty(((n_local + self.every - 1) // self.every, C), dtype=torch.float32, device=device)
-        self.plan_stream = torch.cuda.Stream(device=device) if self.cuda else None
-        self.ekf_done = torch.cuda.Event() if self.cuda else None
-        self.plans = None
+        gathered = gather == "traj" and dist.is_initialized()
+        # chunked only where a gather overlaps the chunks (more than one rank): see the docstring
+        self.chunks = chunks if (gathered and self.world > 1) else 1
+        self.cg = ChunkedTrajectoryGather(T, n_local, C, self.chunks, device, group=group) if gathered else None
+        self.local_hist = None if self.cg is not None else torch.empty((self.chunks, T // self.chunks, n_local, C), dtype=torch.float32, device=device)
+        n_plan = (n_local + self.every - 1) // self.every
+        self.est = [torch.empty((n_plan, C), dtype=torch.float32, device=device) for _ in range(self.depth)]
+        self.plan_streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)] if self.cuda else None
+        self.ekf_done = [torch.cuda.Event() for _ in range(self.depth)] if self.cuda else None
+        self.plan_done = [torch.cuda.Event() for _ in range(self.depth)] if self.cuda else None
+        self._plans = [None] * self.depth
+        self.round = 0
         self.final = None
+
+    @property
+    def plans(self):
+        """The plans of the most recent round (valid after wait())."""
+        return self._plans[(self.round - 1) % self.depth] if self.round else None
+
+    def plans_of(self, rnd):
+        """The plans of round `rnd` (0-based; one of the last `depth` rounds; valid after wait())."""
+        assert max(0, self.round - self.depth) <= rnd < self.round, "that round's slot has been reused"
+        return self._plans[rnd % self.depth]
 
     def run(self):
         main = torch.cuda.current_stream() if self.cuda else None
+        slot = self.round % self.depth
         if self.cg is not None:
             self.cg.run(self.ekf_launch)
         else:
             Tc = self.T // self.chunks
             for c in range(self.chunks):
                 self.ekf_launch(c, c * Tc, (c + 1) * Tc, self.local_hist[c])
-        if self.cuda:
-            main.wait_stream(self.plan_stream)            # the planners of the previous round still read self.est
+        if self.cuda and self.round >= self.depth:
+            main.wait_event(self.plan_done[slot])         # the planners of round r - depth still read self.est[slot]
         x = self.final_state()
-        self.est.copy_(x[:: self.every])
+        self.est[slot].copy_(x[:: self.every])
         if self.cuda:
-            self.ekf_done.record(main)
-            with torch.cuda.stream(self.plan_stream):
-                self.plan_stream.wait_event(self.ekf_done)
-                self.plans = self.plan_launch(self.est)
+            self.ekf_done[slot].record(main)
+            ps = self.plan_streams[slot]
+            with torch.cuda.stream(ps):
+                ps.wait_event(self.ekf_done[slot])
+                self._plans[slot] = self.plan_launch(self.est[slot], slot)
+                self.plan_done[slot].record(ps)
         else:
-            self.plans = self.plan_launch(self.est)
+            self._plans[slot] = self.plan_launch(self.est[slot], slot)
         if self.gather_kind == "final" and dist.is_initialized():
             self.final = gather_agents(x, self.n_total, self.group)
+        self.round += 1
         return self
 
     def wait(self):
         if self.cg is not None:
             self.cg.wait()
         if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.plan_stream)
+            for ps in self.plan_streams:
+                torch.cuda.current_stream().wait_stream(ps)
 
     def gathered_bytes_per_rank(self):
         if not dist.is_initialized() or self.world == 1:
@@ -216,3 +244,89 @@ class MixedSwarmRound:
         if self.cg is None:
             return self.local_hist.reshape(self.T, self.nl, self.C).clone()
         return self.cg.time_major()
+
+
+class SwarmShard:
+    """This rank's shard of BASELINE.json configs[4] on the engine's kernels — what bench.py (`extra.swarm_configs4` /
+    `multi_gpu.swarm_configs4`), scripts/swarm_bench.py and tests/test_swarm_gpu.py run.  Per round (MixedSwarmRound):
+
+      1. every vehicle of the shard runs T fused EKF steps from its start state (crx_ekf_run_batch_dev, xEst history out) — the body of
+         the reference's main loop, /root/reference/src/extended_kalman_filter.cpp:171-188;
+      2. every `plan_every`-th vehicle plans from its final estimate at the commanded speed: nearest course point, calc_ref_trajectory,
+         mpc_solve over Tm knots — one pass of mpc_simulation's loop, /root/reference/src/model_predictive_control.cpp:371-385.  (The
+         estimated pose, not the filter's 4th state: that one integrates the noisy velocity input every step — F(3,3) = 1 and B(3,0) = 1,
+         extended_kalman_filter.cpp:27,34 — a random walk, not a speed estimate.)
+
+    Every input is keyed by the GLOBAL agent id (start poses drawn for the whole swarm and sliced; Philox draws counted from
+    rank * n), so a shard computes what the whole swarm would have computed for its agents.  `input_sets` independent sets of
+    measurements (seed + set index) are used round-robin — the parity test gives consecutive rounds different inputs, so that a
+    planner launch reading another round's estimates could not go unnoticed.
+
+    course: the (cx, cy, cyaw, ck, sp) float32 arrays of the shared course; Q, R: the filter's noise matrices (column-major).
+    mpc_fn(est, xref, Tm, out): the planner launch (default cpprobotics_amd.mpc_solve)."""
+
+    def __init__(self, n, T, course, Q, R, device, rank=0, world=1, Tm=21, plan_every=8, depth=4, chunks=4, gather="traj", seed=99, v_cmd=2.5,
+                 input_sets=1, mpc_fn=None, group=None, record_ekf_events=False):
+        import numpy as np
+
+        import cpprobotics_amd as crx
+        from .ekf import _qr
+        self.crx, self.n, self.T, self.Tm, self.dev, self.rank, self.world, self.v_cmd = crx, n, T, Tm, device, rank, world, float(v_cmd)
+        self.n_total, self.n_plan, self.every = n * world, (n + plan_every - 1) // plan_every, plan_every
+        self.q, self.r = _qr(Q, R)
+        self.dc = crx.Course.from_numpy(course, device=device)
+        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, out=out))
+        ci = np.random.default_rng(seed).integers(0, len(course[0]) - 30, self.n_total)[rank * n:(rank + 1) * n]
+        self.start_index = ci
+        cit = torch.from_numpy(ci).to(device)
+        cx, cy, cyaw = (torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in course[:3])
+        self.x0 = torch.stack([cx[cit], cy[cit], cyaw[cit], torch.full((n,), self.v_cmd, device=device)], dim=1).contiguous()
+        self.P0 = torch.eye(4, device=device).reshape(1, 16).repeat(n, 1).contiguous()
+        u_true = torch.zeros((n, 2), dtype=torch.float32, device=device)               # (accel, yaw rate): the vehicles cruise
+        self.z, self.ud = [], []
+        for s in range(input_sets):
+            w = crx.normal_draws(n, T, agent0=rank * n, seed=seed + s, device=device)
+            z, ud = crx.ekf_simulate_inputs(u_true, self.x0.clone(), self.x0.clone(), w)
+            self.z.append(z); self.ud.append(ud)
+            del w
+        self.x, self.P = self.x0.clone(), self.P0.clone()
+        nv = crx.mpc_n_vars(Tm)
+        self.slots = [dict(tind=torch.zeros(self.n_plan, dtype=torch.int32, device=device),
+                           e=torch.empty(self.n_plan, dtype=torch.float32, device=device),
+                           xref=torch.empty((self.n_plan, 4 * Tm), dtype=torch.float32, device=device),
+                           sol=torch.empty((self.n_plan, nv), dtype=torch.float32, device=device),
+                           status=torch.empty(self.n_plan, dtype=torch.int32, device=device),
+                           cost=torch.empty(self.n_plan, dtype=torch.float64, device=device)) for _ in range(max(1, depth))]
+        self.ekf_events = [] if record_ekf_events else None
+        self.rnd = MixedSwarmRound(n, T, 4, chunks, plan_every, device, self._ekf_launch, lambda: self.x, self._plan_launch, gather=gather,
+                                   n_total=self.n_total, group=group, depth=depth)
+
+    def _ekf_launch(self, c, t0, t1, hist):
+        s = self.rnd.round % len(self.z)
+        if c == 0:
+            self.x.copy_(self.x0); self.P.copy_(self.P0)
+        ev = self.ekf_events
+        if ev is not None:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        self.crx.ekf_run(self.x, self.P, self.z[s][t0:t1], self.ud[s][t0:t1], self.q, self.r, x_hist=hist)
+        if ev is not None:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record(); ev.append((e0, e1))
+
+    def _plan_launch(self, est, slot):
+        b = self.slots[slot]
+        est[:, 3] = self.v_cmd
+        self.crx.calc_nearest_index(est, self.dc, b["tind"], e=b["e"])
+        self.crx.calc_ref_trajectory(est, self.dc, b["tind"], self.Tm, out=b["xref"])
+        self.mpc_fn(est, b["xref"], self.Tm, (b["sol"], b["status"], b["cost"]))
+        return b
+
+    def run(self):
+        self.rnd.run()
+        return self
+
+    def wait(self):
+        self.rnd.wait()
+
+    def algorithmic_bytes_ekf(self):
+        """HBM bytes the round's EKF launches must move (32 B per update + 160 B per vehicle per launch)."""
+        return 32.0 * self.n * self.T + 160.0 * self.n * self.rnd.chunks

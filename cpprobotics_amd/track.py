@@ -87,15 +87,16 @@ def vehicle_params(mpc=False, **over):
     return p
 
 
-def calc_nearest_index(state, course, ind=None):
-    """-> (ind int32 [n], e float32 [n]); ind is updated in place when given."""
+def calc_nearest_index(state, course, ind=None, e=None):
+    """-> (ind int32 [n], e float32 [n]); ind (and e) are written in place when given."""
     import torch
-    L.require_cuda(state, ind)
+    L.require_cuda(state, ind, e)
     n = state.shape[0]
-    L.expect("state", state, "f", n, 4); L.expect("ind", ind, "i", n, optional=True)
+    L.expect("state", state, "f", n, 4); L.expect("ind", ind, "i", n, optional=True); L.expect("e", e, "f", n, optional=True)
     if ind is None:
         ind = torch.zeros((n,), dtype=torch.int32, device=state.device)
-    e = torch.empty((n,), dtype=torch.float32, device=state.device)
+    if e is None:
+        e = torch.empty((n,), dtype=torch.float32, device=state.device)
     L.check(L.lib().crx_calc_nearest_index_batch_dev(n, L.ptr(state), course.ref(), L.ptr(ind), L.ptr(e), L.stream_ptr()),
             "crx_calc_nearest_index_batch_dev")
     return ind, e
@@ -169,13 +170,13 @@ def calc_nearest_index_window(state, course, pind, nsearch=10):
     return out
 
 
-def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10):
-    """-> xref [n,4T] (column-major 4xT per agent); target_ind (int32 [n]) is updated in place."""
+def calc_ref_trajectory(state, course, target_ind, T, dl=1.0, dt=0.2, nsearch=10, out=None):
+    """-> xref [n,4T] (column-major 4xT per agent; `out` when given); target_ind (int32 [n]) is updated in place."""
     import torch
-    L.require_cuda(state, target_ind)
+    L.require_cuda(state, target_ind, out)
     n = state.shape[0]
-    L.expect("state", state, "f", n, 4); L.expect("target_ind", target_ind, "i", n)
-    xref = torch.empty((n, 4 * T), dtype=torch.float32, device=state.device)
+    L.expect("state", state, "f", n, 4); L.expect("target_ind", target_ind, "i", n); L.expect("out", out, "f", n, 4 * T, optional=True)
+    xref = torch.empty((n, 4 * T), dtype=torch.float32, device=state.device) if out is None else out
     L.check(L.lib().crx_calc_ref_trajectory_batch_dev(n, T, L.ptr(state), course.ref(), float(dl), float(dt), int(nsearch),
                                                       L.ptr(target_ind), L.ptr(xref), L.stream_ptr()),
             "crx_calc_ref_trajectory_batch_dev")

@@ -58,10 +58,16 @@ int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
 int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
 
 /* crx_mpc_solve_batch_dev through the lane-refilling kernel (mpc_refill_kernel: a wave owns `agents_per_wave` consecutive agents;
- * once `hold_lanes` of its lanes hold a finished solve they write their solutions and take the next agents of the range).  Built to
- * MEASURE what refilling buys the MPC solve in its throughput regime; scripts/gpu_mpc_refill_ab.py. */
+ * once `hold_lanes` of its lanes hold a finished solve they write their solutions and take the next agents of the range) with the
+ * geometry forced.  Since round 5 the product selects this kernel itself from 65,536 agents on (both libraries serve this entry
+ * point); scripts/gpu_mpc_refill_ab.py, scripts/gpu_mpc_variants_ab.py. */
 int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                double* cost, void* stream, int agents_per_wave, int hold_lanes);
+/* The A/B variants of the one-lane-per-agent solve (libcrx_x.so only).  variant bit 0: the reference trajectory in the placement
+ * the product does NOT use (private copy / global memory), bit 1: the 256-register build with two waves per SIMD (mpc_w2_kernel);
+ * agents_per_wave = 0: mpc_kernel, otherwise the lane-refilling kernel with that many agents per wave.  All bit-identical per agent. */
+int crx_x_mpc_solve_variant_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                double* cost, void* stream, int variant, int agents_per_wave, int hold_lanes);
 
 /* crx_dare_from_v_batch_dev with one agent per lane and the lane-refilling kernel forced (dare_from_v_refill_kernel: a wave owns
  * `agents_per_wave` consecutive agents; once `hold_lanes` of its lanes hold a finished agent they hand them back in one pass and

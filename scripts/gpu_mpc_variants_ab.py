@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""A/B of the one-lane-per-agent MPC solve's round-5 variants, standalone launches at 8,192 .. 1 M agents (T = 21): reference trajectory
+in global / private memory, the 256-register build (two waves per SIMD), lane refilling at several range lengths.  Every variant must
+reproduce mpc_kernel's bits.  One JSON line per batch size -> profiles/rNN/mpc_variants_ab.jsonl.
+  python scripts/gpu_mpc_variants_ab.py [sizes ...]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import numpy as np
+    import torch
+
+    import cpprobotics_amd as crx
+    from cpprobotics_amd import experimental as X
+    from common import mpc_problem
+    sizes = [int(a) for a in sys.argv[1:]] or [8192, 16384, 65536, 262144, 1048576]
+    T = 21
+
+    def timeit(fn, reps):
+        fn(); torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+    for n in sizes:
+        x0, xref = mpc_problem(n, T, 4)
+        x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+        base = X.mpc_solve_lanes(x0, xref, T, lanes_per_agent=1)                 # mpc_kernel forced (the product refills from 65,536 on)
+        sw = (base[1].cpu().numpy() >> 8).astype(np.int64)
+        reps = 5 if n <= 65536 else 2
+        line = {"agents": n, "T": T, "sweeps_mean": float(sw.mean()), "sweeps_max": int(sw.max()),
+                "ms_mpc_kernel": timeit(lambda: X.mpc_solve_lanes(x0, xref, T, lanes_per_agent=1), reps),
+                "ms_product_entry": timeit(lambda: crx.mpc_solve(x0, xref, T), reps)}
+        same = True
+        variants = [("xrp", 1, 0), ("w2", 2, 0), ("w2_xrp", 3, 0)]
+        if n >= 16384:
+            variants += [("refill_%d" % c, 0, c) for c in (128, 256, 512, 1024) if n // c >= 64]
+            variants += [("refill_%d_other_xr" % c, 1, c) for c in (256, 512) if n // c >= 64]
+        for name, bits, apw in variants:
+            out = X.mpc_solve_variant(x0, xref, T, bits, apw)
+            same = same and all(torch.equal(a.view(torch.uint8), b.view(torch.uint8)) for a, b in zip(out, base))
+            line["ms_" + name] = timeit(lambda: X.mpc_solve_variant(x0, xref, T, bits, apw), reps)
+        line["bit_identical"] = bool(same)
+        best = min((k for k in line if k.startswith("ms_")), key=lambda k: line[k])
+        line["best"] = best
+        line["solves_per_s_best"] = n / (line[best] * 1e-3)
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel with the reference trajectory in
+global / private memory, the 256-register build and the lane-refilling kernel, N agents (default 262,144), T = 21, `reps` launches each."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+from cpprobotics_amd import experimental as X
+from common import mpc_problem
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+x0, xref = mpc_problem(n, 21, 4)
+x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+for bits, apw in ((0, 0), (1, 0), (2, 0), (0, 512), (1, 512)):
+    for _ in range(reps):
+        X.mpc_solve_variant(x0, xref, 21, bits, apw)
+    torch.cuda.synchronize()

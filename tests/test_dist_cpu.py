@@ -167,7 +167,7 @@ def _swarm_worker(rank, world, port, n, T, q):
         st["x"], st["P"], h, _ = oracle.ekf_run(st["x"], st["P"], z[t0:t1], ud[t0:t1], Q, R)
         hist.copy_(torch.from_numpy(h))
 
-    def plan_launch(est):
+    def plan_launch(est, slot):
         e = est.numpy().copy(); e[:, 3] = 2.5
         tind = oracle.calc_nearest_index(e, course)[0].astype(np.int32)
         xref, _ = oracle.calc_ref_trajectory(e, course, tind, 6)
@@ -175,7 +175,8 @@ def _swarm_worker(rank, world, port, n, T, q):
 
     outs = []
     for kind in ("traj", "final"):
-        rnd = swarm.MixedSwarmRound(hi - lo, T, 4, 4, 8, "cpu", ekf_launch, lambda: torch.from_numpy(st["x"]), plan_launch, gather=kind, n_total=n)
+        rnd = swarm.MixedSwarmRound(hi - lo, T, 4, 4, 8, "cpu", ekf_launch, lambda: torch.from_numpy(st["x"]), plan_launch, gather=kind, n_total=n,
+                                    depth=2 if kind == "final" else 1)
         for _ in range(2):                       # two rounds: the second one reuses every buffer of the first
             rnd.run()
         rnd.wait()

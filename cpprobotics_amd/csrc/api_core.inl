@@ -13,22 +13,29 @@ int crx_init(void) {
   CRX_HIP(hipFree(nullptr));
   return CRX_OK;
 }
-int crx_release_workspace(void) {
+// per-device work of crx_release_workspace / crx_shutdown; the caller restores the thread's current device whatever this returns
+static int release_device(int d, bool handles_too) {
+  crxh::DeviceCtx& c = crxh::ctx_table()[d];
+  std::lock_guard<std::mutex> l(c.mu);
+  if (!c.dws.p && !c.pws.p && !(handles_too && c.has_handles())) return CRX_OK;
+  CRX_HIP(hipSetDevice(d));
+  CRX_HIP(hipDeviceSynchronize());
+  c.release_workspace();
+  if (handles_too) c.destroy_handles();
+  return CRX_OK;
+}
+static int release_all(bool handles_too) {
   const int nd = crx_device_count();
   int cur = 0;
   if (nd == 0) return CRX_OK;
   CRX_HIP(hipGetDevice(&cur));
-  for (int d = 0; d < nd && d < crxh::kMaxDevices; ++d) {
-    crxh::DeviceCtx& c = crxh::ctx_table()[d];
-    std::lock_guard<std::mutex> l(c.mu);
-    if (!c.dws.p && !c.pws.p) continue;
-    CRX_HIP(hipSetDevice(d));
-    CRX_HIP(hipDeviceSynchronize());
-    c.release_workspace();
-  }
-  CRX_HIP(hipSetDevice(cur));
-  return CRX_OK;
+  int rc = CRX_OK;
+  for (int d = 0; d < nd && d < crxh::kMaxDevices && rc == CRX_OK; ++d) rc = release_device(d, handles_too);
+  const hipError_t e = hipSetDevice(cur);          // on the failure paths too: the caller's later _dev calls must not land on another GPU
+  if (rc == CRX_OK && e != hipSuccess) return hip_fail(e, "hipSetDevice (restore)");
+  return rc;
 }
+int crx_release_workspace(void) { return release_all(false); }
 // Grow the current device's workspaces ahead of time (a latency-sensitive host calls this once at start-up with the sizes of its
 // largest call, so that no call pays for the growth: hipMalloc / hipHostMalloc of hundreds of MB take tens of milliseconds).
 int crx_reserve_workspace(size_t device_bytes, size_t pinned_bytes) {
@@ -43,7 +50,7 @@ int crx_reserve_workspace(size_t device_bytes, size_t pinned_bytes) {
 }
 int crx_shutdown(void) {
   if (crx_device_count() == 0) return CRX_OK;
-  if (int rc = crx_release_workspace()) return rc;
+  if (int rc = release_all(true)) return rc;       // workspaces, and the contexts' streams and events
   CRX_HIP(hipDeviceSynchronize());
   return CRX_OK;
 }

@@ -262,6 +262,10 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
   crxh::DeviceCtx* c = nullptr;
   std::unique_lock<std::mutex> lock;
   CRX_TRY(ctx_open(&c, lock));
+  // every early return below (a failed HIP call, a failed launch) drains the three streams before `lock` is released: queued D2H
+  // copies would otherwise go on writing into pin_out — or, with direct_out, into the caller's x_hist / P_hist — after the call
+  // has reported failure, and the next call could reuse or free the workspaces under them
+  struct Drain { crxh::DeviceCtx* c; bool armed = true; ~Drain() { if (armed) c->drain(); } } drain_guard{c};
   const size_t nl = (size_t)(a1 - a0), nn = (size_t)n;
   const size_t per_step_in = 16 * nl, per_step_out = (x_hist ? 16 * nl : 0) + (P_hist ? 64 * nl : 0);
   const bool direct_in = crxh::is_pinned(z) && crxh::is_pinned(u);
@@ -379,6 +383,7 @@ int ekf_run_host_shard(int n, int a0, int a1, int T, float* x, float* P, const f
   if (per_step_out) CRX_HIP(hipStreamSynchronize(c->s_out));
   std::memcpy(x + 4 * (size_t)a0, pxP, 16 * nl);
   std::memcpy(P + 16 * (size_t)a0, pxP + xb, 64 * nl);
+  drain_guard.armed = false;                       // s_cmp and s_out are idle, s_in's copies were consumed by the kernels
   return CRX_OK;
 }
 

@@ -109,6 +109,9 @@ class HostCall {
   // in the workspace densely.  src: copied in (NULL: not); dst: copied back (NULL: not); zero: cleared when there is no src.
   struct Arg { const char* src; char* dst; size_t row_bytes, rows, pitch; bool zero; char* d; };
 
+  // an early return between commit() and finish() (a failed HIP call, a failed launch) must not leave copies in flight on the
+  // context's streams when the lock goes: drained here, still under the lock (members are destroyed after this body)
+  ~HostCall() { if (c_ && !finished_) c_->drain(); }
   int open() { return ctx_open(&c_, lock_); }
   // kernels that come back to their inputs tick after tick (the closed loops read the course from global memory every tick) must
   // not run out of host memory across PCIe
@@ -149,11 +152,13 @@ class HostCall {
       CRX_HIP(hipStreamSynchronize(c_->s_cmp));
       for (auto& a : args_)
         if (a.dst) crxh::CopyPool::get().submit(crxh::CopyPool::Job{a.dst, a.d, a.row_bytes, a.rows, a.pitch, a.row_bytes}, nullptr);
+      finished_ = true;
       return CRX_OK;
     }
     for (auto& a : args_)
       if (a.dst && a.row_bytes * a.rows) { if (int rc = copy_out(a)) return rc; }
     CRX_HIP(hipStreamSynchronize(c_->s_cmp));
+    finished_ = true;
     return CRX_OK;
   }
 
@@ -161,8 +166,12 @@ class HostCall {
   crxh::DeviceCtx* c_ = nullptr;
   std::unique_lock<std::mutex> lock_;
   std::vector<Arg> args_;
-  bool zc_ = false, allow_zc_ = true;
+  bool zc_ = false, allow_zc_ = true, finished_ = false;
   size_t slot_ = crxh::kStageChunk;
+  // the two staging slots of the pinned ring are shared by every pageable argument of the call: a slot whose H2D has been queued
+  // is refilled only after that DMA's event — across arguments too (the fence used to restart with every argument, so
+  // the second large pageable input of a call overwrote the slot the first one's last DMA was still reading)
+  bool slot_in_flight_[2] = {false, false};
 
   // how a staged copy is cut: `rows == 1` along the bytes, otherwise along the rows
   struct Cut { size_t chunks, unit_rows, unit_bytes; };
@@ -193,7 +202,7 @@ class HostCall {
     const Cut ct = cut(a);
     for (size_t k = 0; k < ct.chunks; ++k) {
       char* slot = pin + (k & 1) * slot_;
-      if (k >= 2) CRX_HIP(hipEventSynchronize(c_->ev_tmp[k & 1]));
+      if (slot_in_flight_[k & 1]) CRX_HIP(hipEventSynchronize(c_->ev_tmp[k & 1]));
       size_t len, doff;
       crxh::CopyPool::Ticket t;
       if (a.rows == 1) {
@@ -207,6 +216,7 @@ class HostCall {
       crxh::CopyPool::get().wait(&t);
       CRX_HIP(hipMemcpyAsync(a.d + doff, slot, len, hipMemcpyHostToDevice, c_->s_cmp));
       CRX_HIP(hipEventRecord(c_->ev_tmp[k & 1], c_->s_cmp));
+      slot_in_flight_[k & 1] = true;
     }
     return CRX_OK;
   }

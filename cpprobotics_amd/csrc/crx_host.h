@@ -193,22 +193,37 @@ struct DeviceCtx {
   hipStream_t s_in = nullptr, s_cmp = nullptr, s_out = nullptr;
   hipEvent_t ev_in[kRing] = {}, ev_cmp[kRing] = {}, ev_out[kRing] = {}, ev_tmp[2] = {};
   bool ready = false;
+  // creates only the handles that are still null: a call that failed half-way leaves nothing behind that a retry would leak
   hipError_t init(int d) {
     if (ready) return hipSuccess;
     dev = d; pws.pinned = true;
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking)) != hipSuccess) return e;
-    if ((e = hipStreamCreateWithFlags(&s_cmp, hipStreamNonBlocking)) != hipSuccess) return e;
-    if ((e = hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking)) != hipSuccess) return e;
-    for (int i = 0; i < kRing; ++i) {
-      if ((e = hipEventCreateWithFlags(&ev_in[i], hipEventDisableTiming)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&ev_cmp[i], hipEventDisableTiming)) != hipSuccess) return e;
-      if ((e = hipEventCreateWithFlags(&ev_out[i], hipEventDisableTiming)) != hipSuccess) return e;
-    }
-    for (int i = 0; i < 2; ++i)
-      if ((e = hipEventCreateWithFlags(&ev_tmp[i], hipEventDisableTiming)) != hipSuccess) return e;
+    for (hipStream_t* s : {&s_in, &s_cmp, &s_out})
+      if (!*s && (e = hipStreamCreateWithFlags(s, hipStreamNonBlocking)) != hipSuccess) { *s = nullptr; return e; }
+    for (hipEvent_t* ev : events())
+      if (!*ev && (e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) { *ev = nullptr; return e; }
     ready = true;
     return hipSuccess;
+  }
+  std::vector<hipEvent_t*> events() {
+    std::vector<hipEvent_t*> v;
+    for (int i = 0; i < kRing; ++i) { v.push_back(&ev_in[i]); v.push_back(&ev_cmp[i]); v.push_back(&ev_out[i]); }
+    v.push_back(&ev_tmp[0]); v.push_back(&ev_tmp[1]);
+    return v;
+  }
+  bool has_handles() { return s_in || s_cmp || s_out; }
+  // crx_shutdown: the device is idle (the caller synchronised it) and the context lock is held
+  void destroy_handles() {
+    for (hipStream_t* s : {&s_in, &s_cmp, &s_out}) if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+    for (hipEvent_t* ev : events()) if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+    ready = false;
+  }
+  // every queued copy and kernel of a host-pointer call has finished: called on the error paths before the context lock is released
+  // (a D2H still in flight would otherwise write into the caller's arrays — or a workspace the next call reuses — after the call
+  // has reported failure)
+  void drain() {
+    for (hipStream_t s : {s_in, s_cmp, s_out}) if (s) (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
   }
   void release_workspace() { dws.release(); pws.release(); }
 };

@@ -358,7 +358,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   bool done = REFILL ? true : !live;
   // REFILL bookkeeping: the lane's agent (-1: none; a done lane with an agent holds a finished solve), the trip of the loop below at
   // which that agent started, the wave's cursor into its range, the lanes asking for an agent
-  int agent_l = -1, it_base = 0, next = feed.lo;
+  int agent_l = -1, next = feed.lo;
   lanemask_t want = ~lanemask_t(0);
   const size_t nv_ = 4 * (size_t)T + 2 * ((size_t)T - 1);
   // the agent's answer in the reference's layout (:341-345) and the speed-bound check of every knot
@@ -387,45 +387,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 #ifdef CRX_MPC_TICKS
   long long tk_b = 0, tk_f = 0, tk_nb = 0, tk_nf = 0; const long long tk_0 = clock64();
 #endif
-  for (int iter = 0; REFILL || iter < p.max_iter; ++iter) {
-    if (PORTFOLIO) { if (quad_converged()) done = true; }      // a sibling variant has the answer: every lane of the quad stops
-    if constexpr (REFILL) {
-      const lanemask_t sweeping = lanes_where(!done);
-      const lanemask_t held = lanes_where(done && agent_l >= 0);
-      if (held && (!sweeping || __builtin_popcountll(held) >= feed.hold)) {        // hand the finished agents back, all at once
-        if (done && agent_l >= 0) {
-          write_solution(feed.solg ? feed.solg + (size_t)agent_l * nv_ : nullptr);
-          if (feed.statusg) feed.statusg[agent_l] = status | (it << 8);
-          if (feed.costg) feed.costg[agent_l] = J;
-          agent_l = -1;
-        }
-        want |= held;
-      }
-      if (want && next < feed.hi) {                                                 // the lanes without an agent take the next ones
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
-        const int mine = next + (int)rank;
-        next += __builtin_popcountll(want);
-        const bool got = ((want >> (threadIdx.x & 63)) & 1) && mine < feed.hi;
-        if (got) {
-          agent_l = mine;
-          xi = reinterpret_cast<const float4*>(feed.x0g)[mine];
-          xr4 = reinterpret_cast<const float4*>(feed.xrefg) + (size_t)mine * (size_t)T;
-          xr_fetch();
-          rN = xr_at(N);
-          start();
-          it_base = iter;
-          done = false;
-        }
-        want &= ~lanes_where(got);
-      }
-      if (!lanes_where(!done)) break;                          // nobody sweeping: every held agent was handed back above
-    } else {
-      if (__all(done)) break;
-    }
-    if (done) continue;
-    const int li = REFILL ? iter - it_base : iter;             // the sweep index of the lane's own agent
-    it = li;
-    const bool exact = gn_left <= 0;
+  // ---- the two halves of a sweep ----------------------------------------------------------------------------------------------
+  double dV1 = 0.0, dV2 = 0.0, gnorm = 0.0;          // results of backward(): expected change of the cost, largest feed-forward step
+  // backward(exact): the Riccati sweep over the stages N-1 .. 0 around the accepted iterate (buffer `cur`); writes the gains kf, Kf
+  auto backward = [&](const bool exact) {
     // ------------------------------------------------------------------ backward sweep
     double lx[4], lp0, lp1;          // V_s
     double Wxx[4][4], Wxp[4][2], Wpp00, Wpp01, Wpp11;  // V_ss (symmetric)
@@ -446,7 +411,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       Wxx[0][0] = 2.0 * p.qx; Wxx[1][1] = 2.0 * p.qy; Wxx[2][2] = 2.0 * p.qyaw; Wxx[3][3] = 2.0 * p.qv;
       Wpp00 = 0.0; Wpp01 = 0.0; Wpp11 = 0.0;
     }
-    double dV1 = 0.0, dV2 = 0.0, gnorm = 0.0;
+    dV1 = 0.0; dV2 = 0.0; gnorm = 0.0;
     // The sweep's operands live in private memory (L2 / HBM latency once only a few waves are still iterating): stage
     // i - 1's knot, trig and reference and stage i - 2's control are requested at the top of stage i and consumed one
     // iteration later.
@@ -670,82 +635,180 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     }
 #if CRX_MPC_TICKS >= 2
     tk_b += clock64() - tk_b0; tk_nb++;
+#endif
+  };
+  // rollout(alpha, nxt): the candidate u + alpha k + K dx rolled through the model into buffer `nxt`; returns its cost
+  auto rollout = [&](const double alpha, const int nxt) -> double {
+#if CRX_MPC_TICKS >= 2
     const long long tk_f0 = clock64();
 #endif
-    if (gnorm < p.tol && mu == 0.0) { status |= 1; done = true; continue; }
-    // ------------------------------------------------------------------ forward rollout + line search
-    const double aJ = fabs(J);
-    const double noise = 1e-12 * (aJ > 1.0 ? aJ : 1.0);
-    const bool trust = -(dV1 + dV2) < noise;
-    bool accepted = false;
-    double alpha = 1.0;
-    const int nxt = cur ^ 1;
-    const int ls_max = exact ? 4 : 10;   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
-    for (int ls = 0; ls < ls_max; ++ls) {
-      double Jn = 0.0;
-      // The candidate rollout carries its state and previous control in registers (they are also written to S[nxt],
-      // U[nxt] for the next backward sweep, but never read back here: a store-to-load round trip through private memory
-      // per stage would sit on the critical path), and requests stage i + 1's operands while stage i computes.
-      double xs[4] = {S[cur][0][0], S[cur][0][1], S[cur][0][2], S[cur][0][3]};
-      double pnd = 0.0, pna = 0.0, pcd = 0.0, pca = 0.0;       // previous stage's new / current controls
-      RollIn nx = load_roll(cur, 0);
-      for (int i = 0; i < N; ++i) {
-        const RollIn in = nx;
-        nx = load_roll(cur, i + 1 < N ? i + 1 : N - 1);      // unconditional, clamped: see the backward sweep (two stages in
-                                                             // flight were measured too: 4 % slower)
-        const double d0 = xs[0] - in.s[0], d1 = xs[1] - in.s[1], d2 = xs[2] - in.s[2], d3 = xs[3] - in.s[3];
-        const double d4 = (i >= 1) ? pnd - pcd : 0.0;
-        const double d5 = (i >= 1) ? pna - pca : 0.0;
-        double du0 = alpha * in.k0;
-        du0 += in.K[0] * d0; du0 += in.K[2] * d1; du0 += in.K[4] * d2; du0 += in.K[6] * d3; du0 += in.K[8] * d4; du0 += in.K[10] * d5;
-        double du1 = alpha * in.k1;
-        du1 += in.K[1] * d0; du1 += in.K[3] * d1; du1 += in.K[5] * d2; du1 += in.K[7] * d3; du1 += in.K[9] * d4; du1 += in.K[11] * d5;
-        const AccelBox nb = accel_box(p, inv_dt, xs[3]);            // the box of a_i at the NEW speed of knot i
-        const double nd = clampd(in.u0 + du0, lb0, ub0);
-        const double na = clampd(in.u1 + du1, nb.lo, nb.hi);
-        U[nxt][i][0] = nd; U[nxt][i][1] = na;
-        double cv = p.r_d * nd * nd + p.r_a * na * na;              // ctrl(nxt, i)
-        if (i >= 1) {
-          const double dd = nd - pnd, da = na - pna;
-          cv += p.rd_d * dd * dd + p.rd_a * da * da;
-        }
-        Jn += cv;
-        if (i >= 1) {                                               // track(xs, i)
-          const double e0 = (double)in.r.x - xs[0], e1 = (double)in.r.y - xs[1], e2 = (double)in.r.z - xs[2], e3 = (double)in.r.w - xs[3];
-          Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
-        }
-        double xn[4];
-        step(xs, nd, na, xn, TR[nxt][i]);
-        S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
-        xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
-        pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
+    double Jn = 0.0;
+    // The candidate rollout carries its state and previous control in registers (they are also written to S[nxt],
+    // U[nxt] for the next backward sweep, but never read back here: a store-to-load round trip through private memory
+    // per stage would sit on the critical path), and requests stage i + 1's operands while stage i computes.
+    double xs[4] = {S[cur][0][0], S[cur][0][1], S[cur][0][2], S[cur][0][3]};
+    double pnd = 0.0, pna = 0.0, pcd = 0.0, pca = 0.0;       // previous stage's new / current controls
+    RollIn nx = load_roll(cur, 0);
+    for (int i = 0; i < N; ++i) {
+      const RollIn in = nx;
+      nx = load_roll(cur, i + 1 < N ? i + 1 : N - 1);      // unconditional, clamped: see the backward sweep (two stages in
+                                                           // flight were measured too: 4 % slower)
+      const double d0 = xs[0] - in.s[0], d1 = xs[1] - in.s[1], d2 = xs[2] - in.s[2], d3 = xs[3] - in.s[3];
+      const double d4 = (i >= 1) ? pnd - pcd : 0.0;
+      const double d5 = (i >= 1) ? pna - pca : 0.0;
+      double du0 = alpha * in.k0;
+      du0 += in.K[0] * d0; du0 += in.K[2] * d1; du0 += in.K[4] * d2; du0 += in.K[6] * d3; du0 += in.K[8] * d4; du0 += in.K[10] * d5;
+      double du1 = alpha * in.k1;
+      du1 += in.K[1] * d0; du1 += in.K[3] * d1; du1 += in.K[5] * d2; du1 += in.K[7] * d3; du1 += in.K[9] * d4; du1 += in.K[11] * d5;
+      const AccelBox nb = accel_box(p, inv_dt, xs[3]);            // the box of a_i at the NEW speed of knot i
+      const double nd = clampd(in.u0 + du0, lb0, ub0);
+      const double na = clampd(in.u1 + du1, nb.lo, nb.hi);
+      U[nxt][i][0] = nd; U[nxt][i][1] = na;
+      double cv = p.r_d * nd * nd + p.r_a * na * na;              // ctrl(nxt, i)
+      if (i >= 1) {
+        const double dd = nd - pnd, da = na - pna;
+        cv += p.rd_d * dd * dd + p.rd_a * da * da;
       }
-      {                                                             // track(xs, N), terminal reference kept in registers
-        const double e0 = (double)rN.x - xs[0], e1 = (double)rN.y - xs[1], e2 = (double)rN.z - xs[2], e3 = (double)rN.w - xs[3];
+      Jn += cv;
+      if (i >= 1) {                                               // track(xs, i)
+        const double e0 = (double)in.r.x - xs[0], e1 = (double)in.r.y - xs[1], e2 = (double)in.r.z - xs[2], e3 = (double)in.r.w - xs[3];
         Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
       }
-#if CRX_MPC_TICKS >= 2
-      tk_nf++;
-#endif
-      if (Jn < J || (trust && Jn <= J + noise)) { J = Jn; accepted = true; break; }
-      alpha *= 0.5;
+      double xn[4];
+      step(xs, nd, na, xn, TR[nxt][i]);
+      S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
+      xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
+      pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
+    }
+    {                                                             // track(xs, N), terminal reference kept in registers
+      const double e0 = (double)rN.x - xs[0], e1 = (double)rN.y - xs[1], e2 = (double)rN.z - xs[2], e3 = (double)rN.w - xs[3];
+      Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
     }
 #if CRX_MPC_TICKS >= 2
-    tk_f += clock64() - tk_f0;
+    tk_nf++; tk_f += clock64() - tk_f0;
 #endif
-    if (accepted) {
-      cur = nxt;
-      if (gn_left > 0) gn_left--;
-      if (alpha == 1.0) mu *= 0.1;
-      if (mu < mu_min) mu = 0.0;
-    } else if (exact) {
+    return Jn;
+  };
+  // what the end of a line search does to the globalisation state
+  auto accept_step = [&](const double alpha, const double Jn, const int nxt) {
+    J = Jn; cur = nxt;
+    if (gn_left > 0) gn_left--;
+    if (alpha == 1.0) mu *= 0.1;
+    if (mu < mu_min) mu = 0.0;
+  };
+  auto reject_step = [&](const bool exact) {
+    if (exact) {
       gn_run = gn_run * 2 > 16 ? 16 : gn_run * 2;   // every failed Newton attempt doubles the Gauss-Newton run after it
       gn_left = gn_run;
     } else {
       mu = (mu * 10.0 > 1e-3) ? mu * 10.0 : 1e-3;
       if (mu > mu_max) done = true;
     }
-    if (li == p.max_iter - 1) { it = p.max_iter; if (REFILL) done = true; }
+  };
+
+  if constexpr (PORTFOLIO) {
+    // The portfolio compares sweep counts across the lanes of a quad: its lanes sweep in lockstep, a sweep = the backward pass and the
+    // whole line search (a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones: 4 tries, otherwise 10).
+    for (int iter = 0; iter < p.max_iter; ++iter) {
+      if (quad_converged()) done = true;                       // a sibling variant has the answer: every lane of the quad stops
+      if (__all(done)) break;
+      if (done) continue;
+      it = iter;
+      const bool exact = gn_left <= 0;
+      backward(exact);
+      if (gnorm < p.tol && mu == 0.0) { status |= 1; done = true; continue; }
+      const double aJ = fabs(J);
+      const double noise = 1e-12 * (aJ > 1.0 ? aJ : 1.0);
+      const bool trust = -(dV1 + dV2) < noise;
+      bool accepted = false;
+      double alpha = 1.0;
+      const int nxt = cur ^ 1;
+      const int ls_max = exact ? 4 : 10;
+      for (int ls = 0; ls < ls_max; ++ls) {
+        const double Jn = rollout(alpha, nxt);
+        if (Jn < J || (trust && Jn <= J + noise)) { accept_step(alpha, Jn, nxt); accepted = true; break; }
+        alpha *= 0.5;
+      }
+      if (!accepted) reject_step(exact);
+      if (iter == p.max_iter - 1) it = p.max_iter;
+    }
+  } else {
+    // One lane per agent: the line search is scheduled ASYNCHRONOUSLY across the lanes of the wave (round 5).  A trip of the loop is one
+    // backward pass for the lanes that are due one and ONE candidate rollout for the lanes that have a line search pending; a lane
+    // whose candidate is refused halves alpha and rolls again in the NEXT trip, next to the other lanes' first candidates, instead of
+    // making the whole wave wait through its retries.  Rounds 1-4 ran the line search as an inner loop: the wave executed
+    // max-over-lanes rollouts per sweep — 31 rollouts for the 16 sweeps of the BASELINE batch's slowest wave, against ~1.3 per sweep that a
+    // lane needs — each a pass over the wave's private arrays with a handful of lanes alive (full cache lines for a few lanes' bytes:
+    // in the throughput regime, where that traffic is HBM traffic, the dominant waste — profiles/r05/mpc_traffic_*.json).  Per agent
+    // the same backward passes and the same rollouts with the same step lengths in the same order: bit-identical results.
+    int sweep = 0;                    // backward passes the lane's agent has started (= the sweep index reported in `status`)
+    bool fwd = false;                 // a line search is pending: the next candidate uses `alpha`
+    double alpha = 1.0, noise = 0.0;
+    int ls = 0;
+    bool trust = false;
+    if (!REFILL && p.max_iter <= 0) done = true;
+    for (;;) {
+      if constexpr (REFILL) {
+        const lanemask_t sweeping = lanes_where(!done);
+        const lanemask_t held = lanes_where(done && agent_l >= 0);
+        if (held && (!sweeping || __builtin_popcountll(held) >= feed.hold)) {        // hand the finished agents back, all at once
+          if (done && agent_l >= 0) {
+            write_solution(feed.solg ? feed.solg + (size_t)agent_l * nv_ : nullptr);
+            if (feed.statusg) feed.statusg[agent_l] = status | (it << 8);
+            if (feed.costg) feed.costg[agent_l] = J;
+            agent_l = -1;
+          }
+          want |= held;
+        }
+        if (want && next < feed.hi) {                                                 // the lanes without an agent take the next ones
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+          const int mine = next + (int)rank;
+          next += __builtin_popcountll(want);
+          const bool got = ((want >> (threadIdx.x & 63)) & 1) && mine < feed.hi;
+          if (got) {
+            agent_l = mine;
+            xi = reinterpret_cast<const float4*>(feed.x0g)[mine];
+            xr4 = reinterpret_cast<const float4*>(feed.xrefg) + (size_t)mine * (size_t)T;
+            xr_fetch();
+            rN = xr_at(N);
+            start();
+            sweep = 0; fwd = false;
+            done = false;
+          }
+          want &= ~lanes_where(got);
+        }
+        if (!lanes_where(!done)) break;                          // nobody sweeping: every held agent was handed back above
+      } else {
+        if (__all(done)) break;
+      }
+      if (!done && !fwd) {
+        it = sweep;
+        backward(gn_left <= 0);
+        if (gnorm < p.tol && mu == 0.0) { status |= 1; done = true; }
+        else {
+          const double aJ = fabs(J);
+          noise = 1e-12 * (aJ > 1.0 ? aJ : 1.0);
+          trust = -(dV1 + dV2) < noise;
+          alpha = 1.0; ls = 0; fwd = true;
+        }
+      }
+      if (!done && fwd) {
+        const bool exact = gn_left <= 0;
+        const int nxt = cur ^ 1;
+        const double Jn = rollout(alpha, nxt);
+        bool end = false;
+        if (Jn < J || (trust && Jn <= J + noise)) { accept_step(alpha, Jn, nxt); end = true; }
+        else {
+          alpha *= 0.5;
+          if (++ls == (exact ? 4 : 10)) { reject_step(exact); end = true; }   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
+        }
+        if (end) {
+          fwd = false;
+          if (sweep == p.max_iter - 1) { it = p.max_iter; done = true; }
+          ++sweep;
+        }
+      }
+    }
   }
   status_out = 0; cost_out = 0.0; a0_out = 0.0f; d0_out = 0.0f;
   if (REFILL) return;                                        // every agent of the range has been written from inside the loop

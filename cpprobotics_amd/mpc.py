@@ -31,7 +31,7 @@ def mpc_solve(x0, xref, T, params=None, return_status=False, portfolio=False, ou
     p = params if params is not None else default_params()
     if out is not None:
         sol, status, cost = out
-        L.require_cuda(sol, status, cost)
+        L.require_cuda(sol, status); L.require_cuda(cost, dtypes=(torch.float64,))
         L.expect("sol", sol, "f", n, mpc_n_vars(T)); L.expect("status", status, "i", n)
         if tuple(cost.shape) != (n,) or cost.dtype != torch.float64 or not cost.is_contiguous():
             raise ValueError("cost must be a contiguous float64 tensor of shape (n,)")

@@ -167,3 +167,18 @@ def test_every_batch_entry_point_refuses_null_arguments(n):
         called += 1
     assert called >= 45
 
+
+
+def test_libraries_bind_their_own_definitions(crx):
+    """libcrx.so and libcrx_x.so define the same inline launch functions and kernel stubs with different bodies; both are loaded into
+    one process by the A/B scripts.  Linked with -Wl,-Bsymbolic neither has a dynamic relocation against a crx symbol of its own, so
+    the second library cannot end up calling the first one's definitions (round 5: an A/B that measured one kernel three times)."""
+    import shutil
+    import subprocess
+    from cpprobotics_amd import experimental as X
+    if not shutil.which("readelf"):
+        pytest.skip("readelf not available")
+    for path in (crx.lib_path(), X.ab_lib_path()):
+        rel = subprocess.run(["readelf", "-r", "--wide", path], capture_output=True, text=True, check=True).stdout
+        bad = [l for l in rel.splitlines() if ("JUMP_SLO" in l or "GLOB_DAT" in l) and ("crx" in l.split()[-1] or "_ZN3crx" in l)]
+        assert not bad, (path, bad[:5])

@@ -214,3 +214,26 @@ def test_single_call_latency_report(crx, oracle_mod):
     for _ in range(200):
         crx.host.ekf_run(x0.copy(), P0.copy(), z, ud, Q, R)
     print(f"ekf_estimation (n = 1) through crx_ekf_run_batch: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per call (Python overhead included)")
+
+
+def test_several_large_pageable_inputs_in_one_call(crx, oracle_mod):
+    """a call with more than one pageable input of >= 1 MB stages them through the same two pinned slots; the fence on
+    slot reuse used to restart with every argument, so the second input could overwrite a slot whose H2D was still in flight.  Large
+    pageable numpy arrays through the host-pointer entry points must give the `_dev` path's bits: mpc_solve (x0 1.6 MB, xref 9.6 MB at
+    T = 6), solve_DARE (A 7 MB, B 2.8 MB, Q 7 MB, R 1.1 MB), and the same three times over (a race is a matter of timing)."""
+    import torch
+    n = 100000
+    x0, xref = mpc_problem(n, 6, seed=31)
+    sd, std, cd = crx.mpc_solve(torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda(), 6, return_status=True)
+    sd, std, cd = sd.cpu().numpy(), std.cpu().numpy(), cd.cpu().numpy()
+    for _ in range(3):
+        s, st, c = crx.host.mpc_solve(x0, xref, 6)
+        assert np.array_equal(st, std) and bit_equal(s, sd) and np.array_equal(c.view(np.int64), cd.view(np.int64))
+    m = 70000
+    v = lqr_speeds(m, seed=33)
+    A, B, Q, R = oracle_mod.lqr_build(v, 5)
+    Xd, itd = crx.solve_DARE(*(torch.from_numpy(a).cuda() for a in (A, B, Q, R)))
+    Kd = crx.dlqr(*(torch.from_numpy(a).cuda() for a in (A, B, Q, R)))
+    for _ in range(3):
+        X, K, it = crx.host.dare(A, B, Q, R)
+        assert bit_equal(X, Xd.cpu().numpy()) and np.array_equal(it, itd.cpu().numpy()) and bit_equal(K, Kd.cpu().numpy())

@@ -706,11 +706,11 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     }
   };
 
-  if constexpr (PORTFOLIO) {
-    // The portfolio compares sweep counts across the lanes of a quad: its lanes sweep in lockstep, a sweep = the backward pass and the
-    // whole line search (a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones: 4 tries, otherwise 10).
+  if constexpr (!REFILL) {
+    // The latency regime (mpc_kernel, the portfolio, the closed loop): the lanes of a wave sweep in lockstep, a sweep = the backward pass
+    // and the whole line search (a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones: 4 tries, otherwise 10).
     for (int iter = 0; iter < p.max_iter; ++iter) {
-      if (quad_converged()) done = true;                       // a sibling variant has the answer: every lane of the quad stops
+      if (PORTFOLIO) { if (quad_converged()) done = true; }    // a sibling variant has the answer: every lane of the quad stops
       if (__all(done)) break;
       if (done) continue;
       it = iter;
@@ -733,22 +733,23 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       if (iter == p.max_iter - 1) it = p.max_iter;
     }
   } else {
-    // One lane per agent: the line search is scheduled ASYNCHRONOUSLY across the lanes of the wave (round 5).  A trip of the loop is one
-    // backward pass for the lanes that are due one and ONE candidate rollout for the lanes that have a line search pending; a lane
-    // whose candidate is refused halves alpha and rolls again in the NEXT trip, next to the other lanes' first candidates, instead of
-    // making the whole wave wait through its retries.  Rounds 1-4 ran the line search as an inner loop: the wave executed
-    // max-over-lanes rollouts per sweep — 31 rollouts for the 16 sweeps of the BASELINE batch's slowest wave, against ~1.3 per sweep that a
-    // lane needs — each a pass over the wave's private arrays with a handful of lanes alive (full cache lines for a few lanes' bytes:
-    // in the throughput regime, where that traffic is HBM traffic, the dominant waste — profiles/r05/mpc_traffic_*.json).  Per agent
-    // the same backward passes and the same rollouts with the same step lengths in the same order: bit-identical results.
+    // The throughput regime (mpc_refill_kernel): the line search is scheduled ASYNCHRONOUSLY across the lanes of the wave (round 5).  A
+    // trip of the loop is one backward pass for the lanes that are due one and ONE candidate rollout for the lanes with a line search
+    // pending; a lane whose candidate is refused halves alpha and rolls again in the NEXT trip, next to the other lanes' first
+    // candidates.  A refilled wave always holds some lane in a long line search, so the lockstep loop above makes it run 3-4 rollout
+    // passes per sweep, most of them for a handful of lanes (full cache lines for a few lanes' bytes; that traffic is HBM traffic here).
+    // Measured (profiles/r05/mpc_variants_ab.jsonl, mpc_traffic_*.json): 262,144 agents 7.83 -> 7.29 ms, memory instructions -25 %.  In
+    // the latency regime the same scheduling LOSES (8,192 agents: 0.94 -> 1.17 ms): a retrying lane waits through the other lanes'
+    // backward pass (three times a rollout) before its next candidate, and it is the retrying lanes that set a launch's critical path —
+    // so mpc_kernel keeps the lockstep loop.  Per agent both loops run the same backward passes and the same rollouts with the same step
+    // lengths in the same order: bit-identical results (tests/test_mpc_gpu.py).
     int sweep = 0;                    // backward passes the lane's agent has started (= the sweep index reported in `status`)
     bool fwd = false;                 // a line search is pending: the next candidate uses `alpha`
     double alpha = 1.0, noise = 0.0;
     int ls = 0;
     bool trust = false;
-    if (!REFILL && p.max_iter <= 0) done = true;
     for (;;) {
-      if constexpr (REFILL) {
+      {
         const lanemask_t sweeping = lanes_where(!done);
         const lanemask_t held = lanes_where(done && agent_l >= 0);
         if (held && (!sweeping || __builtin_popcountll(held) >= feed.hold)) {        // hand the finished agents back, all at once
@@ -778,8 +779,6 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
           want &= ~lanes_where(got);
         }
         if (!lanes_where(!done)) break;                          // nobody sweeping: every held agent was handed back above
-      } else {
-        if (__all(done)) break;
       }
       if (!done && !fwd) {
         it = sweep;
@@ -914,9 +913,12 @@ mpc_portfolio_kernel(int n, int T, const float* __restrict__ x0g, const float* _
   if (costg) costg[agent] = J;
 }
 
-// Which of the two reference-trajectory placements the product kernels use (measured: profiles/r05/mpc_variants_ab.jsonl).
-constexpr bool kMpcXrp = false;          // mpc_kernel (the latency regime: the caches are the launch's own)
-constexpr bool kMpcRefillXrp = true;     // mpc_refill_kernel (the throughput regime)
+// Which of the two reference-trajectory placements the product kernels use: global memory, both.  The private copy was built on the
+// suspicion that the 64-lines-per-knot reads are re-fetched from HBM in the throughput regime; measured (profiles/r05/mpc_variants_ab.jsonl,
+// mpc_traffic_262144.json) it moves neither the traffic (153.50 vs 153.50 KB per agent) nor the time (+-1 %, +5 % at 8,192 agents): the
+// lines survive in L2 from knot to knot.  Kept as an A/B variant.
+constexpr bool kMpcXrp = false;          // mpc_kernel
+constexpr bool kMpcRefillXrp = false;    // mpc_refill_kernel
 inline MpcP mpc_pack(const crx_mpc_params& q) {
   MpcP p;
   p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;

@@ -9,11 +9,25 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def demo(tmp_path_factory, crx):
+def _eigen_flags(kind):
+    """How the drop-in header finds its matrix type: "mat" = its own crx::Mat (no Eigen anywhere), "eigen_standin" = the
+    CRX_DROPIN_HAVE_EIGEN branch — `template <int R, int C> using Mat = Eigen::Matrix<float, R, C>` — compiled against the Eigen stand-in
+    of oracle/ref_shim (fixed-size storage: a dense array, like Eigen's), "eigen" = the same branch against the host's real Eigen."""
+    if kind == "mat":
+        return ["-DCRX_DROPIN_NO_EIGEN"]
+    if kind == "eigen_standin":
+        return ["-DCRX_DROPIN_USE_EIGEN", "-I", os.path.join(ROOT, "oracle", "ref_shim")]
+    inc = next((d for d in ("/usr/include/eigen3", "/usr/local/include/eigen3") if os.path.exists(os.path.join(d, "Eigen", "Eigen"))), None)
+    if inc is None:
+        pytest.skip("no Eigen on this host (/usr/include/eigen3, /usr/local/include/eigen3)")
+    return ["-DCRX_DROPIN_USE_EIGEN", "-I", inc]
+
+
+@pytest.fixture(scope="module", params=["mat", "eigen_standin", "eigen"])
+def demo(request, tmp_path_factory, crx):
     exe = str(tmp_path_factory.mktemp("dropin") / "dropin_demo")
     libdir = os.path.join(ROOT, "cpprobotics_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + _eigen_flags(request.param) + ["-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "dropin_demo.cpp"), "-o", exe, "-L", libdir, "-lcrx",
                            f"-Wl,-rpath,{libdir}", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"])
     return exe

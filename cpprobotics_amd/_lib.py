@@ -224,3 +224,24 @@ def host_floats(values, n):
     if a.size != n:
         raise CrxError(f"expected {n} floats, got {a.size}")
     return a
+
+
+# Which sources decide the code of a kernel family: the committed hardware counters (profiles/traffic.json, profiles/side_counters.json —
+# rocprofv3 PMC passes cannot run inside bench.py) carry the hash of these files at the time they were taken; bench.py prints them only
+# when the hash of the tree it runs from is the same (scripts/summarize_prof.py writes it, bench.py checks it).
+KERNEL_SOURCES = {
+    "ekf": ("ekf_kernels.hip.h", "ekf_math.h", "crx_trig.h", "crx_dsincos.h", "crx_fdlibm.h", "api_ekf.inl", "api_internal.inl", "crx_api.hip", "Makefile"),
+    "side": ("dare_kernels.hip.h", "dare_math.h", "dare_dense_math.h", "mpc_kernels.hip.h", "ekf_kernels.hip.h", "ekf_math.h", "crx_trig.h", "api_lqr.inl",
+             "api_mpc.inl", "api_internal.inl", "crx_api.hip", "Makefile"),
+}
+
+
+def kernel_source_hash(family):
+    """sha256 (16 hex digits) over the csrc files that decide the code of a kernel family ("ekf": the fused EKF launch; "side": the
+    DARE / MPC / single-step kernels of scripts/prof_kernels.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[family]:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]

@@ -128,8 +128,7 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
     FastDomain dom = fast_domain_init();
     ekf_step_packed(sp, zv, uv, pack_consts(k), dom);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_domain_ok(dom)) != 0, 0)) {
-      load_state(s, x, P, a);
-      ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);
+      ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);          // `s` still holds the input: the packed step worked on its copy `sp`
     } else {
       unpack_state(s, sp);
     }

@@ -7,6 +7,8 @@ import os
 import sys
 
 out = sys.argv[1]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cpprobotics_amd._lib import kernel_source_hash   # the counters are bound to the kernel sources they were taken from (bench.py checks)
 
 
 def rows(pattern):
@@ -27,6 +29,13 @@ def stats(sub, keep):
         for r in res:
             w.writerow(r)
     return res
+
+
+def per_dispatch(sub, kernel, name):
+    """the counter's value for every dispatch of the kernel, in dispatch order"""
+    vals = [(int(r["Dispatch_Id"]), float(r["Counter_Value"])) for r in rows(sub + "/**/*counter_collection.csv")
+            if kernel in r.get("Kernel_Name", "") and r["Counter_Name"] == name]
+    return [v for _, v in sorted(vals)]
 
 
 def counters(sub, kernel):
@@ -50,7 +59,7 @@ if fetch and write and sq:
     wb = write["WRITE_SIZE"] * 1024
     tj = {"vehicles": 65536, "T": 1000, "kernel": "crx::ekf_run_kernel<4,true,false,true>",
           "FETCH_SIZE_KB": fetch["FETCH_SIZE"], "WRITE_SIZE_KB": write["WRITE_SIZE"], "fetch_bytes_corrected": fb, "write_bytes": wb,
-          "hbm_bytes_per_launch": fb + wb,
+          "hbm_bytes_per_launch": fb + wb, "kernel_source_hash": kernel_source_hash("ekf"),
           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_prof.sh); FETCH_SIZE doubled per the gfx950 "
                   "half-count of coalesced streaming reads (MI355X_MICROARCH.md, HBM section)",
           "sq_counters_per_launch": dict(sq, unit="SQ_*_CYCLES / ACTIVE / WAIT in units of 4 shader cycles"),
@@ -81,6 +90,12 @@ for key, kern, nveh in (("ekf_step_4M_streaming_rows", "ekf_step_kernel<true>", 
                      "algorithmic_bytes_per_launch": 176.0 * nveh, "traffic_over_algorithmic": (fb + wb) / (176.0 * nveh),
                      "read_over_algorithmic_read": fb / (96.0 * nveh), "write_over_algorithmic_write": wb / (80.0 * nveh),
                      "sq_counters_per_launch": c}
+        # launch by launch: the harness starts from the reference's initial state (xEst = 0: yaw = +0 is outside the packed step's
+        # domain), so the FIRST launch takes the general step in every wave; until round 5 that path re-read the covariance rows
+        fl = per_dispatch("side_fetch", kern, "FETCH_SIZE")
+        if len(fl) >= 2:
+            side[key]["read_over_algorithmic_read_first_launch"] = fl[0] * 2048 / (96.0 * nveh)
+            side[key]["read_over_algorithmic_read_later_launches"] = sum(fl[1:]) / len(fl[1:]) * 2048 / (96.0 * nveh)
         print(key, side[key])
 # the dense kernels in prof_kernels.py — forced on the reference's matrices (SKIP_STRUCTURED = false; the quad layout a batch of 16,384
 # gets, and the one-lane layout beside it) and behind the product entry point on general matrices (SKIP_STRUCTURED = true): told apart
@@ -108,6 +123,7 @@ for key, kern in (("dare5", "dare_from_v_kernel<5, crx::DareFromV"), ("dare5_qua
         e["fp64_flop_per_lane_iteration"] = f64 / it["wave_max_iters_sum"]      # wave-level instruction counts: one lane's flops per sweep
         e["fp32_flop_per_lane_iteration"] = f32 / it["wave_max_iters_sum"]
     side[key] = e
+side["kernel_source_hash"] = kernel_source_hash("side")
 side["note"] = ("rocprofv3 --pmc passes of scripts/prof_kernels.py (scripts/gpu_prof.sh); SQ_INSTS_VALU_* count wave-level instructions, "
                 "so (2 FMA + MUL + ADD) / sum over waves of the wave's sweep count = flops one lane executes per sweep")
 json.dump(side, open(os.path.join(out, "side_counters.json"), "w"), indent=1)

@@ -19,16 +19,15 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-    configs = [("product", d) for d in ((1, 4) if quick else (1, 2, 3, 4, 6, 8))]
+    configs = [("product", d) for d in ((1, 4) if quick else (1, 2, 3, 4, 5, 6, 8))]
     if not quick:
-        configs += [("variant:1", 4), ("variant:2", 4), ("variant:2", 8), ("variant:3", 4), ("variant:3", 8),
-                    ("refill:128", 4), ("refill:256", 4), ("refill:256", 8), ("refill:512", 8), ("refill:512", 12),
-                    ("variant:1:256", 4), ("variant:1:256", 8), ("portfolio", 4)]
+        configs += [("variant:1", 4), ("variant:2", 4), ("refill:128", 3), ("refill:128", 4), ("refill:128", 6), ("refill:256", 4), ("refill:256", 8),
+                    ("portfolio", 4)]
     for spec, depth in configs:
         fn, label = mpc_launcher(spec)
         try:
-            out = bench.measure_swarm_configs4(dev, 0, 1, rounds=30, warmup=8, depth=depth, mpc_fn=fn, mpc_label=label)
-            line = {"mpc": spec, "depth": depth, "round_ms": out["round_ms"], "ekf_ms_per_round": out["roofline"]["kernel_ms_per_round"],
+            out = bench.measure_swarm_configs4(dev, 0, 1, rounds=100, warmup=20, depth=depth, mpc_fn=fn, mpc_label=label, blocks=3)
+            line = {"mpc": spec, "depth": depth, "round_ms": out["round_ms"], "round_ms_of_every_block": out["round_ms_of_every_block"], "ekf_ms_per_round": out["roofline"]["kernel_ms_per_round"],
                     "ekf_frac_of_8TBps": out["roofline"]["frac"], "ekf_updates_per_s": out["ekf_updates_per_s"],
                     "mpc_solves_per_s": out["mpc_solves_per_s"], "mpc_sweeps": out["mpc_sweeps"], "label": label}
         except Exception as e:

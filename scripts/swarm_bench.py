@@ -42,8 +42,8 @@ def main():
     ap.add_argument("--agents", type=int, default=131072, help="agents per GPU (1,048,576 / 8)")
     ap.add_argument("--T", type=int, default=100, help="EKF steps per round")
     ap.add_argument("--gpus", type=int, default=None, help="must equal WORLD_SIZE when given (bench.py's contract)")
-    ap.add_argument("--steps", "--rounds", dest="steps", type=int, default=20, help="timed rounds")
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", "--rounds", dest="steps", type=int, default=60, help="timed rounds per block (three blocks, the median is reported)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
     ap.add_argument("--chunks", type=int, default=4, help="EKF launches per round where the trajectory gather overlaps them (N > 1)")
     ap.add_argument("--depth", type=int, default=4, help="planner launches in flight")

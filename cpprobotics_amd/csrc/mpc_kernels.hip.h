@@ -245,12 +245,13 @@ struct MpcFeed {
   const float* __restrict__ x0g; const float* __restrict__ xrefg;
   float* __restrict__ solg; int* __restrict__ statusg; double* __restrict__ costg;
 };
-// XRP: the lane's reference trajectory is copied into private memory at the start of its solve and read from there.  A lane's 16 B x T
-// reference is contiguous in global memory (336 B at T = 21), i.e. a wave's read of knot i touches 64 different cache lines for 1 KiB of
-// payload; while a launch leaves the caches to itself the lines survive from knot to knot, in the throughput regime (every SIMD busy,
-// the waves' private arrays streaming through L2) they do not.  In private memory the hardware interleaves the lanes: 16 B per lane per
-// knot is what moves.  Same values, same arithmetic: bit-identical per agent.
-template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool XRP = false>
+// LEAN: the trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is NOT kept for the backward sweep, which
+// recomputes it from the stored knots and controls — the same functions of the same doubles, i.e. the same bits (mpc_sincos / mpc_tan
+// are written with explicit fma() and single multiplications: no contraction can differ between the two places).  Trades ~70 VALU
+// instructions per backward stage for 24 B written per rollout stage and 24 B read per backward stage: 11 % of the solver's memory
+// traffic.  Pays where that traffic is HBM traffic (the throughput regime: mpc_refill_kernel, and mpc_kernel launches a caller
+// declares pipelined — crx_mpc_params.schedule); costs ~6 % where the launch is a latency chain (mpc_kernel by default).
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
                                                const MpcFeed feed = MpcFeed{}) {
@@ -268,12 +269,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
   double U[2][MAXT][2];   // stages: delta, a
   double kf[MAXT][2];     // feed-forward
-  double Kf[MAXT][12];    // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev)
-  double TR[2][MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them
-  float4 XR[XRP ? MAXT : 1];   // XRP: the reference trajectory, private copy
-  auto xr_at = [&](int i) -> float4 { if constexpr (XRP) return XR[i]; else return xr4[i]; };
-  auto xr_fetch = [&]() { if constexpr (XRP) { for (int i = 0; i < T; ++i) XR[i] = xr4[i]; } };
-  if (!REFILL) xr_fetch();
+  // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev) — kept in FLOAT (round 5): the gains only steer the candidate rollouts
+  // (u + alpha k + K dx), the fixed point is decided by the feed-forward k (double) alone, and they are 41 % of the solver's memory
+  // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
+  // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
+  float Kf[MAXT][12];
+  double TR[LEAN ? 1 : 2][LEAN ? 1 : MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them (LEAN: recomputes them)
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
@@ -284,7 +285,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
   // rolls controls U[c] from x0 and returns fg[0]
   auto track = [&](const double* s, int i) -> double {
-    const float4 r = xr_at(i);
+    const float4 r = xr4[i];
     const double e0 = (double)r.x - s[0], e1 = (double)r.y - s[1], e2 = (double)r.z - s[2], e3 = (double)r.w - s[3];
     return p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
   };
@@ -301,7 +302,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
     const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
-    tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
+    if constexpr (!LEAN) { tr[0] = sn_; tr[1] = cs_; tr[2] = tn_; }
     sn[0] = s[0] + s[3] * cs_ * dt;
     sn[1] = s[1] + s[3] * sn_ * dt;
     sn[2] = s[2] + s[3] * tn_ * dt_wb;
@@ -310,7 +311,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 
   struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
   auto load_stage = [&](int c, int i) -> StageIn {
-    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr_at(i)};
+    if constexpr (LEAN) return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
+    else return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
   };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
@@ -320,12 +322,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     for (int a = 0; a < 4; ++a) q.s[a] = S[c][i][a];
     q.u0 = U[c][i][0]; q.u1 = U[c][i][1]; q.k0 = kf[i][0]; q.k1 = kf[i][1];
 #pragma unroll
-    for (int a = 0; a < 12; ++a) q.K[a] = Kf[i][a];
-    q.r = xr_at(i);
+    for (int a = 0; a < 12; ++a) q.K[a] = (double)Kf[i][a];
+    q.r = xr4[i];
     return q;
   };
 
-  float4 rN = REFILL ? float4{0.f, 0.f, 0.f, 0.f} : xr_at(N);   // terminal reference: used by every sweep and every rollout
+  float4 rN = REFILL ? float4{0.f, 0.f, 0.f, 0.f} : xr4[N];   // terminal reference: used by every sweep and every rollout
 
   int cur = 0;
   double J = 0.0;
@@ -349,7 +351,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       U[0][i][0] = 0.0; U[0][i][1] = a0;
       J += ctrl(0, i);
       if (i >= 1) J += track(S[0][i], i);
-      step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
+      step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
     }
     J += track(S[0][N], N);
     mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
@@ -432,9 +434,13 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       uc0 = up0; uc1 = up1;
       { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
-      const double sn_ = in.sn, cs_ = in.cs;
+      double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
+      if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
+        mpc_sincos(s[2], &sn_, &cs_);
+        tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
+      }
       const double v = s[3];
-      const double tn = in.tn, sec2 = 1.0 + tn * tn;
+      const double sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
       const double bd = v * sec2 * dt_wb;
       // stage cost derivatives
@@ -577,7 +583,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       }
       kf[i][0] = k0; kf[i][1] = k1;
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = K[0][b]; Kf[i][2 * b + 1] = K[1][b]; }
+      for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = (float)K[0][b]; Kf[i][2 * b + 1] = (float)K[1][b]; }
       gnorm = fmax(gnorm, fmax(fabs(k0), fabs(k1)));
       // expected change and value function (unregularised, symmetrised Quu)
       const double Quuk0 = Quu00 * k0 + hod * k1, Quuk1 = hod * k0 + Quu11 * k1;
@@ -675,7 +681,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
         Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
       }
       double xn[4];
-      step(xs, nd, na, xn, TR[nxt][i]);
+      step(xs, nd, na, xn, LEAN ? TR[0][0] : TR[nxt][i]);
       S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
       xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
       pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
@@ -770,8 +776,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
             agent_l = mine;
             xi = reinterpret_cast<const float4*>(feed.x0g)[mine];
             xr4 = reinterpret_cast<const float4*>(feed.xrefg) + (size_t)mine * (size_t)T;
-            xr_fetch();
-            rN = xr_at(N);
+              rN = xr4[N];
             start();
             sweep = 0; fwd = false;
             done = false;
@@ -844,9 +849,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 // 8 agents per wave take 1.18 / 1.41 / 1.95 ms against 1.08, and so do two or four waves per workgroup (1.18 / 1.42 ms at
 // full waves): every wave streams its lanes' 5.4 KB of private memory through L2 each sweep whether the lanes are used or
 // not, and waves that share a CU share its path to it.
-template <int MAXT, bool XRP>
-__device__ __forceinline__ void mpc_kernel_body(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, const MpcP& p,
-                                                float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+template <int MAXT, bool LEAN = false>
+__global__ void __launch_bounds__(256)   // 1-4 waves per workgroup, one wave per SIMD: the register budget of a lone wave
+mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+           float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
   const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   const size_t agent = wave * (size_t)live_lanes + lane;
@@ -856,42 +862,25 @@ __device__ __forceinline__ void mpc_kernel_body(int n, int T, int live_lanes, co
   const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
   const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, false, XRP>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  mpc_solve_lane<MAXT, false, false, LEAN>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
 }
-template <int MAXT, bool XRP = false>
-__global__ void __launch_bounds__(256)   // 1-4 waves per workgroup, one wave per SIMD: the register budget of a lone wave
-mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
-           float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
-  mpc_kernel_body<MAXT, XRP>(n, T, live_lanes, x0g, xrefg, p, solg, statusg, costg);
-}
-#if CRX_EXPERIMENTAL_KERNELS
-// A/B: the same solve under a 256-register budget (VGPRs + AGPRs), so that two waves fit a SIMD and fill each other's issue gaps
-// (a lone wave issues this fp64 mix every ~6.6 cycles) — at the price of spills into the private memory that is
-// already the kernel's traffic.
-template <int MAXT, bool XRP = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-mpc_w2_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
-              float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
-  mpc_kernel_body<MAXT, XRP>(n, T, live_lanes, x0g, xrefg, p, solg, statusg, costg);
-}
-#endif
 
 // The throughput-regime launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>):
 // a wave of mpc_kernel lasts as long as the slowest of its 64 agents (mean of the wave maximum ~12 sweeps against a mean of 6.8), here a
 // finished lane takes the wave's next agent.  Per agent the same sweeps in the same order: bit-identical to mpc_kernel.  Round 4
 // measured it (profiles/r04/mpc_refill_ab.jsonl: 1.14x at 65,536 agents, 1.16x at 262,144, 0.99x at 1 M) and kept it in the A/B build;
-// round 5 ships it for the batches where it wins (api_internal.inl: mpc_refill_chunk) — the planners of a swarm shard are such a batch.
-template <int MAXT, bool XRP = false>
+// round 5 ships it — with the asynchronous line search (mpc_solve_lane) — for the batches where it wins (api_internal.inl: mpc_refill_chunk).
+template <int MAXT, bool LEAN = true>
 __global__ void __launch_bounds__(64)
 mpc_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
                   float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
   const int lo = (int)blockIdx.x * chunk;
   const MpcFeed feed{lo, (n - lo < chunk) ? n : lo + chunk, hold, x0g, xrefg, solg, statusg, costg};
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, true, XRP>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
+  mpc_solve_lane<MAXT, false, true, LEAN>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
 }
 
 // The portfolio launch: agent a on lanes 4a .. 4a+3 (16 agents per wave, single-wave workgroups): 4x the waves of mpc_kernel — at the
@@ -913,12 +902,6 @@ mpc_portfolio_kernel(int n, int T, const float* __restrict__ x0g, const float* _
   if (costg) costg[agent] = J;
 }
 
-// Which of the two reference-trajectory placements the product kernels use: global memory, both.  The private copy was built on the
-// suspicion that the 64-lines-per-knot reads are re-fetched from HBM in the throughput regime; measured (profiles/r05/mpc_variants_ab.jsonl,
-// mpc_traffic_262144.json) it moves neither the traffic (153.50 vs 153.50 KB per agent) nor the time (+-1 %, +5 % at 8,192 agents): the
-// lines survive in L2 from knot to knot.  Kept as an A/B variant.
-constexpr bool kMpcXrp = false;          // mpc_kernel
-constexpr bool kMpcRefillXrp = false;    // mpc_refill_kernel
 inline MpcP mpc_pack(const crx_mpc_params& q) {
   MpcP p;
   p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
@@ -942,54 +925,42 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
 }
 
 // lanes refilled: `chunk` agents per wave, hand-back in batches of `hold` lanes (max_iter >= 1)
-template <bool XRP>
+template <bool LEAN>
 inline hipError_t mpc_refill_launch_t(int n, int T, const float* x0, const float* xref, const MpcP& p, float* sol,
                                       int* status, double* cost, hipStream_t stream, int chunk, int hold) {
   const dim3 grid((unsigned)(((size_t)n + chunk - 1) / chunk)), block(64);
   if (T <= 8)
-    hipLaunchKernelGGL((mpc_refill_kernel<8, XRP>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<8, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   else if (T <= 24)
-    hipLaunchKernelGGL((mpc_refill_kernel<24, XRP>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<24, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   else
-    hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T, XRP>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                                    int* status, double* cost, hipStream_t stream, int chunk, int hold, bool other_xrp = false) {
+                                    int* status, double* cost, hipStream_t stream, int chunk, int hold, bool lean = true) {
   const MpcP p = mpc_pack(q);
-#if CRX_EXPERIMENTAL_KERNELS
-  if (other_xrp) return mpc_refill_launch_t<!kMpcRefillXrp>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold);
-#endif
-  return mpc_refill_launch_t<kMpcRefillXrp>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold);
+  return lean ? mpc_refill_launch_t<true>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold)
+              : mpc_refill_launch_t<false>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold);
 }
 
-// variant: 0 = the product's kernel; A/B build only: bit 0 = the other reference-trajectory placement, bit 1 = the 256-register build
-// with two waves per SIMD (mpc_w2_kernel)
+// lean: the traffic-lean build of the solve (mpc_solve_lane's LEAN) — bit-identical, picked where the launch shares the GPU with others
 template <int MAXT>
-inline void mpc_launch_mt(int variant, dim3 grid, dim3 block, hipStream_t stream, int n, int T, int live, const float* x0, const float* xref,
+inline void mpc_launch_mt(bool lean, dim3 grid, dim3 block, hipStream_t stream, int n, int T, int live, const float* x0, const float* xref,
                           const MpcP& p, float* sol, int* status, double* cost) {
-#if CRX_EXPERIMENTAL_KERNELS
-  const bool xrp = (variant & 1) ? !kMpcXrp : kMpcXrp;
-  if (variant & 2) {
-    if (xrp) hipLaunchKernelGGL((mpc_w2_kernel<MAXT, true>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-    else hipLaunchKernelGGL((mpc_w2_kernel<MAXT, false>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-    return;
-  }
-  if (variant & 1) { hipLaunchKernelGGL((mpc_kernel<MAXT, !kMpcXrp>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost); return; }
-#endif
-  hipLaunchKernelGGL((mpc_kernel<MAXT, kMpcXrp>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  if (lean) hipLaunchKernelGGL((mpc_kernel<MAXT, true>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else hipLaunchKernelGGL((mpc_kernel<MAXT, false>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
 }
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1, int variant = 0) {
+                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1, bool lean = false) {
   const MpcP p = mpc_pack(q);
   if (live < 1 || live > 64) live = 64;
   if (wg_waves < 1 || wg_waves > 4) wg_waves = 1;
-  if (variant & 2) wg_waves = 1;
   const size_t waves = ((size_t)n + live - 1) / live;
   const dim3 grid((unsigned)((waves + wg_waves - 1) / wg_waves)), block(64 * wg_waves);
-  if (T <= 8) mpc_launch_mt<8>(variant, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else if (T <= 24) mpc_launch_mt<24>(variant, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else mpc_launch_mt<CRX_MPC_MAX_T>(variant, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
+  if (T <= 8) mpc_launch_mt<8>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else if (T <= 24) mpc_launch_mt<24>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else mpc_launch_mt<CRX_MPC_MAX_T>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 

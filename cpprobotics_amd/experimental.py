@@ -151,10 +151,9 @@ def mpc_solve_lanes(x0, xref, T, lanes_per_agent=0, params=None):
     return sol, status, cost
 
 
-def mpc_solve_variant(x0, xref, T, variant=0, agents_per_wave=0, hold_lanes=16, params=None, out=None):
-    """mpc_solve through an A/B variant of the one-lane-per-agent solve (libcrx_x.so): variant bit 0 = the reference trajectory in
-    the placement the product does not use, bit 1 = the 256-register build (two waves per SIMD); agents_per_wave = 0: mpc_kernel,
-    otherwise the lane-refilling kernel with that many agents per wave.  -> sol, status, cost (out = the caller's tensors)."""
+def mpc_solve_variant(x0, xref, T, lean=0, agents_per_wave=0, hold_lanes=16, params=None, out=None):
+    """mpc_solve with the kernel forced: lean = 0 / 1 (the traffic-lean build), agents_per_wave = 0: mpc_kernel, otherwise the
+    lane-refilling kernel with that many agents per wave.  All bit-identical per agent.  -> sol, status, cost (out = the caller's)."""
     import torch
     from .mpc import default_params, mpc_n_vars
     L.require_cuda(x0, xref)
@@ -165,9 +164,8 @@ def mpc_solve_variant(x0, xref, T, variant=0, agents_per_wave=0, hold_lanes=16, 
         out = (torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device), torch.empty((n,), dtype=torch.int32, device=x0.device),
                torch.empty((n,), dtype=torch.float64, device=x0.device))
     sol, status, cost = out
-    _check_ab(ablib().crx_x_mpc_solve_variant_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
-                                                  L.stream_ptr(), int(variant), int(agents_per_wave), int(hold_lanes)),
-              "crx_x_mpc_solve_variant_dev (libcrx_x.so)")
+    L.check(xlib().crx_x_mpc_solve_variant_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                               L.stream_ptr(), int(lean), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_variant_dev")
     return sol, status, cost
 
 

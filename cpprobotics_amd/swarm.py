@@ -275,7 +275,12 @@ class SwarmShard:
         self.n_total, self.n_plan, self.every = n * world, (n + plan_every - 1) // plan_every, plan_every
         self.q, self.r = _qr(Q, R)
         self.dc = crx.Course.from_numpy(course, device=device)
-        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, out=out))
+        # the round keeps `depth` planner launches in flight: it tells the engine so (crx_mpc_params.schedule), which picks the traffic-lean
+        # kernel for them — same bits, less HBM traffic where the launches share the memory system
+        from ._lib import MPC_SCHEDULE_THROUGHPUT
+        self.mpc_params = crx.mpc.default_params()
+        self.mpc_params.schedule = MPC_SCHEDULE_THROUGHPUT
+        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, params=self.mpc_params, out=out))
         ci = np.random.default_rng(seed).integers(0, len(course[0]) - 30, self.n_total)[rank * n:(rank + 1) * n]
         self.start_index = ci
         cit = torch.from_numpy(ci).to(device)

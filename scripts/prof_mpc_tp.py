@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel with the reference trajectory in
-global / private memory, the 256-register build and the lane-refilling kernel, N agents (default 262,144), T = 21, `reps` launches each."""
+"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel and the lane-refilling kernel, each in
+the default and the traffic-lean build, N agents (default 262,144), T = 21, `reps` launches each."""
 import os
 import sys
 
@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 x0, xref = mpc_problem(n, 21, 4)
 x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
-for bits, apw in ((0, 0), (1, 0), (2, 0), (0, 512), (1, 512)):
+for bits, apw in ((0, 0), (1, 0), (0, 512), (1, 512)):        # (lean, agents per wave)
     for _ in range(reps):
         X.mpc_solve_variant(x0, xref, 21, bits, apw)
     torch.cuda.synchronize()

@@ -6,8 +6,9 @@ bench.py prints as `extra.swarm_configs4` (N = 1) / `multi_gpu.swarm_configs4` (
   python scripts/swarm_bench.py --agents 131072 --depth 4          # one GPU, one shard of the 1,048,576-agent swarm
 
 The round itself is cpprobotics_amd/swarm.py: SwarmShard / MixedSwarmRound (its docstring describes the streams and the slot ring), the
-measurement bench.py: measure_swarm_configs4.  --mpc selects the planner launch for A/Bs: `product` (crx_mpc_solve_batch_dev),
-`portfolio`, `refill:<agents per wave>[:<hold>]`, `variant:<bits>[:<agents per wave>]` (libcrx_x.so, see include/crx_experimental.h).
+measurement bench.py: measure_swarm_configs4.  --mpc selects the planner launch for A/Bs: `product` (crx_mpc_solve_batch_dev with
+params.schedule = THROUGHPUT: what SwarmShard issues), `auto` / `latency` (the other two schedules), `portfolio`,
+`kernel:<lean 0|1>[:<agents per wave>[:<hold>]]` (the kernel forced, include/crx_experimental.h).
 Prints one JSON line on rank 0."""
 import argparse
 import json
@@ -24,17 +25,19 @@ def mpc_launcher(spec):
     import cpprobotics_amd as crx
     kind, *rest = spec.split(":")
     if kind == "product":
-        return None, "crx_mpc_solve_batch_dev"
+        return None, "crx_mpc_solve_batch_dev, schedule = THROUGHPUT"
+    if kind in ("auto", "latency"):
+        from cpprobotics_amd import _lib as L
+        p = crx.mpc.default_params(); p.schedule = L.MPC_SCHEDULE_AUTO if kind == "auto" else L.MPC_SCHEDULE_LATENCY
+        return (lambda est, xref, Tm, out: crx.mpc_solve(est, xref, Tm, params=p, out=out)), f"crx_mpc_solve_batch_dev, schedule = {kind.upper()}"
     if kind == "portfolio":
         return (lambda est, xref, Tm, out: crx.mpc_solve(est, xref, Tm, portfolio=True, out=out)), "crx_mpc_solve_portfolio_batch_dev"
     from cpprobotics_amd import experimental as X
-    if kind == "refill":
-        apw, hold = int(rest[0]), int(rest[1]) if len(rest) > 1 else 16
-        return (lambda est, xref, Tm, out: X.mpc_solve_variant(est, xref, Tm, 0, apw, hold, out=out)), f"mpc_refill_kernel, {apw} agents per wave, hold {hold}"
-    if kind == "variant":
-        bits, apw = int(rest[0]), int(rest[1]) if len(rest) > 1 else 0
-        return (lambda est, xref, Tm, out: X.mpc_solve_variant(est, xref, Tm, bits, apw, 16, out=out)), f"crx_x_mpc_solve_variant_dev(variant={bits}, agents_per_wave={apw})"
-    raise SystemExit(f"--mpc {spec}: product | portfolio | refill:<apw>[:<hold>] | variant:<bits>[:<apw>]")
+    if kind == "kernel":
+        lean, apw, hold = int(rest[0]), int(rest[1]) if len(rest) > 1 else 0, int(rest[2]) if len(rest) > 2 else 16
+        name = f"mpc_refill_kernel, {apw} agents per wave, hold {hold}" if apw else "mpc_kernel"
+        return (lambda est, xref, Tm, out: X.mpc_solve_variant(est, xref, Tm, lean, apw, hold, out=out)), name + (", traffic-lean build" if lean else "")
+    raise SystemExit(f"--mpc {spec}: product | auto | latency | portfolio | kernel:<lean>[:<apw>[:<hold>]]")
 
 
 def main():

@@ -262,16 +262,25 @@ def test_mpc_product_dispatch_is_bit_identical_across_the_refill_threshold(crx):
 
 
 @pytest.mark.parametrize("T", [6, 21, 30])
-def test_mpc_ab_variants_are_bit_identical(crx, T):
-    """The A/B variants of round 5 (libcrx_x.so: the reference trajectory in private memory / in global memory, the 256-register build
-    with two waves per SIMD, with and without lane refilling) run the same arithmetic per agent: identical bits."""
+def test_mpc_kernel_builds_are_bit_identical(crx, T):
+    """The four one-lane-per-agent kernels a product call can get — mpc_kernel and mpc_refill_kernel, each in the default and in the
+    traffic-lean build (the backward sweep recomputes the rollout's trig) — and the three settings of crx_mpc_params.schedule run the same
+    arithmetic per agent: identical bits.  An agent's answer depends on its problem, never on how the launch is scheduled."""
     import torch
+    from cpprobotics_amd import _lib as L
     from cpprobotics_amd.experimental import mpc_solve_variant
+    from cpprobotics_amd.mpc import default_params
     n = 3001
     x0, xref = mpc_problem(n, T, 90 + T)
     x0, xref = _t(x0), _t(xref)
     sol0, st0, c0 = crx.mpc_solve(x0, xref, T, return_status=True)
-    for variant, apw in ((0, 0), (1, 0), (2, 0), (3, 0), (0, 128), (1, 128)):
-        sol, st, c = mpc_solve_variant(x0, xref, T, variant, apw)
-        assert torch.equal(st, st0), (variant, apw)
-        assert torch.equal(sol.view(torch.int32), sol0.view(torch.int32)) and torch.equal(c.view(torch.int64), c0.view(torch.int64)), (variant, apw)
+    outs = [mpc_solve_variant(x0, xref, T, lean, apw) for lean, apw in ((0, 0), (1, 0), (0, 128), (1, 128), (1, 3001))]
+    for sched in (L.MPC_SCHEDULE_LATENCY, L.MPC_SCHEDULE_THROUGHPUT):
+        p = default_params(); p.schedule = sched
+        outs.append(crx.mpc_solve(x0, xref, T, return_status=True, params=p))
+    for k, (sol, st, c) in enumerate(outs):
+        assert torch.equal(st, st0), k
+        assert torch.equal(sol.view(torch.int32), sol0.view(torch.int32)) and torch.equal(c.view(torch.int64), c0.view(torch.int64)), k
+    p = default_params(); p.schedule = 7
+    with pytest.raises(crx.CrxError):
+        crx.mpc_solve(x0, xref, T, params=p)

@@ -69,7 +69,9 @@ inline int dare_refill_chunk(int n) {
 // ~3/4 M agents on the plain kernel's 16 waves per SIMD queue hide what refilling recovers, and its footprint per resident wave is smaller)
 constexpr int kMpcRefillMinAgents = 65536, kMpcRefillMaxAgents = 786432;
 constexpr int kMpcRefillHold = 16;
-inline int mpc_refill_chunk(int n) {
+// throughput: the caller keeps several launches in flight (crx_mpc_params.schedule) — a small batch is then not a latency chain either
+inline int mpc_refill_chunk(int n, bool throughput = false) {
+  (void)throughput;                         // measured (profiles/r05/swarm_pipeline_ab.jsonl): below the window the lockstep kernel stays ahead also when pipelined
   if (n < kMpcRefillMinAgents || n >= kMpcRefillMaxAgents) return 0;
   return n < 262144 ? 256 : 512;
 }

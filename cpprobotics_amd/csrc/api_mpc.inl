@@ -8,7 +8,7 @@ extern "C" {
 // agents_per_wave (1..64) and waves_per_workgroup (1..4): the launch geometry; the product entry point uses full waves in
 // single-wave workgroups (every emptier or stacked geometry measured slower: profiles/r02/mpc_tail.txt).
 static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
-                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup, bool lean = false) {
+                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
   if (agents_per_wave < 1 || agents_per_wave > 64 || waves_per_workgroup < 1 || waves_per_workgroup > 4)
@@ -17,12 +17,12 @@ static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup, lean);
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
 // The lane-refilling launch (mpc_refill_kernel: a wave owns `agents_per_wave` consecutive agents; bit-identical to mpc_kernel per agent).
 static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                            double* cost, void* stream, int agents_per_wave, int hold_lanes, bool lean = true) {
+                            double* cost, void* stream, int agents_per_wave, int hold_lanes) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve (refill): bad argument (2 <= T <= 64)");
   if (agents_per_wave < 64 || agents_per_wave > (1 << 20) || hold_lanes < 1 || hold_lanes > 64)
@@ -32,7 +32,7 @@ static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, co
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
   if (p.max_iter < 1) return fail(CRX_ERR_INVALID, "mpc_solve (refill): max_iter must be at least 1");
-  const hipError_t e = crx::mpc_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes, lean);
+  const hipError_t e = crx::mpc_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc refill launch");
 }
 // lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
@@ -44,10 +44,9 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   if (lanes_per_agent == 0) {                        // the product's choice; the quad variant lost its A/B at every batch size (profiles/r03/mpc_lanes_ab.txt)
     const int sched = prm ? prm->schedule : CRX_MPC_SCHEDULE_AUTO;
     if (sched < CRX_MPC_SCHEDULE_AUTO || sched > CRX_MPC_SCHEDULE_THROUGHPUT) return fail(CRX_ERR_INVALID, "mpc_solve: params.schedule must be CRX_MPC_SCHEDULE_AUTO, _LATENCY or _THROUGHPUT");
-    const int chunk = sched == CRX_MPC_SCHEDULE_LATENCY ? 0 : mpc_refill_chunk(n);
+    const int chunk = sched == CRX_MPC_SCHEDULE_LATENCY ? 0 : mpc_refill_chunk(n, sched == CRX_MPC_SCHEDULE_THROUGHPUT);
     if (chunk && (!prm || prm->max_iter >= 1)) return mpc_solve_refill(n, T, x0, xref, prm, sol, status, cost, stream, chunk, kMpcRefillHold);
-    // a batch below the refilling window that the caller pipelines: the lockstep kernel in its traffic-lean build
-    return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1, sched == CRX_MPC_SCHEDULE_THROUGHPUT);
+    lanes_per_agent = 1;
   }
   if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 #if !CRX_EXPERIMENTAL_KERNELS
@@ -91,16 +90,6 @@ int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref,
                                double* cost, void* stream, int agents_per_wave, int hold_lanes) {
   CRX_TRACE();
   return mpc_solve_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes);
-}
-// The two builds of the one-lane-per-agent solve with the kernel forced (A/B and parity tests): lean = 0 / 1 (mpc_solve_lane's LEAN: the
-// backward sweep recomputes the rollout's trig instead of reading it back); agents_per_wave = 0: mpc_kernel, otherwise the
-// lane-refilling kernel with that many agents per wave.  Bit-identical per agent, all four.
-int crx_x_mpc_solve_variant_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                                double* cost, void* stream, int lean, int agents_per_wave, int hold_lanes) {
-  CRX_TRACE();
-  if (lean < 0 || lean > 1) return fail(CRX_ERR_INVALID, "mpc_solve (variant): lean 0 or 1");
-  if (agents_per_wave) return mpc_solve_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes, lean != 0);
-  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1, lean != 0);
 }
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {

@@ -245,13 +245,16 @@ struct MpcFeed {
   const float* __restrict__ x0g; const float* __restrict__ xrefg;
   float* __restrict__ solg; int* __restrict__ statusg; double* __restrict__ costg;
 };
-// LEAN: the trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is NOT kept for the backward sweep, which
+// The trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is NOT kept for the backward sweep, which
 // recomputes it from the stored knots and controls — the same functions of the same doubles, i.e. the same bits (mpc_sincos / mpc_tan
-// are written with explicit fma() and single multiplications: no contraction can differ between the two places).  Trades ~70 VALU
-// instructions per backward stage for 24 B written per rollout stage and 24 B read per backward stage: 11 % of the solver's memory
-// traffic.  Pays where that traffic is HBM traffic (the throughput regime: mpc_refill_kernel, and mpc_kernel launches a caller
-// declares pipelined — crx_mpc_params.schedule); costs ~6 % where the launch is a latency chain (mpc_kernel by default).
-template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false>
+// are written with explicit fma() and single multiplications).  Rounds 1-4 stored it (TR[2][MAXT][3]): 24 B written per rollout stage and
+// 24 B read per backward stage, 11 % of the solver's memory traffic, against ~70 VALU instructions per backward stage now.  Where the
+// solver's traffic is HBM traffic (>= 65,536 agents in a launch, or several launches in flight: the mixed swarm round) that is 9-17 % of
+// the time (1 M agents: 21.4 -> 17.8 ms); a lone 8,192-agent launch — a latency chain — pays 7 % (0.91 -> 0.99 ms).  One build for every
+// batch size, so that an agent's answer never depends on the batch it travels in: a second, trig-storing build for small batches was
+// measured too, but the compiler contracts the backward sweep's sums of products differently per build (costs equal to 1e-14, not to
+// the bit) — profiles/r05/mpc_variants_ab.jsonl, README there.
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
                                                const MpcFeed feed = MpcFeed{}) {
@@ -274,7 +277,6 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
   float Kf[MAXT][12];
-  double TR[LEAN ? 1 : 2][LEAN ? 1 : MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them (LEAN: recomputes them)
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
@@ -284,36 +286,39 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
   // rolls controls U[c] from x0 and returns fg[0]
-  auto track = [&](const double* s, int i) -> double {
-    const float4 r = xr4[i];
+  // The arithmetic of a rollout — model step, control and tracking cost, the feedback law — is written with explicit fma(): under
+  // `fp contract(fast)` the compiler decides per build which product of a sum of products it fuses, and the candidate's cost J decides
+  // accept / reject.  With the fusion spelled out every build of this function (lockstep, refilling, portfolio, the closed loop)
+  // rolls the same bits out of the same gains.
+  auto track_cost = [&](const float4 r, const double* s) -> double {
     const double e0 = (double)r.x - s[0], e1 = (double)r.y - s[1], e2 = (double)r.z - s[2], e3 = (double)r.w - s[3];
-    return p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
+    return fma(p.qx * e0, e0, fma(p.qy * e1, e1, fma(p.qyaw * e2, e2, (p.qv * e3) * e3)));
   };
-  auto ctrl = [&](int c, int i) -> double {
-    const double d = U[c][i][0], a = U[c][i][1];
-    double v = p.r_d * d * d + p.r_a * a * a;
-    if (i >= 1) {
-      const double dd = d - U[c][i - 1][0], da = a - U[c][i - 1][1];
-      v += p.rd_d * dd * dd + p.rd_a * da * da;
+  auto ctrl_cost = [&](bool inner, double d, double a, double pd, double pa) -> double {
+    double v = fma(p.r_d * d, d, (p.r_a * a) * a);
+    if (inner) {
+      const double dd = d - pd, da = a - pa;
+      v = fma(p.rd_d * dd, dd, fma(p.rd_a * da, da, v));
     }
     return v;
   };
-  auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
+  auto track = [&](const double* s, int i) -> double { return track_cost(xr4[i], s); };
+  auto ctrl = [&](int c, int i) -> double {
+    const int j = i >= 1 ? i - 1 : 0;
+    return ctrl_cost(i >= 1, U[c][i][0], U[c][i][1], U[c][j][0], U[c][j][1]);
+  };
+  auto step = [&](const double* s, double d, double a, double* sn) {
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
     const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
-    if constexpr (!LEAN) { tr[0] = sn_; tr[1] = cs_; tr[2] = tn_; }
-    sn[0] = s[0] + s[3] * cs_ * dt;
-    sn[1] = s[1] + s[3] * sn_ * dt;
-    sn[2] = s[2] + s[3] * tn_ * dt_wb;
-    sn[3] = s[3] + a * dt;
+    sn[0] = fma(s[3] * cs_, dt, s[0]);
+    sn[1] = fma(s[3] * sn_, dt, s[1]);
+    sn[2] = fma(s[3] * tn_, dt_wb, s[2]);
+    sn[3] = fma(a, dt, s[3]);
   };
 
-  struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
-  auto load_stage = [&](int c, int i) -> StageIn {
-    if constexpr (LEAN) return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
-    else return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
-  };
+  struct StageIn { double s0, s1, s2, s3; float4 r; };
+  auto load_stage = [&](int c, int i) -> StageIn { return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], xr4[i]}; };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
   auto load_roll = [&](int c, int i) -> RollIn {
@@ -351,7 +356,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       U[0][i][0] = 0.0; U[0][i][1] = a0;
       J += ctrl(0, i);
       if (i >= 1) J += track(S[0][i], i);
-      step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
+      step(S[0][i], 0.0, a0, S[0][i + 1]);
     }
     J += track(S[0][N], N);
     mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
@@ -434,11 +439,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       uc0 = up0; uc1 = up1;
       { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
-      double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
-      if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
-        mpc_sincos(s[2], &sn_, &cs_);
-        tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
-      }
+      double sn_, cs_;                 // what step() computed when this knot was rolled out: the same functions of the same doubles
+      mpc_sincos(s[2], &sn_, &cs_);
+      const double tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
       const double v = s[3];
       const double sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
@@ -663,33 +666,22 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       const double d4 = (i >= 1) ? pnd - pcd : 0.0;
       const double d5 = (i >= 1) ? pna - pca : 0.0;
       double du0 = alpha * in.k0;
-      du0 += in.K[0] * d0; du0 += in.K[2] * d1; du0 += in.K[4] * d2; du0 += in.K[6] * d3; du0 += in.K[8] * d4; du0 += in.K[10] * d5;
+      du0 = fma(in.K[0], d0, du0); du0 = fma(in.K[2], d1, du0); du0 = fma(in.K[4], d2, du0); du0 = fma(in.K[6], d3, du0); du0 = fma(in.K[8], d4, du0); du0 = fma(in.K[10], d5, du0);
       double du1 = alpha * in.k1;
-      du1 += in.K[1] * d0; du1 += in.K[3] * d1; du1 += in.K[5] * d2; du1 += in.K[7] * d3; du1 += in.K[9] * d4; du1 += in.K[11] * d5;
+      du1 = fma(in.K[1], d0, du1); du1 = fma(in.K[3], d1, du1); du1 = fma(in.K[5], d2, du1); du1 = fma(in.K[7], d3, du1); du1 = fma(in.K[9], d4, du1); du1 = fma(in.K[11], d5, du1);
       const AccelBox nb = accel_box(p, inv_dt, xs[3]);            // the box of a_i at the NEW speed of knot i
       const double nd = clampd(in.u0 + du0, lb0, ub0);
       const double na = clampd(in.u1 + du1, nb.lo, nb.hi);
       U[nxt][i][0] = nd; U[nxt][i][1] = na;
-      double cv = p.r_d * nd * nd + p.r_a * na * na;              // ctrl(nxt, i)
-      if (i >= 1) {
-        const double dd = nd - pnd, da = na - pna;
-        cv += p.rd_d * dd * dd + p.rd_a * da * da;
-      }
-      Jn += cv;
-      if (i >= 1) {                                               // track(xs, i)
-        const double e0 = (double)in.r.x - xs[0], e1 = (double)in.r.y - xs[1], e2 = (double)in.r.z - xs[2], e3 = (double)in.r.w - xs[3];
-        Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
-      }
+      Jn += ctrl_cost(i >= 1, nd, na, pnd, pna);                  // ctrl(nxt, i)
+      if (i >= 1) Jn += track_cost(in.r, xs);                     // track(xs, i)
       double xn[4];
-      step(xs, nd, na, xn, LEAN ? TR[0][0] : TR[nxt][i]);
+      step(xs, nd, na, xn);
       S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
       xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
       pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
     }
-    {                                                             // track(xs, N), terminal reference kept in registers
-      const double e0 = (double)rN.x - xs[0], e1 = (double)rN.y - xs[1], e2 = (double)rN.z - xs[2], e3 = (double)rN.w - xs[3];
-      Jn += p.qx * e0 * e0 + p.qy * e1 * e1 + p.qyaw * e2 * e2 + p.qv * e3 * e3;
-    }
+    Jn += track_cost(rN, xs);                                     // track(xs, N), terminal reference kept in registers
 #if CRX_MPC_TICKS >= 2
     tk_nf++; tk_f += clock64() - tk_f0;
 #endif
@@ -849,7 +841,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 // 8 agents per wave take 1.18 / 1.41 / 1.95 ms against 1.08, and so do two or four waves per workgroup (1.18 / 1.42 ms at
 // full waves): every wave streams its lanes' 5.4 KB of private memory through L2 each sweep whether the lanes are used or
 // not, and waves that share a CU share its path to it.
-template <int MAXT, bool LEAN = false>
+template <int MAXT>
 __global__ void __launch_bounds__(256)   // 1-4 waves per workgroup, one wave per SIMD: the register budget of a lone wave
 mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
            float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
@@ -862,7 +854,7 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
   const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, false, LEAN>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  mpc_solve_lane<MAXT>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
@@ -873,14 +865,14 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
 // finished lane takes the wave's next agent.  Per agent the same sweeps in the same order: bit-identical to mpc_kernel.  Round 4
 // measured it (profiles/r04/mpc_refill_ab.jsonl: 1.14x at 65,536 agents, 1.16x at 262,144, 0.99x at 1 M) and kept it in the A/B build;
 // round 5 ships it — with the asynchronous line search (mpc_solve_lane) — for the batches where it wins (api_internal.inl: mpc_refill_chunk).
-template <int MAXT, bool LEAN = true>
+template <int MAXT>
 __global__ void __launch_bounds__(64)
 mpc_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
                   float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
   const int lo = (int)blockIdx.x * chunk;
   const MpcFeed feed{lo, (n - lo < chunk) ? n : lo + chunk, hold, x0g, xrefg, solg, statusg, costg};
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, true, LEAN>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
+  mpc_solve_lane<MAXT, false, true>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
 }
 
 // The portfolio launch: agent a on lanes 4a .. 4a+3 (16 agents per wave, single-wave workgroups): 4x the waves of mpc_kernel — at the
@@ -925,42 +917,32 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
 }
 
 // lanes refilled: `chunk` agents per wave, hand-back in batches of `hold` lanes (max_iter >= 1)
-template <bool LEAN>
-inline hipError_t mpc_refill_launch_t(int n, int T, const float* x0, const float* xref, const MpcP& p, float* sol,
-                                      int* status, double* cost, hipStream_t stream, int chunk, int hold) {
+inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                    int* status, double* cost, hipStream_t stream, int chunk, int hold) {
+  const MpcP p = mpc_pack(q);
   const dim3 grid((unsigned)(((size_t)n + chunk - 1) / chunk)), block(64);
   if (T <= 8)
-    hipLaunchKernelGGL((mpc_refill_kernel<8, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<8>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   else if (T <= 24)
-    hipLaunchKernelGGL((mpc_refill_kernel<24, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<24>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   else
-    hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T, LEAN>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+    hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
-inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                                    int* status, double* cost, hipStream_t stream, int chunk, int hold, bool lean = true) {
-  const MpcP p = mpc_pack(q);
-  return lean ? mpc_refill_launch_t<true>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold)
-              : mpc_refill_launch_t<false>(n, T, x0, xref, p, sol, status, cost, stream, chunk, hold);
-}
 
-// lean: the traffic-lean build of the solve (mpc_solve_lane's LEAN) — bit-identical, picked where the launch shares the GPU with others
-template <int MAXT>
-inline void mpc_launch_mt(bool lean, dim3 grid, dim3 block, hipStream_t stream, int n, int T, int live, const float* x0, const float* xref,
-                          const MpcP& p, float* sol, int* status, double* cost) {
-  if (lean) hipLaunchKernelGGL((mpc_kernel<MAXT, true>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else hipLaunchKernelGGL((mpc_kernel<MAXT, false>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-}
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1, bool lean = false) {
+                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1) {
   const MpcP p = mpc_pack(q);
   if (live < 1 || live > 64) live = 64;
   if (wg_waves < 1 || wg_waves > 4) wg_waves = 1;
   const size_t waves = ((size_t)n + live - 1) / live;
   const dim3 grid((unsigned)((waves + wg_waves - 1) / wg_waves)), block(64 * wg_waves);
-  if (T <= 8) mpc_launch_mt<8>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else if (T <= 24) mpc_launch_mt<24>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else mpc_launch_mt<CRX_MPC_MAX_T>(lean, grid, block, stream, n, T, live, x0, xref, p, sol, status, cost);
+  if (T <= 8)
+    hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else if (T <= 24)
+    hipLaunchKernelGGL((mpc_kernel<24>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else
+    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 

@@ -10,7 +10,6 @@ _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
-    "crx_x_mpc_solve_variant_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
                                              C.POINTER(L.LoopParams), _P, _P, _P, _I]),
@@ -151,25 +150,7 @@ def mpc_solve_lanes(x0, xref, T, lanes_per_agent=0, params=None):
     return sol, status, cost
 
 
-def mpc_solve_variant(x0, xref, T, lean=0, agents_per_wave=0, hold_lanes=16, params=None, out=None):
-    """mpc_solve with the kernel forced: lean = 0 / 1 (the traffic-lean build), agents_per_wave = 0: mpc_kernel, otherwise the
-    lane-refilling kernel with that many agents per wave.  All bit-identical per agent.  -> sol, status, cost (out = the caller's)."""
-    import torch
-    from .mpc import default_params, mpc_n_vars
-    L.require_cuda(x0, xref)
-    n = x0.shape[0]
-    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
-    p = params if params is not None else default_params()
-    if out is None:
-        out = (torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device), torch.empty((n,), dtype=torch.int32, device=x0.device),
-               torch.empty((n,), dtype=torch.float64, device=x0.device))
-    sol, status, cost = out
-    L.check(xlib().crx_x_mpc_solve_variant_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
-                                               L.stream_ptr(), int(lean), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_variant_dev")
-    return sol, status, cost
-
-
-def mpc_solve_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, poison=True):
+def mpc_solve_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, poison=True, out=None):
     """mpc_solve through the lane-refilling kernel (a wave owns `agents_per_wave` consecutive agents, finished lanes hand their
     agents back `hold_lanes` at a time and take the next ones) with the geometry forced; the product selects this kernel itself
     from 65,536 agents on.  -> sol, status, cost."""
@@ -179,11 +160,14 @@ def mpc_solve_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=No
     n = x0.shape[0]
     L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
     p = params if params is not None else default_params()
-    sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
-    status = torch.empty((n,), dtype=torch.int32, device=x0.device)
-    cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
-    if poison:                         # an agent the range bookkeeping skipped would show
-        sol.fill_(float("nan")); status.fill_(-1); cost.fill_(float("nan"))
+    if out is not None:
+        sol, status, cost = out
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+        if poison:                         # an agent the range bookkeeping skipped would show
+            sol.fill_(float("nan")); status.fill_(-1); cost.fill_(float("nan"))
     L.check(xlib().crx_x_mpc_solve_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                               L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_refill_dev")
     return sol, status, cost

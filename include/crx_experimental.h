@@ -63,12 +63,7 @@ int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long lon
  * point); scripts/gpu_mpc_refill_ab.py, scripts/gpu_mpc_variants_ab.py. */
 int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                double* cost, void* stream, int agents_per_wave, int hold_lanes);
-/* The one-lane-per-agent solve with the kernel forced.  lean = 0 / 1: the traffic-lean build (the backward sweep recomputes the
- * rollout's trig instead of reading it back); agents_per_wave = 0: mpc_kernel, otherwise the lane-refilling kernel with that many
- * agents per wave.  All bit-identical per agent; which one a product call gets is decided by the batch size and
- * crx_mpc_params.schedule (include/crx.h).  scripts/gpu_mpc_variants_ab.py. */
-int crx_x_mpc_solve_variant_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                                double* cost, void* stream, int lean, int agents_per_wave, int hold_lanes);
+
 
 /* crx_dare_from_v_batch_dev with one agent per lane and the lane-refilling kernel forced (dare_from_v_refill_kernel: a wave owns
  * `agents_per_wave` consecutive agents; once `hold_lanes` of its lanes hold a finished agent they hand them back in one pass and

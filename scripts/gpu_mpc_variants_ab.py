@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""A/B of the one-lane-per-agent MPC solve's kernels, standalone launches at 8,192 .. 1 M agents (T = 21): mpc_kernel and
-mpc_refill_kernel (several range lengths), each in the default and the traffic-lean build.  Every one must reproduce mpc_kernel's bits.
-(Round 5 also measured a private copy of the reference trajectory and a 256-register build: profiles/r05/mpc_variants_ab_run*.jsonl.)  One JSON line per batch size -> profiles/rNN/mpc_variants_ab.jsonl.
+"""A/B of the one-lane-per-agent MPC solve's kernels, standalone launches at 8,192 .. 1 M agents (T = 21): mpc_kernel (lockstep) and
+mpc_refill_kernel at several range lengths.  Every one must reproduce mpc_kernel's bits.  (Round 5 also measured a private copy of the
+reference trajectory, a 256-register build and a trig-storing build beside the recomputing one: profiles/r05/mpc_variants_ab_run*.jsonl.)  One JSON line per batch size -> profiles/rNN/mpc_variants_ab.jsonl.
   python scripts/gpu_mpc_variants_ab.py [sizes ...]"""
 import json
 import os
@@ -40,14 +40,13 @@ def main():
                 "ms_mpc_kernel": timeit(lambda: X.mpc_solve_lanes(x0, xref, T, lanes_per_agent=1), reps),
                 "ms_product_entry": timeit(lambda: crx.mpc_solve(x0, xref, T), reps)}
         same = True
-        variants = [("mpc_kernel_lean", 1, 0)]
+        variants = []
         if n >= 16384:
-            variants += [("refill_%d_lean" % c, 1, c) for c in (128, 256, 512, 1024) if n // c >= 64]
-            variants += [("refill_%d" % c, 0, c) for c in (256, 512) if n // c >= 64]
-        for name, bits, apw in variants:
-            out = X.mpc_solve_variant(x0, xref, T, bits, apw)
+            variants += [("refill_%d" % c, c) for c in (128, 256, 512, 1024) if n // c >= 64]
+        for name, apw in variants:
+            out = X.mpc_solve_refill(x0, xref, T, apw, 16)
             same = same and all(torch.equal(a.view(torch.uint8), b.view(torch.uint8)) for a, b in zip(out, base))
-            line["ms_" + name] = timeit(lambda: X.mpc_solve_variant(x0, xref, T, bits, apw), reps)
+            line["ms_" + name] = timeit(lambda: X.mpc_solve_refill(x0, xref, T, apw, 16, poison=False), reps)
         line["bit_identical"] = bool(same)
         best = min((k for k in line if k.startswith("ms_")), key=lambda k: line[k])
         line["best"] = best

@@ -21,8 +21,7 @@ def main():
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
     configs = [("product", d) for d in ((1, 4) if quick else (1, 2, 3, 4, 5, 6, 8))]
     if not quick:
-        configs += [("latency", 3), ("latency", 4), ("latency", 6), ("kernel:0:128", 4), ("kernel:1:128", 3), ("kernel:1:128", 4), ("kernel:1:128", 6),
-                    ("kernel:1:256", 4), ("kernel:1:256", 8), ("portfolio", 4)]
+        configs += [("refill:128", 3), ("refill:128", 4), ("refill:128", 6), ("refill:256", 4), ("refill:256", 8), ("portfolio", 4)]
     for spec, depth in configs:
         fn, label = mpc_launcher(spec)
         try:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel and the lane-refilling kernel, each in
-the default and the traffic-lean build, N agents (default 262,144), T = 21, `reps` launches each."""
+"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel and the lane-refilling kernel, N agents
+(default 262,144), T = 21, `reps` launches each."""
 import os
 import sys
 
@@ -16,7 +16,10 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 x0, xref = mpc_problem(n, 21, 4)
 x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
-for bits, apw in ((0, 0), (1, 0), (0, 512), (1, 512)):        # (lean, agents per wave)
+for apw in (0, 512):                                           # agents per wave of the refilling kernel; 0: mpc_kernel
     for _ in range(reps):
-        X.mpc_solve_variant(x0, xref, 21, bits, apw)
+        if apw:
+            X.mpc_solve_refill(x0, xref, 21, apw, 16, poison=False)
+        else:
+            X.mpc_solve_lanes(x0, xref, 21, lanes_per_agent=1)
     torch.cuda.synchronize()

@@ -8,7 +8,7 @@ bench.py prints as `extra.swarm_configs4` (N = 1) / `multi_gpu.swarm_configs4` (
 The round itself is cpprobotics_amd/swarm.py: SwarmShard / MixedSwarmRound (its docstring describes the streams and the slot ring), the
 measurement bench.py: measure_swarm_configs4.  --mpc selects the planner launch for A/Bs: `product` (crx_mpc_solve_batch_dev with
 params.schedule = THROUGHPUT: what SwarmShard issues), `auto` / `latency` (the other two schedules), `portfolio`,
-`kernel:<lean 0|1>[:<agents per wave>[:<hold>]]` (the kernel forced, include/crx_experimental.h).
+`refill:<agents per wave>[:<hold>]` (the lane-refilling kernel forced, include/crx_experimental.h).
 Prints one JSON line on rank 0."""
 import argparse
 import json
@@ -33,11 +33,10 @@ def mpc_launcher(spec):
     if kind == "portfolio":
         return (lambda est, xref, Tm, out: crx.mpc_solve(est, xref, Tm, portfolio=True, out=out)), "crx_mpc_solve_portfolio_batch_dev"
     from cpprobotics_amd import experimental as X
-    if kind == "kernel":
-        lean, apw, hold = int(rest[0]), int(rest[1]) if len(rest) > 1 else 0, int(rest[2]) if len(rest) > 2 else 16
-        name = f"mpc_refill_kernel, {apw} agents per wave, hold {hold}" if apw else "mpc_kernel"
-        return (lambda est, xref, Tm, out: X.mpc_solve_variant(est, xref, Tm, lean, apw, hold, out=out)), name + (", traffic-lean build" if lean else "")
-    raise SystemExit(f"--mpc {spec}: product | auto | latency | portfolio | kernel:<lean>[:<apw>[:<hold>]]")
+    if kind == "refill":
+        apw, hold = int(rest[0]), int(rest[1]) if len(rest) > 1 else 16
+        return (lambda est, xref, Tm, out: X.mpc_solve_refill(est, xref, Tm, apw, hold, out=out)), f"mpc_refill_kernel, {apw} agents per wave, hold {hold}"
+    raise SystemExit(f"--mpc {spec}: product | auto | latency | portfolio | refill:<apw>[:<hold>]")
 
 
 def main():

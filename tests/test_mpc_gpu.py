@@ -262,19 +262,19 @@ def test_mpc_product_dispatch_is_bit_identical_across_the_refill_threshold(crx):
 
 
 @pytest.mark.parametrize("T", [6, 21, 30])
-def test_mpc_kernel_builds_are_bit_identical(crx, T):
-    """The four one-lane-per-agent kernels a product call can get — mpc_kernel and mpc_refill_kernel, each in the default and in the
-    traffic-lean build (the backward sweep recomputes the rollout's trig) — and the three settings of crx_mpc_params.schedule run the same
-    arithmetic per agent: identical bits.  An agent's answer depends on its problem, never on how the launch is scheduled."""
+def test_mpc_schedules_and_kernels_are_bit_identical(crx, T):
+    """The kernels a product call can get — mpc_kernel (lockstep line search) and mpc_refill_kernel (lanes refilled, line search scheduled
+    asynchronously), whatever crx_mpc_params.schedule says — run the same arithmetic per agent: identical bits.  An agent's answer depends
+    on its problem, never on how its launch is scheduled."""
     import torch
     from cpprobotics_amd import _lib as L
-    from cpprobotics_amd.experimental import mpc_solve_variant
+    from cpprobotics_amd.experimental import mpc_solve_refill
     from cpprobotics_amd.mpc import default_params
     n = 3001
     x0, xref = mpc_problem(n, T, 90 + T)
     x0, xref = _t(x0), _t(xref)
     sol0, st0, c0 = crx.mpc_solve(x0, xref, T, return_status=True)
-    outs = [mpc_solve_variant(x0, xref, T, lean, apw) for lean, apw in ((0, 0), (1, 0), (0, 128), (1, 128), (1, 3001))]
+    outs = [mpc_solve_refill(x0, xref, T, apw, hold) for apw, hold in ((128, 16), (64, 1), (3001, 64))]
     for sched in (L.MPC_SCHEDULE_LATENCY, L.MPC_SCHEDULE_THROUGHPUT):
         p = default_params(); p.schedule = sched
         outs.append(crx.mpc_solve(x0, xref, T, return_status=True, params=p))

@@ -63,18 +63,6 @@ inline int dare_refill_chunk(int n) {
   const int per = ((n / 2048 + 63) / 64) * 64;
   return per < 256 ? 256 : (per > 1024 ? 1024 : per);
 }
-// MPC: mpc_refill_kernel from this batch on (agents per wave: a multiple of 64).  Measured: profiles/r04/mpc_refill_ab.jsonl,
-// profiles/r05/mpc_variants_ab.jsonl.  0 = mpc_kernel.
-// (round 5, final loops: 65,536 agents 3.25 -> 3.04 ms with 256 agents per wave, 262,144 8.52 -> 7.47 with 512, 1 M 26.5 -> 27.6-28.5: from
-// ~3/4 M agents on the plain kernel's 16 waves per SIMD queue hide what refilling recovers, and its footprint per resident wave is smaller)
-constexpr int kMpcRefillMinAgents = 65536, kMpcRefillMaxAgents = 786432;
-constexpr int kMpcRefillHold = 16;
-// throughput: the caller keeps several launches in flight (crx_mpc_params.schedule) — a small batch is then not a latency chain either
-inline int mpc_refill_chunk(int n, bool throughput = false) {
-  (void)throughput;                         // measured (profiles/r05/swarm_pipeline_ab.jsonl): below the window the lockstep kernel stays ahead also when pipelined
-  if (n < kMpcRefillMinAgents || n >= kMpcRefillMaxAgents) return 0;
-  return n < 262144 ? 256 : 512;
-}
 constexpr int kDareChainMaxAgents = 98304;   // one lane per agent: the unmasked two-evaluations-per-branch loop up to here (profiles/r03/dare_lanes_ab.txt)
 
 // Threads per workgroup of the iterative kernels (dense DARE, tracking): full 64-lane waves in single-wave workgroups.  Narrower

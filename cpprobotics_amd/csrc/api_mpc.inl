@@ -27,6 +27,9 @@ static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, co
     return fail(CRX_ERR_INVALID, "mpc_solve (refill): bad argument (2 <= T <= 64)");
   if (agents_per_wave < 64 || agents_per_wave > (1 << 20) || hold_lanes < 1 || hold_lanes > 64)
     return fail(CRX_ERR_INVALID, "mpc_solve (refill): agents_per_wave 64 .. 2^20, hold_lanes 1 .. 64");
+#if !CRX_EXPERIMENTAL_KERNELS
+  return fail(CRX_ERR_INVALID, "mpc_solve (refill): this libcrx.so was built without the experimental kernels (CRX_EXPERIMENTAL_KERNELS=0)");
+#else
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
@@ -34,6 +37,7 @@ static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, co
   if (p.max_iter < 1) return fail(CRX_ERR_INVALID, "mpc_solve (refill): max_iter must be at least 1");
   const hipError_t e = crx::mpc_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc refill launch");
+#endif
 }
 // lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
 // measured 0.95x at BASELINE configs[3] and less beyond, never selected), 0 = what the product entry point uses (= 1).
@@ -41,13 +45,10 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
                            double* cost, void* stream, int lanes_per_agent) {
   if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
     return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
-  if (lanes_per_agent == 0) {                        // the product's choice; the quad variant lost its A/B at every batch size (profiles/r03/mpc_lanes_ab.txt)
-    const int sched = prm ? prm->schedule : CRX_MPC_SCHEDULE_AUTO;
-    if (sched < CRX_MPC_SCHEDULE_AUTO || sched > CRX_MPC_SCHEDULE_THROUGHPUT) return fail(CRX_ERR_INVALID, "mpc_solve: params.schedule must be CRX_MPC_SCHEDULE_AUTO, _LATENCY or _THROUGHPUT");
-    const int chunk = sched == CRX_MPC_SCHEDULE_LATENCY ? 0 : mpc_refill_chunk(n, sched == CRX_MPC_SCHEDULE_THROUGHPUT);
-    if (chunk && (!prm || prm->max_iter >= 1)) return mpc_solve_refill(n, T, x0, xref, prm, sol, status, cost, stream, chunk, kMpcRefillHold);
-    lanes_per_agent = 1;
-  }
+  // the product's choice: one lane per agent, lockstep line search, at every batch size.  (The quad variant lost its A/B at every batch
+  // size, profiles/r03/mpc_lanes_ab.txt; the lane-refilling kernel — 1.14-1.16x at 65,536 .. 262,144 agents in round 4 — no longer wins
+  // anywhere since round 5 cut the solver's memory traffic by a third: profiles/r05/mpc_variants_ab.jsonl.)
+  if (lanes_per_agent == 0) lanes_per_agent = 1;
   if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 #if !CRX_EXPERIMENTAL_KERNELS
   return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): this libcrx.so was built without the experimental kernels");

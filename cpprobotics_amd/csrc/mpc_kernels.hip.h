@@ -731,16 +731,15 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       if (iter == p.max_iter - 1) it = p.max_iter;
     }
   } else {
-    // The throughput regime (mpc_refill_kernel): the line search is scheduled ASYNCHRONOUSLY across the lanes of the wave (round 5).  A
-    // trip of the loop is one backward pass for the lanes that are due one and ONE candidate rollout for the lanes with a line search
-    // pending; a lane whose candidate is refused halves alpha and rolls again in the NEXT trip, next to the other lanes' first
-    // candidates.  A refilled wave always holds some lane in a long line search, so the lockstep loop above makes it run 3-4 rollout
-    // passes per sweep, most of them for a handful of lanes (full cache lines for a few lanes' bytes; that traffic is HBM traffic here).
-    // Measured (profiles/r05/mpc_variants_ab.jsonl, mpc_traffic_*.json): 262,144 agents 7.83 -> 7.29 ms, memory instructions -25 %.  In
-    // the latency regime the same scheduling LOSES (8,192 agents: 0.94 -> 1.17 ms): a retrying lane waits through the other lanes'
-    // backward pass (three times a rollout) before its next candidate, and it is the retrying lanes that set a launch's critical path —
-    // so mpc_kernel keeps the lockstep loop.  Per agent both loops run the same backward passes and the same rollouts with the same step
-    // lengths in the same order: bit-identical results (tests/test_mpc_gpu.py).
+    // mpc_refill_kernel (A/B build): the line search is scheduled ASYNCHRONOUSLY across the lanes of the wave (round 5).  A trip of the
+    // loop is one backward pass for the lanes that are due one and ONE candidate rollout for the lanes with a line search pending; a lane
+    // whose candidate is refused halves alpha and rolls again in the NEXT trip, next to the other lanes' first candidates.  A refilled wave
+    // always holds some lane in a long line search, so the lockstep loop above makes it run 3-4 rollout passes per sweep, most of them for
+    // a handful of lanes.  Measured (profiles/r05/mpc_variants_ab_run2_async_everywhere.jsonl): the refilling kernel at 262,144 agents
+    // 7.83 -> 7.29 ms, memory instructions -25 %.  In the latency regime the same scheduling LOSES (8,192 agents: 0.94 -> 1.17 ms): a
+    // retrying lane waits through the other lanes' backward pass (three times a rollout) before its next candidate, and it is the
+    // retrying lanes that set a launch's critical path — so mpc_kernel keeps the lockstep loop.  Per agent both loops run the same
+    // backward passes and the same rollouts with the same step lengths in the same order: bit-identical results (tests/test_mpc_gpu.py).
     int sweep = 0;                    // backward passes the lane's agent has started (= the sweep index reported in `status`)
     bool fwd = false;                 // a line search is pending: the next candidate uses `alpha`
     double alpha = 1.0, noise = 0.0;
@@ -860,11 +859,15 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   if (costg) costg[agent] = J;
 }
 
-// The throughput-regime launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>):
-// a wave of mpc_kernel lasts as long as the slowest of its 64 agents (mean of the wave maximum ~12 sweeps against a mean of 6.8), here a
-// finished lane takes the wave's next agent.  Per agent the same sweeps in the same order: bit-identical to mpc_kernel.  Round 4
-// measured it (profiles/r04/mpc_refill_ab.jsonl: 1.14x at 65,536 agents, 1.16x at 262,144, 0.99x at 1 M) and kept it in the A/B build;
-// round 5 ships it — with the asynchronous line search (mpc_solve_lane) — for the batches where it wins (api_internal.inl: mpc_refill_chunk).
+// The lane-refilling launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>): a wave
+// of mpc_kernel lasts as long as the slowest of its 64 agents (mean of the wave maximum ~12 sweeps against a mean of 6.8), here a finished
+// lane takes the wave's next agent, and the line search is scheduled asynchronously.  Per agent the same sweeps in the same order:
+// bit-identical to mpc_kernel.  MEASURED AND REJECTED, twice: round 4 1.14x at 65,536 agents, 1.16x at 262,144, 0.99x at 1 M
+// (profiles/r04/mpc_refill_ab.jsonl); round 5, after the solver's memory traffic fell by a third (float gains, recomputed trig) and with
+// the asynchronous line search, 1.00x / 0.96x / 0.89x (profiles/r05/mpc_variants_ab.jsonl): where waves queue the memory system, not the
+// idle lanes, is the limit, and mpc_kernel's short-lived waves hand their SIMD and their share of the caches to the next one.  Compiled
+// into the A/B build only (CRX_EXPERIMENTAL_KERNELS), reachable through crx_x_mpc_solve_refill_dev.
+#if CRX_EXPERIMENTAL_KERNELS
 template <int MAXT>
 __global__ void __launch_bounds__(64)
 mpc_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
@@ -874,6 +877,7 @@ mpc_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x
   int status; double J; float a0, d0;
   mpc_solve_lane<MAXT, false, true>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed);
 }
+#endif
 
 // The portfolio launch: agent a on lanes 4a .. 4a+3 (16 agents per wave, single-wave workgroups): 4x the waves of mpc_kernel — at the
 // BASELINE batch 512 waves on 1,024 SIMDs, still one per SIMD.
@@ -916,6 +920,7 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
   return hipGetLastError();
 }
 
+#if CRX_EXPERIMENTAL_KERNELS
 // lanes refilled: `chunk` agents per wave, hand-back in batches of `hold` lanes (max_iter >= 1)
 inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                     int* status, double* cost, hipStream_t stream, int chunk, int hold) {
@@ -929,6 +934,7 @@ inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* 
     hipLaunchKernelGGL((mpc_refill_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
+#endif
 
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                              int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1) {

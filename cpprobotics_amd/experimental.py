@@ -152,8 +152,8 @@ def mpc_solve_lanes(x0, xref, T, lanes_per_agent=0, params=None):
 
 def mpc_solve_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, poison=True, out=None):
     """mpc_solve through the lane-refilling kernel (a wave owns `agents_per_wave` consecutive agents, finished lanes hand their
-    agents back `hold_lanes` at a time and take the next ones) with the geometry forced; the product selects this kernel itself
-    from 65,536 agents on.  -> sol, status, cost."""
+    agents back `hold_lanes` at a time and take the next ones; asynchronous line search): measured and rejected, in the A/B build
+    libcrx_x.so only.  -> sol, status, cost."""
     import torch
     from .mpc import default_params, mpc_n_vars
     L.require_cuda(x0, xref)
@@ -168,8 +168,8 @@ def mpc_solve_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=No
         cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
         if poison:                         # an agent the range bookkeeping skipped would show
             sol.fill_(float("nan")); status.fill_(-1); cost.fill_(float("nan"))
-    L.check(xlib().crx_x_mpc_solve_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
-                                              L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_refill_dev")
+    _check_ab(ablib().crx_x_mpc_solve_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                 L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_refill_dev (libcrx_x.so)")
     return sol, status, cost
 
 

@@ -146,6 +146,23 @@ class ChunkedTrajectoryGather:
         return self.gathered.permute(0, 2, 1, 3, 4).reshape(self.T, self.world * self.nl, self.C).contiguous()
 
 
+def want_hw_queues(streams):
+    """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share a queue
+    run their kernels one after the other.  A pipelined round — one launch stream + `depth` planner streams (+ RCCL's) — needs a queue per
+    stream: measured on one MI355X at depth 6, 0.74 ms per round with 4 queues, 0.49 with 8 (profiles/r05/swarm_hw_queues.txt).  The
+    variable is read when the runtime initialises the device, so this must run before the process first touches the GPU; returns what is
+    in effect (None if the device was already initialised without it: the caller then runs with the default)."""
+    import os
+    want = max(8, int(streams))
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None and int(cur) >= want:
+        return int(cur)
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(cur) if cur is not None else None
+    os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    return want
+
+
 class MixedSwarmRound:
     """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (bench.py and scripts/swarm_bench.py run it
     on the GPUs, tests/test_swarm_gpu.py checks it there against the oracle, tests/test_dist_cpu.py with gloo and the CPU oracle
@@ -265,7 +282,7 @@ class SwarmShard:
     course: the (cx, cy, cyaw, ck, sp) float32 arrays of the shared course; Q, R: the filter's noise matrices (column-major).
     mpc_fn(est, xref, Tm, out): the planner launch (default cpprobotics_amd.mpc_solve)."""
 
-    def __init__(self, n, T, course, Q, R, device, rank=0, world=1, Tm=21, plan_every=8, depth=4, chunks=4, gather="traj", seed=99, v_cmd=2.5,
+    def __init__(self, n, T, course, Q, R, device, rank=0, world=1, Tm=21, plan_every=8, depth=6, chunks=4, gather="traj", seed=99, v_cmd=2.5,
                  input_sets=1, mpc_fn=None, group=None, record_ekf_events=False):
         import numpy as np
 
@@ -275,12 +292,7 @@ class SwarmShard:
         self.n_total, self.n_plan, self.every = n * world, (n + plan_every - 1) // plan_every, plan_every
         self.q, self.r = _qr(Q, R)
         self.dc = crx.Course.from_numpy(course, device=device)
-        # the round keeps `depth` planner launches in flight: it tells the engine so (crx_mpc_params.schedule), which picks the traffic-lean
-        # kernel for them — same bits, less HBM traffic where the launches share the memory system
-        from ._lib import MPC_SCHEDULE_THROUGHPUT
-        self.mpc_params = crx.mpc.default_params()
-        self.mpc_params.schedule = MPC_SCHEDULE_THROUGHPUT
-        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, params=self.mpc_params, out=out))
+        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, out=out))
         ci = np.random.default_rng(seed).integers(0, len(course[0]) - 30, self.n_total)[rank * n:(rank + 1) * n]
         self.start_index = ci
         cit = torch.from_numpy(ci).to(device)

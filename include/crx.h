@@ -183,15 +183,7 @@ typedef struct crx_mpc_params {
   double q_x, q_y, q_yaw, q_v; /* 1, 1, 0.5, 0.5  tracking cost :247-250 */
   double tol;        /* stop when the projected-gradient norm and the step are below tol */
   int max_iter;      /* outer iteration cap (the reference: IPOPT max_iter 50, :326)     */
-  int schedule;      /* CRX_MPC_SCHEDULE_*: how the launch is scheduled — never what it computes (every choice gives every agent the
-                        same bits).  AUTO (0, what crx_mpc_default_params sets): by batch size — below 65,536 agents the launch is a
-                        latency chain (its slowest agent's sweeps) and gets the kernel built for that, from there on the lane-refilling,
-                        traffic-lean one.  THROUGHPUT: the caller keeps several launches in flight (a pipelined planner, the mixed swarm
-                        round of BASELINE configs[4]): also a small batch then runs where HBM traffic, not one launch's latency, is the
-                        limit, and gets the traffic-lean kernel.  LATENCY: the latency-chain kernel whatever the size.  (The field sits
-                        in what was padding: sizeof(crx_mpc_params) is unchanged.) */
 } crx_mpc_params;
-enum { CRX_MPC_SCHEDULE_AUTO = 0, CRX_MPC_SCHEDULE_LATENCY = 1, CRX_MPC_SCHEDULE_THROUGHPUT = 2 };
 void crx_mpc_default_params(crx_mpc_params* p);
 
 /* mpc_solve(State x0, M_XREF traj_ref)  src/model_predictive_control.cpp:255-346 for n agents.

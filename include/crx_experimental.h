@@ -58,9 +58,9 @@ int crx_x_datan2_dev(int n, const double* y, double* out, void* stream);
 int crx_x_datan2_sweep_dev(double L, unsigned long long* sums, unsigned long long* ocml_diff, unsigned* diff_k, void* stream);
 
 /* crx_mpc_solve_batch_dev through the lane-refilling kernel (mpc_refill_kernel: a wave owns `agents_per_wave` consecutive agents;
- * once `hold_lanes` of its lanes hold a finished solve they write their solutions and take the next agents of the range) with the
- * geometry forced.  Since round 5 the product selects this kernel itself from 65,536 agents on (both libraries serve this entry
- * point); scripts/gpu_mpc_refill_ab.py, scripts/gpu_mpc_variants_ab.py. */
+ * once `hold_lanes` of its lanes hold a finished solve they write their solutions and take the next agents of the range; the line
+ * search scheduled asynchronously across the lanes).  Measured and rejected twice (rounds 4 and 5): libcrx_x.so only.
+ * scripts/gpu_mpc_refill_ab.py, scripts/gpu_mpc_variants_ab.py. */
 int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                double* cost, void* stream, int agents_per_wave, int hold_lanes);
 

@@ -6,9 +6,8 @@ bench.py prints as `extra.swarm_configs4` (N = 1) / `multi_gpu.swarm_configs4` (
   python scripts/swarm_bench.py --agents 131072 --depth 4          # one GPU, one shard of the 1,048,576-agent swarm
 
 The round itself is cpprobotics_amd/swarm.py: SwarmShard / MixedSwarmRound (its docstring describes the streams and the slot ring), the
-measurement bench.py: measure_swarm_configs4.  --mpc selects the planner launch for A/Bs: `product` (crx_mpc_solve_batch_dev with
-params.schedule = THROUGHPUT: what SwarmShard issues), `auto` / `latency` (the other two schedules), `portfolio`,
-`refill:<agents per wave>[:<hold>]` (the lane-refilling kernel forced, include/crx_experimental.h).
+measurement bench.py: measure_swarm_configs4.  --mpc selects the planner launch for A/Bs: `product` (crx_mpc_solve_batch_dev),
+`portfolio`, `refill:<agents per wave>[:<hold>]` (the lane-refilling A/B kernel, include/crx_experimental.h).
 Prints one JSON line on rank 0."""
 import argparse
 import json
@@ -25,18 +24,14 @@ def mpc_launcher(spec):
     import cpprobotics_amd as crx
     kind, *rest = spec.split(":")
     if kind == "product":
-        return None, "crx_mpc_solve_batch_dev, schedule = THROUGHPUT"
-    if kind in ("auto", "latency"):
-        from cpprobotics_amd import _lib as L
-        p = crx.mpc.default_params(); p.schedule = L.MPC_SCHEDULE_AUTO if kind == "auto" else L.MPC_SCHEDULE_LATENCY
-        return (lambda est, xref, Tm, out: crx.mpc_solve(est, xref, Tm, params=p, out=out)), f"crx_mpc_solve_batch_dev, schedule = {kind.upper()}"
+        return None, "crx_mpc_solve_batch_dev"
     if kind == "portfolio":
         return (lambda est, xref, Tm, out: crx.mpc_solve(est, xref, Tm, portfolio=True, out=out)), "crx_mpc_solve_portfolio_batch_dev"
     from cpprobotics_amd import experimental as X
     if kind == "refill":
         apw, hold = int(rest[0]), int(rest[1]) if len(rest) > 1 else 16
         return (lambda est, xref, Tm, out: X.mpc_solve_refill(est, xref, Tm, apw, hold, out=out)), f"mpc_refill_kernel, {apw} agents per wave, hold {hold}"
-    raise SystemExit(f"--mpc {spec}: product | auto | latency | portfolio | refill:<apw>[:<hold>]")
+    raise SystemExit(f"--mpc {spec}: product | portfolio | refill:<apw>[:<hold>]")
 
 
 def main():
@@ -48,9 +43,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gather", choices=["traj", "final", "none"], default="traj")
     ap.add_argument("--chunks", type=int, default=4, help="EKF launches per round where the trajectory gather overlaps them (N > 1)")
-    ap.add_argument("--depth", type=int, default=4, help="planner launches in flight")
+    ap.add_argument("--depth", type=int, default=6, help="planner launches in flight")
     ap.add_argument("--mpc", default="product")
     args = ap.parse_args()
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.depth + 3)))     # a hardware queue per stream: cpprobotics_amd/swarm.py: want_hw_queues
     import torch
     import torch.distributed as dist
 

@@ -45,14 +45,12 @@ def test_experimental_entry_points_are_separate(crx):
 
 
 def test_product_library_does_not_carry_the_rejected_variants(crx):
-    """the measured-and-rejected kernel variants (two-lane EKF, four-lane MPC) are compiled into the A/B build libcrx_x.so
-    only; the product libcrx.so neither contains their code objects nor runs them.  (The lane-refilling MPC kernel was among them until
-    round 5; it is a product kernel now: selected from 65,536 agents on.)"""
+    """the measured-and-rejected kernel variants (two-lane EKF, four-lane MPC, lane-refilling MPC) are compiled into the A/B
+    build libcrx_x.so only; the product libcrx.so neither contains their code objects nor runs them."""
     from cpprobotics_amd import experimental as X
     prod = open(crx.lib_path(), "rb").read()
-    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel"):
+    for k in (b"ekf_run_pair_kernel", b"mpc_quad_kernel", b"mpc_refill_kernel"):
         assert k not in prod, k
-    assert b"mpc_refill_kernel" in prod
     ab = X.ab_lib_path()
     assert os.path.exists(ab), "libcrx_x.so missing: make -C cpprobotics_amd/csrc all"
     abb = open(ab, "rb").read()

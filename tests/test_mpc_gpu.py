@@ -228,7 +228,7 @@ def test_mpc_edge_cases(crx):
 
 
 def test_mpc_lane_refilling_variant_equals_the_production_kernel(crx):
-    """mpc_refill_kernel (a wave owns a range of agents and refills its lanes; the product's kernel from 65,536 agents on) — the same sweeps
+    """mpc_refill_kernel (measured and rejected, A/B build only: a wave owns a range of agents, refills its lanes and schedules the line search asynchronously) — the same sweeps
     per agent in the same order: solutions, status words (sweep counts included) and costs equal mpc_kernel's bit for bit, for odd
     range lengths, hand-back thresholds, ragged sizes, both horizons and a small sweep cap."""
     import torch
@@ -245,42 +245,16 @@ def test_mpc_lane_refilling_variant_equals_the_production_kernel(crx):
 
 
 
-def test_mpc_product_dispatch_is_bit_identical_across_the_refill_threshold(crx):
-    """From 65,536 agents on crx_mpc_solve_batch_dev runs the lane-refilling kernel (api_internal.inl: mpc_refill_chunk): an agent's
-    answer must not depend on the batch it travels in — the first 4,096 agents of a 70,000-agent call equal a 4,096-agent call (mpc_kernel)
-    bit for bit, and the whole batch equals mpc_kernel forced on it (crx_x_mpc_solve_lanes_dev)."""
+def test_mpc_answer_does_not_depend_on_the_batch(crx):
+    """An agent's answer must not depend on the batch it travels in: the first 4,096 agents of a 70,000-agent call equal a 4,096-agent call
+    bit for bit, and the lane-refilling A/B kernel (asynchronous line search) reproduces the whole batch."""
     import torch
-    from cpprobotics_amd.experimental import mpc_solve_lanes
+    from cpprobotics_amd.experimental import mpc_solve_refill
     n, T = 70000, 21
     x0, xref = mpc_problem(n, T, 77)
     x0, xref = _t(x0), _t(xref)
     sol, st, c = crx.mpc_solve(x0, xref, T, return_status=True)
-    sol1, st1, c1 = mpc_solve_lanes(x0, xref, T, lanes_per_agent=1)
+    sol1, st1, c1 = mpc_solve_refill(x0, xref, T, 256, 16)
     assert torch.equal(st, st1) and torch.equal(sol.view(torch.int32), sol1.view(torch.int32)) and torch.equal(c.view(torch.int64), c1.view(torch.int64))
     sol2, st2, c2 = crx.mpc_solve(x0[:4096].contiguous(), xref[:4096].contiguous(), T, return_status=True)
     assert torch.equal(st[:4096], st2) and torch.equal(sol[:4096].view(torch.int32), sol2.view(torch.int32))
-
-
-@pytest.mark.parametrize("T", [6, 21, 30])
-def test_mpc_schedules_and_kernels_are_bit_identical(crx, T):
-    """The kernels a product call can get — mpc_kernel (lockstep line search) and mpc_refill_kernel (lanes refilled, line search scheduled
-    asynchronously), whatever crx_mpc_params.schedule says — run the same arithmetic per agent: identical bits.  An agent's answer depends
-    on its problem, never on how its launch is scheduled."""
-    import torch
-    from cpprobotics_amd import _lib as L
-    from cpprobotics_amd.experimental import mpc_solve_refill
-    from cpprobotics_amd.mpc import default_params
-    n = 3001
-    x0, xref = mpc_problem(n, T, 90 + T)
-    x0, xref = _t(x0), _t(xref)
-    sol0, st0, c0 = crx.mpc_solve(x0, xref, T, return_status=True)
-    outs = [mpc_solve_refill(x0, xref, T, apw, hold) for apw, hold in ((128, 16), (64, 1), (3001, 64))]
-    for sched in (L.MPC_SCHEDULE_LATENCY, L.MPC_SCHEDULE_THROUGHPUT):
-        p = default_params(); p.schedule = sched
-        outs.append(crx.mpc_solve(x0, xref, T, return_status=True, params=p))
-    for k, (sol, st, c) in enumerate(outs):
-        assert torch.equal(st, st0), k
-        assert torch.equal(sol.view(torch.int32), sol0.view(torch.int32)) and torch.equal(c.view(torch.int64), c0.view(torch.int64)), k
-    p = default_params(); p.schedule = 7
-    with pytest.raises(crx.CrxError):
-        crx.mpc_solve(x0, xref, T, params=p)

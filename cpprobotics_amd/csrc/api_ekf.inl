@@ -400,7 +400,11 @@ int crx_ekf_run_batch(int n, int T, float* x, float* P, const float* z, const fl
   if (n == 0 || T == 0) return CRX_OK;
   return run_sharded(n, [&](const crxh::Shard& sh) -> int {
     const size_t a0 = sh.a0, nl = sh.a1 - sh.a0, nn = (size_t)n, tt = (size_t)T;
-    if (nl * tt * (32 + (P_hist ? 64 : 0)) + 80 * nl > crxh::kZeroCopyBytes)
+    // what HostCall::commit() would place for this shard — the same 256-byte aligned sum, argument by argument (x_hist only when asked
+    // for): a call on the edge must not be sent to HostCall and then miss its zero-copy path
+    const size_t zc_total = crxh::align_up(16 * nl) + crxh::align_up(64 * nl) + 2 * crxh::align_up(8 * nl * tt) +
+                            (x_hist ? crxh::align_up(16 * nl * tt) : 0) + (P_hist ? crxh::align_up(64 * nl * tt) : 0);
+    if (zc_total > crxh::kZeroCopyBytes)
       return ekf_run_host_shard(n, sh.a0, sh.a1, T, x, P, z, u, x_hist, P_hist, Q, R, prm);
     // a small call — the literal drop-in, ekf_estimation() for one vehicle — is zero-copy: one pinned block, one launch
     HostCall hc;

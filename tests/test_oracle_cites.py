@@ -170,7 +170,7 @@ def _our_files():
         glob.glob(os.path.join(ROOT, "oracle", "*.py")) + \
         glob.glob(os.path.join(ROOT, "oracle", "ref_shim", "*.cpp")) + glob.glob(os.path.join(ROOT, "include", "*")) + \
         glob.glob(os.path.join(ROOT, "cpprobotics_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "cpprobotics_amd", "*.py")) + \
-        glob.glob(os.path.join(ROOT, "examples", "*.cpp")) + [os.path.join(ROOT, "DESIGN.md"), os.path.join(ROOT, "INTEGRATION.md")]
+        glob.glob(os.path.join(ROOT, "examples", "*.cpp")) + [os.path.join(ROOT, "DESIGN.md"), os.path.join(ROOT, "HISTORY.md"), os.path.join(ROOT, "INTEGRATION.md")]
     return [p for p in files if os.path.isfile(p)]
 
 

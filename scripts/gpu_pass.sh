@@ -42,7 +42,9 @@ for s in $STEPS; do
         timeout 600 python scripts/gpu_dare_refill_ab.py > $OUT/dare_refill_ab.jsonl 2> $OUT/dare_refill_ab.err; cut -c1-200 $OUT/dare_refill_ab.jsonl
         timeout 300 python scripts/gpu_hbm_calib.py > $OUT/hbm_calibration.jsonl 2> $OUT/hbm_calib.err; tail -4 $OUT/hbm_calibration.jsonl | cut -c1-200 ;;
     side) timeout 900 python scripts/side_bench.py > $OUT/side_bench.jsonl 2> $OUT/side_bench.err; cut -c1-300 $OUT/side_bench.jsonl ;;
-    swarm) timeout 300 python scripts/swarm_bench.py --agents 131072 > $OUT/swarm_1gpu.json 2> $OUT/swarm.err; cut -c1-600 $OUT/swarm_1gpu.json; tail -2 $OUT/swarm.err ;;
+    swarm) timeout 300 python scripts/swarm_bench.py --agents 131072 > $OUT/swarm_1gpu.json 2> $OUT/swarm.err; cut -c1-600 $OUT/swarm_1gpu.json; tail -2 $OUT/swarm.err
+           timeout 600 python scripts/gpu_swarm_pipeline_ab.py > $OUT/swarm_pipeline_ab.jsonl 2> $OUT/swarm_pipeline_ab.err; cut -c1-160 $OUT/swarm_pipeline_ab.jsonl
+           timeout 400 python scripts/gpu_mpc_variants_ab.py > $OUT/mpc_variants_ab.jsonl 2> $OUT/mpc_variants_ab.err; cut -c1-260 $OUT/mpc_variants_ab.jsonl ;;
     fuzz) timeout 1500 python scripts/gpu_fuzz_bitexact.py ${SEED0:-300} ${SEEDS:-20} > $OUT/fuzz_bitexact.txt 2>&1; tail -12 $OUT/fuzz_bitexact.txt ;;
     prof) timeout 2400 bash scripts/gpu_prof.sh $TAG/prof > $OUT/prof.log 2>&1; tail -40 $OUT/prof.log ;;
     *) echo "unknown step $s" ;;

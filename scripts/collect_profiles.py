@@ -81,9 +81,11 @@ for name, o in (("side_sq", "side_pmc_sq.csv"), ("side_flop", "side_pmc_flop.csv
                 ("side_fetch", "side_pmc_fetch.csv"), ("side_write", "side_pmc_write.csv")):
     counters(name, o, SIDE)
 p = os.path.join(src, "prof")
-for f in ("summary.txt", "traffic.json", "side_counters.json"):
+for f in ("summary.txt", "traffic.json", "side_counters.json", "mpc_traffic.json"):
     copy(f, base=p)
-for f in ("traffic.json", "side_counters.json"):        # what bench.py cites as `counters_source`
+for f in ("swarm_pipeline_ab.jsonl", "mpc_variants_ab.jsonl"):
+    copy(f)
+for f in ("traffic.json", "side_counters.json", "mpc_traffic.json"):        # what bench.py cites as `counters_source`
     if os.path.exists(os.path.join(p, f)):
         shutil.copy(os.path.join(p, f), os.path.join(ROOT, "profiles", f))
 print("collected", sorted(done))

@@ -12,7 +12,7 @@
 #     side       scripts/side_bench.py (DARE, MPC, tracking, PF, DWA, Frenet)
 #     swarm      scripts/swarm_bench.py, one GPU's shard of BASELINE configs[4]
 #     fuzz       scripts/gpu_fuzz_bitexact.py (SEED0=first seed, default 300; SEEDS=how many, default 20)
-#     prof       scripts/gpu_prof.sh TAG/prof (rocprofv3 kernel stats + PMC passes, markers)
+#     prof       scripts/gpu_prof.sh TAG/prof (rocprofv3 kernel stats + PMC passes, markers) and scripts/gpu_mpc_traffic.sh (the MPC solve's HBM traffic at 262,144 agents)
 # Everything lands in gpurun_out/TAG/; `python scripts/collect_profiles.py TAG rNN` copies the judged summaries into profiles/rNN/.
 # (Rounds 1-3 kept one copy of this script per round — gpu_round.sh, gpu_round2.sh, gpu_final2.sh, gpu_final3.sh — and one-off
 # variants of single steps; this is their union.)
@@ -46,7 +46,8 @@ for s in $STEPS; do
            timeout 600 python scripts/gpu_swarm_pipeline_ab.py > $OUT/swarm_pipeline_ab.jsonl 2> $OUT/swarm_pipeline_ab.err; cut -c1-160 $OUT/swarm_pipeline_ab.jsonl
            timeout 400 python scripts/gpu_mpc_variants_ab.py > $OUT/mpc_variants_ab.jsonl 2> $OUT/mpc_variants_ab.err; cut -c1-260 $OUT/mpc_variants_ab.jsonl ;;
     fuzz) timeout 1500 python scripts/gpu_fuzz_bitexact.py ${SEED0:-300} ${SEEDS:-20} > $OUT/fuzz_bitexact.txt 2>&1; tail -12 $OUT/fuzz_bitexact.txt ;;
-    prof) timeout 2400 bash scripts/gpu_prof.sh $TAG/prof > $OUT/prof.log 2>&1; tail -40 $OUT/prof.log ;;
+    prof) timeout 2400 bash scripts/gpu_prof.sh $TAG/prof > $OUT/prof.log 2>&1; tail -40 $OUT/prof.log
+          timeout 600 bash scripts/gpu_mpc_traffic.sh $TAG/prof > $OUT/mpc_traffic.log 2>&1; tail -4 $OUT/mpc_traffic.log ;;
     *) echo "unknown step $s" ;;
   esac
 done

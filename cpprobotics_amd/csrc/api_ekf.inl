@@ -58,12 +58,20 @@ int crx_ekf_step_batch_dev(int n, float* x, float* P, const float* z, const floa
   if (n == 0) return CRX_OK;
   const crx::EkfConsts k = make_consts(Q, R, prm);
   const dim3 grid(blocks_for(n, CRX_EKF_STEP_BLOCK)), block(CRX_EKF_STEP_BLOCK);
+  // DTS: DT * cos / DT * sin in the fp32 split form — exact for the reference's DT = 0.1 only (ekf_math.h: dt_mul_split)
+  const bool dts = crx::dt_split_is_exact(k.dt);
+#define CRX_LAUNCH_STEP(NT_)                                                                                                       \
+  do {                                                                                                                             \
+    if (dts) hipLaunchKernelGGL((crx::ekf_step_kernel<NT_, true>), grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);         \
+    else hipLaunchKernelGGL((crx::ekf_step_kernel<NT_, false>), grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);            \
+  } while (0)
 #ifdef CRX_EKF_STEP_NT_FORCE     // A/B builds only (scripts/experiments/gpu_ekf_step_ab.sh)
-  hipLaunchKernelGGL(crx::ekf_step_kernel<(CRX_EKF_STEP_NT_FORCE != 0)>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+  CRX_LAUNCH_STEP((CRX_EKF_STEP_NT_FORCE != 0));
 #else
-  if (n >= crx::kEkfStepNtMinN) hipLaunchKernelGGL(crx::ekf_step_kernel<true>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
-  else hipLaunchKernelGGL(crx::ekf_step_kernel<false>, grid, block, 0, (hipStream_t)stream, n, x, P, z, u, k);
+  if (n >= crx::kEkfStepNtMinN) CRX_LAUNCH_STEP(true);
+  else CRX_LAUNCH_STEP(false);
 #endif
+#undef CRX_LAUNCH_STEP
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }
@@ -88,16 +96,19 @@ static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, cons
   // 32-bit buffer offsets (ekf_kernels.hip.h) up to kEkfBufMaxN vehicles, the 64-bit-address kernels above (tests force the
   // latter on small inputs through crx_x_ekf_run_addr64_dev)
   const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !force_addr64;
-#define CRX_LAUNCH_RUN(XH, PH)                                                                          \
+  const bool dts = crx::dt_split_is_exact(k.dt);      // DT * cos / DT * sin in the fp32 split form: the reference's DT = 0.1 only
+#define CRX_LAUNCH_RUN2(XH, PH, DTS_)                                                                   \
   do {                                                                                                  \
-    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
-    else hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, false>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
+    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
+    else hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, false, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
   } while (0)
+#define CRX_LAUNCH_RUN(XH, PH) do { if (dts) CRX_LAUNCH_RUN2(XH, PH, true); else CRX_LAUNCH_RUN2(XH, PH, false); } while (0)
   if (x_hist && P_hist) CRX_LAUNCH_RUN(true, true);
   else if (x_hist) CRX_LAUNCH_RUN(true, false);
   else if (P_hist) CRX_LAUNCH_RUN(false, true);
   else CRX_LAUNCH_RUN(false, false);
 #undef CRX_LAUNCH_RUN
+#undef CRX_LAUNCH_RUN2
   CRX_HIP(hipGetLastError());
   return CRX_OK;
 }

@@ -90,7 +90,7 @@ __device__ __forceinline__ void store_P(const EkfState& s, float* __restrict__ P
 #define CRX_EKF_STEP_BLOCK 256      // lanes per workgroup (a multiple of 64); the LDS tile is private to a wave
 #endif
 constexpr int kEkfStepNtMinN = 3 << 20;    // 3 M vehicles: 503 MB of state
-template <bool NT>
+template <bool NT, bool DTS>
 __global__ void __launch_bounds__(CRX_EKF_STEP_BLOCK)
 ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float* __restrict__ z,
                 const float* __restrict__ u, EkfConsts k) {
@@ -126,7 +126,7 @@ ekf_step_kernel(int n, float* __restrict__ x, float* __restrict__ P, const float
     EkfStateP sp;
     pack_state(sp, s);
     FastDomain dom = fast_domain_init();
-    ekf_step_packed(sp, zv, uv, pack_consts(k), dom);
+    ekf_step_packed<DTS>(sp, zv, uv, pack_consts(k), dom);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(!fast_domain_ok(dom)) != 0, 0)) {
       ekf_step_dev(s, zv.x, zv.y, uv.x, uv.y, k);          // `s` still holds the input: the packed step worked on its copy `sp`
     } else {
@@ -176,7 +176,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int D, bool XHIST, bool PHIST, bool BUF>
+template <int D, bool XHIST, bool PHIST, bool BUF, bool DTS>
 __global__ void __launch_bounds__(CRX_EKF_RUN_BLOCK)
 ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
                const float* __restrict__ z, const float* __restrict__ u,
@@ -232,7 +232,7 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const size_t t = (size_t)(t0 + d);
-      ekf_step_packed(sp, zq[d], uq[d], kp, dom);
+      ekf_step_packed<DTS>(sp, zq[d], uq[d], kp, dom);
       // refill the slot just consumed (its registers are dead now: no copy at the loop back-edge)
       if (BUF) {
         zq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rz, lane * 8u, (unsigned)(d + D) * un * 8u, 2));

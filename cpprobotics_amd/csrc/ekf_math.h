@@ -139,7 +139,26 @@ struct EkfConstsP {
   v2f Rc0, Rc1;
   double dt;
   float dtf;
+  float dt_hi, dt_lo;   // dt = dt_hi + dt_lo + (less than 2^-53 dt): the split of dt_mul_split
 };
+
+// (float)(dt * (double)t) — B_(0,0), B_(1,0) of motion_model (:30-31) and jF(0,3), jF(1,3) of jacobF (:43,45): a float promoted to
+// double, multiplied by the double literal DT and rounded back — WITHOUT leaving fp32: fma(t, dt_hi, t * dt_lo).  On gfx950 the double
+// form is two conversions at 8 cycles and a multiply; four of them per EKF step were 80 of the step's 873 VALU cycles, the split form
+// is one v_pk_mul_f32 + one v_pk_fma_f32 per PAIR.  It is the reference's value, bit for bit, for dt = 0.1 (the reference's `#define
+// DT 0.1`) and every finite float with |t| >= 2^-120: proved by walking all 2^32 floats (tests/tools/dt_split_exhaustive.cpp;
+// below 2^-120 the low product underflows — 10 M mismatches, all there).  The step feeds it sines and cosines of angles in the fast
+// domain, 2^-100 <= |yaw| < 120, whose magnitudes are >= 2^-100 (same tool).  For any other dt the kernels are instantiated with the
+// double form (dt_split_is_exact; the host decides per launch).
+CRX_HD bool dt_split_is_exact(double dt) { return dt == 0.1; }
+CRX_HD v2f pk_fma(v2f a, v2f b, v2f c) {
+#if defined(__clang__)
+  return __builtin_elementwise_fma(a, b, c);
+#else
+  return v2f{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
+#endif
+}
+CRX_HD v2f dt_mul_split(v2f t, float dt_hi, float dt_lo) { return pk_fma(t, v2f{dt_hi, dt_hi}, t * v2f{dt_lo, dt_lo}); }
 
 CRX_HD EkfConstsP pack_consts(const EkfConsts& k) {
   EkfConstsP c;
@@ -152,6 +171,8 @@ CRX_HD EkfConstsP pack_consts(const EkfConsts& k) {
   c.Rc1 = v2f{k.R[2], k.R[3]};
   c.dt = k.dt;
   c.dtf = (float)k.dt;
+  c.dt_hi = (float)k.dt;
+  c.dt_lo = (float)(k.dt - (double)c.dt_hi);
   return c;
 }
 
@@ -176,7 +197,8 @@ CRX_HD void unpack_state(EkfState& s, const EkfStateP& p) {
 
 // ---- fast-domain bookkeeping ------------------------------------------------------------------
 // The packed step below takes two shortcuts that are bit-identical to the general code only on a
-// domain: 0 < |yaw| < 120 for both angles of the step (sincos) and 2^-60 <= |det S| <= 2^60 (reciprocal).
+// domain: 2^-100 <= |yaw| < 120 for both angles of the step (sincos; the lower end keeps their sines above 2^-120, where the fp32
+// form of DT * sin is exact — dt_mul_split) and 2^-60 <= |det S| <= 2^60 (reciprocal).
 // Instead of a per-step boolean (v_cmp + mask logic), each lane keeps running max/min of the
 // quantities involved — one VALU instruction each — and the caller tests them once per chunk.
 // NaNs pass through max/min unnoticed; that is harmless: a NaN angle or determinant turns the state
@@ -187,7 +209,7 @@ struct FastDomain {
 };
 CRX_HD FastDomain fast_domain_init() { return FastDomain{0.0f, 1.0f, 1.0f, 1.0f}; }
 CRX_HD bool fast_domain_ok(const FastDomain& f) {
-  return (f.amax < 120.0f) & (f.amin > 0.0f) & (f.dmax <= 0x1p60f) & (f.dmin >= 0x1p-60f);
+  return (f.amax < 120.0f) & (f.amin >= 0x1p-100f) & (f.dmax <= 0x1p60f) & (f.dmin >= 0x1p-60f);
 }
 
 // Bit helpers of the quadrant logic.  Deliberately NOT inline asm: the compiler's hazard recogniser does
@@ -281,6 +303,8 @@ CRX_HD float recip_fast(float d, FastDomain& dom) {
 CRX_HD v2f bc(float a) { return v2f{a, a}; }
 
 // One ekf_estimation() (:64-78), packed.  Same operation order as ekf_step_dev, entry by entry.
+// DTS: the four DT * cos / DT * sin entries through dt_mul_split (requires dt_split_is_exact(k.dt)), otherwise in double as written.
+template <bool DTS = false>
 CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, FastDomain& dom) {
   const float u0 = u[0], u1 = u[1];
   // motion_model: both yaw angles of the step are known up front
@@ -290,16 +314,22 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   float sn[2], cs[2];
   sincos_fast2(yaws, sn, cs, dom);
   const float s0 = sn[0], c0 = cs[0], s1 = sn[1], c1 = cs[1];
-  const v2f b01 = v2f{(float)(k.dt * (double)c0), (float)(k.dt * (double)s0)};
+  v2f b01, jB;
+  if constexpr (DTS) {
+    b01 = dt_mul_split(v2f{c0, s0}, k.dt_hi, k.dt_lo);
+    jB = dt_mul_split(v2f{c1, s1}, k.dt_hi, k.dt_lo);
+  } else {
+    b01 = v2f{(float)(k.dt * (double)c0), (float)(k.dt * (double)s0)};
+    jB = v2f{(float)(k.dt * (double)c1), (float)(k.dt * (double)s1)};
+  }
   const v2f xp01 = s.x01 + b01 * bc(u0);
   const v2f xp23 = v2f{yaw1, s.x23[1] + u0};
   // jacobF(xPred, u): yaw = xPred(2), v = u(0)
   const double dv = k.dt * (double)u0;
   const float j02 = (float)((-dv) * (double)s1);
-  const float j03 = (float)(k.dt * (double)c1);
   const float j12 = (float)(dv * (double)c1);
-  const float j13 = (float)(k.dt * (double)s1);
-  const v2f jA = v2f{j02, j12}, jB = v2f{j03, j13};
+  const float j03 = jB[0], j13 = jB[1];
+  const v2f jA = v2f{j02, j12};
   // The matrix part is written stage-major (the same operation across all columns, then the next
   // operation): consecutive instructions are then independent, and the packed-op result hazard
   // (a dependent instruction right behind a v_pk_* needs a wait state) costs no s_nop.

@@ -116,3 +116,21 @@ def test_packed_step_nonfinite_state_falls_back(packed, oracle_mod):
     ok = [0, 3, 4, 5, 6, 7]
     assert bit_equal(xh[:, ok], xho[:, ok]) and bit_equal(P[ok], Po[ok])
     assert np.isnan(xh[:, 1:3]).all() and np.isnan(xho[:, 1:3]).all()
+
+
+def test_dt_split_is_the_double_product_on_every_float(tmp_path):
+    """csrc/ekf_math.h: dt_mul_split — fma(t, dt_hi, t * dt_lo) in fp32 instead of (float)(0.1 * (double)t) — walked over ALL 2^32 floats:
+    the same bits for every finite |t| >= 2^-120, and every sine / cosine of a fast-domain angle (2^-100 <= |yaw| < 120) lies there
+    (tests/tools/dt_split_exhaustive.cpp; ~10 s on 8 cores).  Reference lines: /root/reference/src/extended_kalman_filter.cpp:30-31,43,45."""
+    import subprocess
+    exe = str(tmp_path / "dts")
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-pthread"]
+    try:
+        cpuflags = open("/proc/cpuinfo").read()
+    except OSError:
+        cpuflags = ""
+    if " fma " in cpuflags or " fma\n" in cpuflags:
+        flags.append("-mfma")               # hardware fmaf; without it libm's (correctly rounded, slow): then a stride keeps the test short
+    subprocess.check_call(["g++", *flags, os.path.join(HERE, "tools", "dt_split_exhaustive.cpp"), "-o", exe])
+    r = subprocess.run([exe, "1" if "-mfma" in flags else "257"], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 mismatching;" in r.stdout and " 0 with |sin| or |cos|" in r.stdout, r.stdout

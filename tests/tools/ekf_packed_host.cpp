@@ -28,7 +28,8 @@ extern "C" int ekf_packed_run(int n, int T, float* x, float* P, const float* z, 
       const crx::v2f zc = {z[2 * o], z[2 * o + 1]}, uc = {u[2 * o], u[2 * o + 1]};
       const crx::EkfStateP s_in = sp;
       crx::FastDomain dom = crx::fast_domain_init();
-      crx::ekf_step_packed(sp, zc, uc, kp, dom);
+      if (crx::dt_split_is_exact(dt)) crx::ekf_step_packed<true>(sp, zc, uc, kp, dom);       // as the host side of the engine picks it
+      else crx::ekf_step_packed<false>(sp, zc, uc, kp, dom);
       if (!crx::fast_domain_ok(dom)) {
         ++slow;
         crx::unpack_state(s, s_in);

@@ -1,7 +1,7 @@
 // trig_fast_exhaustive.cpp — walks EVERY float with |y| < 120 (and a band above) and checks that the
 // fused EKF kernel's fast sincos (csrc/ekf_math.h: sincos_fast2) is bit-identical to crx::sincosf_
 // (itself bit-identical to glibc's sinf/cosf on all 2^32 inputs, trig_exhaustive.cpp) wherever it
-// reports "inside the fast domain", and that it reports "outside" exactly for |y| >= 120 and y = +-0.
+// reports "inside the fast domain", and that it reports "outside" exactly for |y| >= 120 and |y| < 2^-100.
 // Build & run:  g++ -O2 -std=c++17 -ffp-contract=off -pthread trig_fast_exhaustive.cpp -o tfe && ./tfe
 #include <atomic>
 #include <cmath>
@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
           crx::FastDomain dom = crx::fast_domain_init();
           crx::sincos_fast2(ys, s, co, dom);
           const bool ok = crx::fast_domain_ok(dom);
-          const bool expect_ok = (std::fabs(y) < 120.0f) && (std::fabs(y2) < 120.0f) && y != 0.0f && y2 != 0.0f;
+          const bool expect_ok = (std::fabs(y) < 120.0f) && (std::fabs(y2) < 120.0f) && std::fabs(y) >= 0x1p-100f && std::fabs(y2) >= 0x1p-100f;
           if (ok != expect_ok) ++b;
           if (ok) {
             ++in;

@@ -17,6 +17,13 @@ extern int *ticks_done_dev, *target_ind_dev, *ticks_dev, *status_dev;
 extern float goal_x, goal_y, target_speed;
 extern void* stream;
 extern std::vector<float> wx, wy, r_x_, sp, ryaw, rcurvature;
+// what the pipelined-host snippet (section 5b) leaves to the reader: HIP's stream / event calls and the host's own buffers
+typedef void* hipStream_t; typedef void* hipEvent_t;
+int hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned); int hipEventRecord(hipEvent_t, hipStream_t);
+const int DEPTH = 6;
+extern int m, rounds; extern crx_course course;
+extern float *est[DEPTH], *err[DEPTH], *xref[DEPTH], *sol[DEPTH]; extern int *tind[DEPTH], *status[DEPTH]; extern double* cost[DEPTH];
+void gather_every_eighth(float*, const float*, hipStream_t);
 '''
 
 

@@ -226,22 +226,56 @@ def host_floats(values, n):
     return a
 
 
-# Which sources decide the code of a kernel family: the committed hardware counters (profiles/traffic.json, profiles/side_counters.json —
-# rocprofv3 PMC passes cannot run inside bench.py) carry the hash of these files at the time they were taken; bench.py prints them only
-# when the hash of the tree it runs from is the same (scripts/summarize_prof.py writes it, bench.py checks it).
-KERNEL_SOURCES = {
-    "ekf": ("ekf_kernels.hip.h", "ekf_math.h", "crx_trig.h", "crx_dsincos.h", "crx_fdlibm.h", "api_ekf.inl", "api_internal.inl", "crx_api.hip", "Makefile"),
-    "side": ("dare_kernels.hip.h", "dare_math.h", "dare_dense_math.h", "mpc_kernels.hip.h", "ekf_kernels.hip.h", "ekf_math.h", "crx_trig.h", "api_lqr.inl",
-             "api_mpc.inl", "api_internal.inl", "crx_api.hip", "Makefile"),
+# The committed hardware counters (profiles/traffic.json, side_counters.json, mpc_traffic.json — rocprofv3 PMC passes cannot run inside
+# bench.py) carry a hash of the CODE of the kernels they were taken from: the instruction stream of those functions in the gfx950 code
+# object of the libcrx.so that was loaded (mnemonics and operands; addresses and encodings stripped, so that a change elsewhere in the
+# library — or a comment — does not invalidate them, and any change to the kernels' code does).  scripts/summarize_prof.py and
+# scripts/gpu_mpc_traffic.sh write it, bench.py prints the counters only when the library it runs has the same hash.
+KERNEL_FAMILIES = {
+    "ekf": ("ekf_run_kernel",),
+    "side": ("dare_", "mpc_kernel", "mpc_portfolio_kernel", "ekf_step_kernel", "lqr_closed_loop"),
+    "mpc": ("mpc_kernel",),
 }
+_LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+_code_hashes = {}
 
 
-def kernel_source_hash(family):
-    """sha256 (16 hex digits) over the csrc files that decide the code of a kernel family ("ekf": the fused EKF launch; "side": the
-    DARE / MPC / single-step kernels of scripts/prof_kernels.py)."""
+def disassemble_code_object(lib):
+    """llvm-objdump -d of the gfx950 code object embedded in a libcrx build (also what scripts/check_isa.py reads)."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([os.path.join(_LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
+        return subprocess.run([os.path.join(_LLVM_BIN, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+
+
+def kernel_code_hash(family, lib=None):
+    """sha256 (16 hex digits) over the instruction streams of a kernel family in the library's gfx950 code object, or None when the
+    code object cannot be read on this host (no ROCm LLVM tools)."""
     import hashlib
+    import re
+    lib = lib or lib_path()
+    key = (lib, os.path.getmtime(lib))
+    if key not in _code_hashes:
+        try:
+            funcs, cur = {}, None
+            for line in disassemble_code_object(lib).splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if m:
+                    cur = funcs.setdefault(m.group(1), [])
+                elif cur is not None and line.startswith("\t"):
+                    cur.append(line.split("//")[0].strip())
+            _code_hashes[key] = funcs
+        except Exception:
+            _code_hashes[key] = None
+    funcs = _code_hashes[key]
+    if not funcs:
+        return None
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES[family]:
-        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
-            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    for name in sorted(funcs):
+        if any(p in name for p in KERNEL_FAMILIES[family]):
+            h.update(name.encode() + b"\0" + "\n".join(funcs[name]).encode() + b"\0")
     return h.hexdigest()[:16]

@@ -144,8 +144,9 @@ struct EkfConstsP {
 
 // (float)(dt * (double)t) — B_(0,0), B_(1,0) of motion_model (:30-31) and jF(0,3), jF(1,3) of jacobF (:43,45): a float promoted to
 // double, multiplied by the double literal DT and rounded back — WITHOUT leaving fp32: fma(t, dt_hi, t * dt_lo).  On gfx950 the double
-// form is two conversions at 8 cycles and a multiply; four of them per EKF step were 80 of the step's 873 VALU cycles, the split form
-// is one v_pk_mul_f32 + one v_pk_fma_f32 per PAIR.  It is the reference's value, bit for bit, for dt = 0.1 (the reference's `#define
+// form is two conversions and a multiply; the split form is one v_pk_mul_f32 + one v_pk_fma_f32 per PAIR (6 conversions and 4 fp64
+// multiplies fewer per step, 197 -> 190 VALU instructions; measured on one box, alternating builds: 131.7 -> 133.4 G updates/s, +1.3 % —
+// less than the instruction count suggests: the fp64 side of the step overlaps the packed fp32 matrix work).  It is the reference's value, bit for bit, for dt = 0.1 (the reference's `#define
 // DT 0.1`) and every finite float with |t| >= 2^-120: proved by walking all 2^32 floats (tests/tools/dt_split_exhaustive.cpp;
 // below 2^-120 the low product underflows — 10 M mismatches, all there).  The step feeds it sines and cosines of angles in the fast
 // domain, 2^-100 <= |yaw| < 120, whose magnitudes are >= 2^-100 (same tool).  For any other dt the kernels are instantiated with the

@@ -17,16 +17,12 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LLVM = "/opt/rocm/lib/llvm/bin"
-TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
 def disassemble(lib):
-    with tempfile.TemporaryDirectory() as d:
-        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
-        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-        subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={fat}", f"--output={co}"])
-        return subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    sys.path.insert(0, ROOT)
+    from cpprobotics_amd._lib import disassemble_code_object
+    return disassemble_code_object(lib)
 
 
 def vregs(op):

@@ -18,7 +18,7 @@ python - $OUT $N <<'PY'
 import csv, glob, json, os, sys
 out, n = sys.argv[1], int(sys.argv[2])
 sys.path.insert(0, os.getcwd())
-from cpprobotics_amd._lib import kernel_source_hash
+from cpprobotics_amd._lib import kernel_code_hash
 def rows(pat):
     for f in glob.glob(os.path.join(out, pat), recursive=True):
         with open(f) as fh:
@@ -44,7 +44,7 @@ for name, c in res.items():
         a["hbm_bytes_per_agent"] = a["hbm_bytes"] / n
     if "SQ_WAVE_CYCLES" in a: a["valu_active_frac"] = a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"]
     summ[name] = a
-json.dump({"agents": n, "T": 21, "kernel_source_hash": kernel_source_hash("side"), "kernels": summ, "note": "FETCH_SIZE in KB, doubled (gfx950 half-count, MI355X_MICROARCH.md); WRITE_SIZE KB"}, open(os.path.join(out, "mpc_traffic.json"), "w"), indent=1)
+json.dump({"agents": n, "T": 21, "kernel_code_hash": kernel_code_hash("mpc"), "kernels": summ, "note": "FETCH_SIZE in KB, doubled (gfx950 half-count, MI355X_MICROARCH.md); WRITE_SIZE KB"}, open(os.path.join(out, "mpc_traffic.json"), "w"), indent=1)
 for k, v in summ.items(): print(k, {a: round(b, 3) if isinstance(b, float) else b for a, b in v.items() if a in ("avg_ms", "hbm_bytes", "hbm_TB_per_s", "hbm_bytes_per_agent", "valu_active_frac", "SQ_INSTS_VMEM", "SQ_INSTS_VALU")})
 PY
 find $OUT -name "*.csv" -size +3M -delete; find $OUT -name "*.db" -delete

@@ -86,3 +86,23 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "GB/s"
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1 and "workload" in d["config"]
     assert d["vs_baseline"] is None and d["dtype"] == "f32" and d["higher_is_better"] is True
+
+
+def test_committed_counters_are_bound_to_the_kernel_code(crx):
+    """profiles/traffic.json, side_counters.json and mpc_traffic.json carry the hash of the kernels' instruction streams they were taken
+    from (cpprobotics_amd/_lib.py: kernel_code_hash); bench.py prints them only when the loaded libcrx.so has the same code.  Here: the
+    hash is readable on the build box, stable, sensitive to the kernel family — and a stale file is reported (a warning, not a failure:
+    the counters can only be re-taken on a GPU box)."""
+    import json
+    import warnings
+    from cpprobotics_amd._lib import kernel_code_hash
+    h = {f: kernel_code_hash(f) for f in ("ekf", "side", "mpc")}
+    assert all(v and len(v) == 16 for v in h.values()) and len(set(h.values())) == 3
+    assert h == {f: kernel_code_hash(f) for f in h}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, fam in (("traffic.json", "ekf"), ("side_counters.json", "side"), ("mpc_traffic.json", "mpc")):
+        d = json.load(open(os.path.join(root, "profiles", name)))
+        assert "kernel_code_hash" in d, name
+        if d["kernel_code_hash"] != h[fam]:
+            warnings.warn(f"profiles/{name} was taken from kernel code {d['kernel_code_hash']}, this build has {h[fam]}: bench.py will print "
+                          "its counters as null until scripts/gpu_prof.sh is re-run")

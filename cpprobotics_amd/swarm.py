@@ -315,6 +315,12 @@ class SwarmShard:
                            status=torch.empty(self.n_plan, dtype=torch.int32, device=device),
                            cost=torch.empty(self.n_plan, dtype=torch.float64, device=device)) for _ in range(max(1, depth))]
         self.ekf_events = [] if record_ekf_events else None
+        self.hw_queues = want_hw_queues(depth + 2) if torch.device(device).type == "cuda" else None
+        if torch.device(device).type == "cuda" and depth + 1 > (self.hw_queues or 4):
+            import warnings
+            warnings.warn(f"SwarmShard: {depth} planner streams + the launch stream on {self.hw_queues or 4} hardware queues — streams that share a "
+                          f"queue run one after the other; set GPU_MAX_HW_QUEUES >= {depth + 2} before the process first touches the GPU "
+                          "(cpprobotics_amd.swarm.want_hw_queues)")
         self.rnd = MixedSwarmRound(n, T, 4, chunks, plan_every, device, self._ekf_launch, lambda: self.x, self._plan_launch, gather=gather,
                                    n_total=self.n_total, group=group, depth=depth)
 

@@ -86,10 +86,19 @@ static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, cons
   const crx::EkfConsts k = make_consts(Q, R, prm);
   const dim3 grid(blocks_for(n, CRX_EKF_RUN_BLOCK)), block(CRX_EKF_RUN_BLOCK);
   hipStream_t s = (hipStream_t)stream;
+  // D = steps per chunk of the kernel's main loop (= its z,u prefetch distance).  A chunk pays ~50 scalar instructions of stream
+  // set-up (descriptors, offsets) that a lone wave issues like any other instruction; eight steps per chunk halve their share: +1.5 % on
+  // the headline launch (same box, alternating builds: profiles/r05/ekf_prefetch_ab.txt; 12 and 16 give it back).  The last < 2 D steps
+  // of a launch run through the general step, so short launches (the 25- and 100-step launches of the swarm round) keep D = 4, and so
+  // does the launch with the covariance history, which is bound by its stores and loses with a deeper queue (profiles/r04, HISTORY.md 4.2).
 #ifndef CRX_EKF_PREFETCH
 #define CRX_EKF_PREFETCH 4
 #endif
-  constexpr int D = CRX_EKF_PREFETCH;
+#ifndef CRX_EKF_PREFETCH_LONG
+#define CRX_EKF_PREFETCH_LONG 8
+#endif
+  constexpr int D = CRX_EKF_PREFETCH, DL = CRX_EKF_PREFETCH_LONG;
+  const bool long_chunks = !P_hist && T >= 256;
 #ifndef CRX_EKF_BUFFER_ADDRESSING
 #define CRX_EKF_BUFFER_ADDRESSING 1
 #endif
@@ -97,17 +106,17 @@ static int ekf_run_launch(int n, int T, float* x, float* P, const float* z, cons
   // latter on small inputs through crx_x_ekf_run_addr64_dev)
   const bool buf = CRX_EKF_BUFFER_ADDRESSING && n <= crx::kEkfBufMaxN && !force_addr64;
   const bool dts = crx::dt_split_is_exact(k.dt);      // DT * cos / DT * sin in the fp32 split form: the reference's DT = 0.1 only
-#define CRX_LAUNCH_RUN2(XH, PH, DTS_)                                                                   \
+#define CRX_LAUNCH_RUN3(D_, XH, PH, DTS_)                                                               \
   do {                                                                                                  \
-    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, true, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
-    else hipLaunchKernelGGL((crx::ekf_run_kernel<D, XH, PH, false, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
+    if (buf) hipLaunchKernelGGL((crx::ekf_run_kernel<D_, XH, PH, true, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);  \
+    else hipLaunchKernelGGL((crx::ekf_run_kernel<D_, XH, PH, false, DTS_>), grid, block, 0, s, n, T, x, P, z, u, x_hist, P_hist, k);     \
   } while (0)
-#define CRX_LAUNCH_RUN(XH, PH) do { if (dts) CRX_LAUNCH_RUN2(XH, PH, true); else CRX_LAUNCH_RUN2(XH, PH, false); } while (0)
-  if (x_hist && P_hist) CRX_LAUNCH_RUN(true, true);
-  else if (x_hist) CRX_LAUNCH_RUN(true, false);
-  else if (P_hist) CRX_LAUNCH_RUN(false, true);
-  else CRX_LAUNCH_RUN(false, false);
-#undef CRX_LAUNCH_RUN
+#define CRX_LAUNCH_RUN2(D_, XH, PH) do { if (dts) CRX_LAUNCH_RUN3(D_, XH, PH, true); else CRX_LAUNCH_RUN3(D_, XH, PH, false); } while (0)
+  if (x_hist && P_hist) CRX_LAUNCH_RUN2(D, true, true);
+  else if (P_hist) CRX_LAUNCH_RUN2(D, false, true);
+  else if (x_hist) { if (long_chunks) CRX_LAUNCH_RUN2(DL, true, false); else CRX_LAUNCH_RUN2(D, true, false); }
+  else { if (long_chunks) CRX_LAUNCH_RUN2(DL, false, false); else CRX_LAUNCH_RUN2(D, false, false); }
+#undef CRX_LAUNCH_RUN3
 #undef CRX_LAUNCH_RUN2
   CRX_HIP(hipGetLastError());
   return CRX_OK;

@@ -204,7 +204,23 @@ class MixedSwarmRound:
         self.plan_done = [torch.cuda.Event() for _ in range(self.depth)] if self.cuda else None
         self._plans = [None] * self.depth
         self.round = 0
-        self.final = None
+        # gather="final": the all-gather of round r's final estimates runs asynchronously (RCCL's stream on GPUs) out of a snapshot of the
+        # state — the next round resets it — into the slot's own buffer, and is waited for only when the slot comes round again (or in
+        # wait()): a synchronous gather in front of every round would stall the launch stream once per round (one rank, RCCL: 0.79 ms per
+        # round against 0.47 without any gather).  Equal shards; ragged shards fall back to the synchronous gather_agents.
+        self._final_async = gather == "final" and dist.is_initialized() and len(set(shard_sizes(self.n_total, self.world))) == 1
+        if self._final_async:
+            self._final_src = [torch.empty((n_local, C), dtype=torch.float32, device=device) for _ in range(self.depth)]
+            self._final_out = [torch.empty((self.n_total, C), dtype=torch.float32, device=device) for _ in range(self.depth)]
+            self._final_work = [None] * self.depth
+        self._final_sync = None
+
+    @property
+    def final(self):
+        """[n_total, C]: the gathered final estimates of the most recent round (gather="final"; valid after wait())."""
+        if not self._final_async:
+            return self._final_sync
+        return self._final_out[(self.round - 1) % self.depth] if self.round else None
 
     @property
     def plans(self):
@@ -238,14 +254,24 @@ class MixedSwarmRound:
                 self.plan_done[slot].record(ps)
         else:
             self._plans[slot] = self.plan_launch(self.est[slot], slot)
-        if self.gather_kind == "final" and dist.is_initialized():
-            self.final = gather_agents(x, self.n_total, self.group)
+        if self._final_async:
+            if self._final_work[slot] is not None:
+                self._final_work[slot].wait()               # round r - depth's gather has left this slot's buffers
+            self._final_src[slot].copy_(x)
+            self._final_work[slot] = _all_gather_into(self._final_out[slot], self._final_src[slot], self.group, async_op=True)
+        elif self.gather_kind == "final" and dist.is_initialized():
+            self._final_sync = gather_agents(x, self.n_total, self.group)
         self.round += 1
         return self
 
     def wait(self):
         if self.cg is not None:
             self.cg.wait()
+        if self._final_async:
+            for k, w in enumerate(self._final_work):
+                if w is not None:
+                    w.wait()
+                    self._final_work[k] = None
         if self.cuda:
             for ps in self.plan_streams:
                 torch.cuda.current_stream().wait_stream(ps)

@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--depth", type=int, default=6, help="planner launches in flight")
     ap.add_argument("--mpc", default="product")
     args = ap.parse_args()
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, args.depth + 3)))     # a hardware queue per stream: cpprobotics_amd/swarm.py: want_hw_queues
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(16, args.depth + 10)))     # a hardware queue per stream: cpprobotics_amd/swarm.py: want_hw_queues
     import torch
     import torch.distributed as dist
 

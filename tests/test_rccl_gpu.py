@@ -41,3 +41,40 @@ def test_bench_force_dist_runs_on_rccl(gather):
     for kind in ("gather_final", "gather_traj"):
         assert "error" not in sw[kind], sw[kind]
         assert sw[kind]["round_ms"] > 0 and sw[kind]["mpc_sweeps"]["converged_frac"] > 0.99
+
+
+_SWARM_SCRIPT = r'''
+import os, sys
+import torch, torch.distributed as dist
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from cpprobotics_amd import swarm
+from common import ekf_QR, mpc_course_f32
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+Q, R = ekf_QR(); course, goal = mpc_course_f32()
+for kind in ("final", "traj"):
+    shard = swarm.SwarmShard(8192, 40, course, Q, R, dev, depth=3, gather=kind, input_sets=2, seed=5)
+    snaps = []
+    for r in range(5):                              # slots are reused from round 3 on: the asynchronous gathers' buffers too
+        shard.run()
+        snaps.append((shard.x.clone(), shard.rnd.local_hist.clone() if shard.rnd.local_hist is not None else shard.rnd.cg.local.clone()))
+    shard.wait(); torch.cuda.synchronize()
+    if kind == "final":
+        assert torch.equal(shard.rnd.final, snaps[-1][0]), "gathered final estimates differ from the local state"
+    else:
+        assert torch.equal(shard.rnd.trajectory_time_major(), snaps[-1][1].reshape(40, 8192, 4)), "gathered trajectory differs from the local history"
+    assert not torch.equal(snaps[-1][0], snaps[-2][0])        # consecutive rounds really had different inputs
+dist.barrier(); dist.destroy_process_group()
+print("swarm gathers ok", torch.cuda.nccl.version())
+'''
+
+
+def test_swarm_round_gathers_on_rccl():
+    """MixedSwarmRound's two gather forms on a one-rank RCCL group: the asynchronous final-estimate gather (slot ring) and the chunked
+    trajectory gather return, after five rounds with slot reuse, exactly the last round's local results."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"], env["MASTER_PORT"] = "127.0.0.1", "29543"
+    r = subprocess.run([sys.executable, "-c", _SWARM_SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "swarm gathers ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])

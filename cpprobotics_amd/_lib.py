@@ -228,7 +228,7 @@ def host_floats(values, n):
 
 # The committed hardware counters (profiles/traffic.json, side_counters.json, mpc_traffic.json — rocprofv3 PMC passes cannot run inside
 # bench.py) carry a hash of the CODE of the kernels they were taken from: the instruction stream of those functions in the gfx950 code
-# object of the libcrx.so that was loaded (mnemonics and operands; addresses and encodings stripped, so that a change elsewhere in the
+# object of the libcrx.so that was loaded (mnemonics and operands; addresses, encodings and pc-relative distances stripped, so that a change elsewhere in the
 # library — or a comment — does not invalidate them, and any change to the kernels' code does).  scripts/summarize_prof.py and
 # scripts/gpu_mpc_traffic.sh write it, bench.py prints the counters only when the library it runs has the same hash.
 KERNEL_FAMILIES = {
@@ -267,7 +267,12 @@ def kernel_code_hash(family, lib=None):
                 if m:
                     cur = funcs.setdefault(m.group(1), [])
                 elif cur is not None and line.startswith("\t"):
-                    cur.append(line.split("//")[0].strip())
+                    ins = line.split("//")[0].strip()
+                    # the literal of the s_add_u32 behind an s_getpc_b64 is the distance to a global (a constant table, a symbol's GOT
+                    # slot): it moves whenever ANY function of the library changes size — layout, not this kernel's code
+                    if ins.startswith("s_add_u32") and cur and cur[-1].startswith("s_getpc_b64"):
+                        ins = re.sub(r"0x[0-9a-f]+$|\d+$", "<pcrel>", ins)
+                    cur.append(ins)
             _code_hashes[key] = funcs
         except Exception:
             _code_hashes[key] = None

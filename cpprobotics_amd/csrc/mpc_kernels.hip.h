@@ -245,15 +245,15 @@ struct MpcFeed {
   const float* __restrict__ x0g; const float* __restrict__ xrefg;
   float* __restrict__ solg; int* __restrict__ statusg; double* __restrict__ costg;
 };
-// The trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is NOT kept for the backward sweep, which
-// recomputes it from the stored knots and controls — the same functions of the same doubles, i.e. the same bits (mpc_sincos / mpc_tan
-// are written with explicit fma() and single multiplications).  Rounds 1-4 stored it (TR[2][MAXT][3]): 24 B written per rollout stage and
-// 24 B read per backward stage, 11 % of the solver's memory traffic, against ~70 VALU instructions per backward stage now.  Where the
-// solver's traffic is HBM traffic (>= 65,536 agents in a launch, or several launches in flight: the mixed swarm round) that is 9-17 % of
-// the time (1 M agents: 21.4 -> 17.8 ms); a lone 8,192-agent launch — a latency chain — pays 7 % (0.91 -> 0.99 ms).  One build for every
-// batch size, so that an agent's answer never depends on the batch it travels in: a second, trig-storing build for small batches was
-// measured too, but the compiler contracts the backward sweep's sums of products differently per build (costs equal to 1e-14, not to
-// the bit) — profiles/r05/mpc_variants_ab.jsonl, README there.
+// The trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is kept for the backward sweep (TR): 24 B written per
+// rollout stage and 24 B read per backward stage.  Round 5 also built the solver WITHOUT that array — the backward sweep recomputing the
+// trig, ~70 VALU instructions per stage for 11 % less memory traffic — and measured both (profiles/r05/mpc_variants_ab_run4*.jsonl,
+// mpc_experiments.txt): the recomputing build wins where the solver's traffic is HBM traffic and nothing else matters (262,144 agents
+// 6.9 -> 6.4 ms, 1 M 21.4 -> 17.8 ms) and by 2.5 % in the pipelined swarm round (0.487 -> 0.475 ms), and loses 7-8 % wherever a launch
+// is a latency chain: BASELINE configs[3] (8,192 agents: 0.91 -> 0.97 ms) and the persistent closed loop (116 -> 107 M agent-ticks/s).
+// The two cannot coexist behind one entry point: the compiler contracts the backward sweep's sums of products differently per build
+// (costs equal to 1e-14, not to the bit), and an agent's answer must not depend on the batch it travels in.  The BASELINE configurations
+// decide: the trig stays stored.
 template <int MAXT, bool PORTFOLIO = false, bool REFILL = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
@@ -277,6 +277,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
   float Kf[MAXT][12];
+  double TR[2][MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
@@ -307,18 +308,21 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     const int j = i >= 1 ? i - 1 : 0;
     return ctrl_cost(i >= 1, U[c][i][0], U[c][i][1], U[c][j][0], U[c][j][1]);
   };
-  auto step = [&](const double* s, double d, double a, double* sn) {
+  auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
     const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
+    tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
     sn[0] = fma(s[3] * cs_, dt, s[0]);
     sn[1] = fma(s[3] * sn_, dt, s[1]);
     sn[2] = fma(s[3] * tn_, dt_wb, s[2]);
     sn[3] = fma(a, dt, s[3]);
   };
 
-  struct StageIn { double s0, s1, s2, s3; float4 r; };
-  auto load_stage = [&](int c, int i) -> StageIn { return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], xr4[i]}; };
+  struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
+  auto load_stage = [&](int c, int i) -> StageIn {
+    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
+  };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
   auto load_roll = [&](int c, int i) -> RollIn {
@@ -356,7 +360,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       U[0][i][0] = 0.0; U[0][i][1] = a0;
       J += ctrl(0, i);
       if (i >= 1) J += track(S[0][i], i);
-      step(S[0][i], 0.0, a0, S[0][i + 1]);
+      step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
     }
     J += track(S[0][N], N);
     mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
@@ -439,9 +443,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       uc0 = up0; uc1 = up1;
       { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
-      double sn_, cs_;                 // what step() computed when this knot was rolled out: the same functions of the same doubles
-      mpc_sincos(s[2], &sn_, &cs_);
-      const double tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
+      const double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
       const double v = s[3];
       const double sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
@@ -676,7 +678,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       Jn += ctrl_cost(i >= 1, nd, na, pnd, pna);                  // ctrl(nxt, i)
       if (i >= 1) Jn += track_cost(in.r, xs);                     // track(xs, i)
       double xn[4];
-      step(xs, nd, na, xn);
+      step(xs, nd, na, xn, TR[nxt][i]);
       S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
       xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
       pnd = nd; pna = na; pcd = in.u0; pca = in.u1;

@@ -252,28 +252,33 @@ def disassemble_code_object(lib):
         return subprocess.run([os.path.join(_LLVM_BIN, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
 
 
+def _functions_of_disassembly(text):
+    """{function: [instruction, ...]} of an llvm-objdump -d listing: mnemonics and operands only."""
+    import re
+    funcs, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+        elif cur is not None and line.startswith("\t"):
+            ins = line.split("//")[0].strip()
+            # the literal of the s_add_u32 behind an s_getpc_b64 is the distance to a global (a constant table, a symbol's GOT
+            # slot): it moves whenever ANY function of the library changes size — layout, not this kernel's code
+            if ins.startswith("s_add_u32") and cur and cur[-1].startswith("s_getpc_b64"):
+                ins = re.sub(r"0x[0-9a-f]+$|\d+$", "<pcrel>", ins)
+            cur.append(ins)
+    return funcs
+
+
 def kernel_code_hash(family, lib=None):
     """sha256 (16 hex digits) over the instruction streams of a kernel family in the library's gfx950 code object, or None when the
     code object cannot be read on this host (no ROCm LLVM tools)."""
     import hashlib
-    import re
     lib = lib or lib_path()
     key = (lib, os.path.getmtime(lib))
     if key not in _code_hashes:
         try:
-            funcs, cur = {}, None
-            for line in disassemble_code_object(lib).splitlines():
-                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-                if m:
-                    cur = funcs.setdefault(m.group(1), [])
-                elif cur is not None and line.startswith("\t"):
-                    ins = line.split("//")[0].strip()
-                    # the literal of the s_add_u32 behind an s_getpc_b64 is the distance to a global (a constant table, a symbol's GOT
-                    # slot): it moves whenever ANY function of the library changes size — layout, not this kernel's code
-                    if ins.startswith("s_add_u32") and cur and cur[-1].startswith("s_getpc_b64"):
-                        ins = re.sub(r"0x[0-9a-f]+$|\d+$", "<pcrel>", ins)
-                    cur.append(ins)
-            _code_hashes[key] = funcs
+            _code_hashes[key] = _functions_of_disassembly(disassemble_code_object(lib))
         except Exception:
             _code_hashes[key] = None
     funcs = _code_hashes[key]

@@ -106,3 +106,19 @@ def test_committed_counters_are_bound_to_the_kernel_code(crx):
         if d["kernel_code_hash"] != h[fam]:
             warnings.warn(f"profiles/{name} was taken from kernel code {d['kernel_code_hash']}, this build has {h[fam]}: bench.py will print "
                           "its counters as null until scripts/gpu_prof.sh is re-run")
+
+
+def test_code_hash_ignores_layout_not_code():
+    """The hash behind the committed counters must survive a change ELSEWHERE in the library (addresses, encodings, the pc-relative
+    distance to a constant table all move) and must not survive a change to the kernel's own instructions."""
+    from cpprobotics_amd._lib import _functions_of_disassembly
+    a = ("0000000000001000 <_Z3ekfv>:\n"
+         "\ts_getpc_b64 s[8:9]                       // 000000001000: BE881C00\n"
+         "\ts_add_u32 s8, s8, 0x153470                // 000000001004: 8008FF08 00153470\n"
+         "\ts_addc_u32 s9, s9, 0                      // 00000000100C: 82098009\n"
+         "\tv_fma_f32 v0, v1, v2, v3                  // 000000001010: D1CB0000 040E0501\n")
+    moved = a.replace("0x153470", "0x14f99c").replace("000000001", "000000007").replace("0000000000001000", "0000000000007000")
+    other = a.replace("v_fma_f32 v0, v1, v2, v3", "v_fma_f32 v0, v1, v2, v4")
+    assert _functions_of_disassembly(a) == _functions_of_disassembly(moved)
+    assert _functions_of_disassembly(a) != _functions_of_disassembly(other)
+    assert _functions_of_disassembly(a)["_Z3ekfv"][1] == "s_add_u32 s8, s8, <pcrel>"

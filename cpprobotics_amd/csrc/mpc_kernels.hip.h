@@ -43,6 +43,9 @@
 #ifndef CRX_EXPERIMENTAL_KERNELS
 #define CRX_EXPERIMENTAL_KERNELS 0
 #endif
+#ifndef CRX_MPC_LEAN   // A/B builds only (scripts/build_variants.sh lean="-DCRX_MPC_LEAN=1"): the backward sweep recomputes the rollout's trig
+#define CRX_MPC_LEAN 0
+#endif
 
 namespace crx {
 
@@ -312,7 +315,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
     const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
+#if !CRX_MPC_LEAN
     tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
+#endif
     sn[0] = fma(s[3] * cs_, dt, s[0]);
     sn[1] = fma(s[3] * sn_, dt, s[1]);
     sn[2] = fma(s[3] * tn_, dt_wb, s[2]);
@@ -321,7 +326,11 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 
   struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
   auto load_stage = [&](int c, int i) -> StageIn {
+#if CRX_MPC_LEAN
+    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
+#else
     return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
+#endif
   };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
@@ -443,7 +452,13 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       uc0 = up0; uc1 = up1;
       { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
+#if CRX_MPC_LEAN
+      double sn_, cs_;                 // what step() computed when this knot was rolled out: the same functions of the same doubles
+      mpc_sincos(in.s2, &sn_, &cs_);
+      const double tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
+#else
       const double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
+#endif
       const double v = s[3];
       const double sec2 = 1.0 + tn * tn;
       const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;

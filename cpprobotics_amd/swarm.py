@@ -163,6 +163,23 @@ def want_hw_queues(streams):
     return want
 
 
+_planner_stream_cache = {}
+
+
+def planner_streams(device, depth):
+    """The first `depth` planner streams of a device, created once per process and shared by every MixedSwarmRound on it.  Each hardware
+    queue a solver launch has ever run on keeps a scratch (private-memory) reservation sized for that kernel — the MPC solve needs
+    ~0.4 MB per wave — and the reservations of all queues come out of one pool: a process that built one round object after another,
+    each with fresh streams (torch hands out pool streams round-robin, so they land on different hardware queues), died on the fifth
+    with HSA_STATUS_ERROR_OUT_OF_RESOURCES once all 16 queues held one (round 5, gpurun_out/r05m).  With shared streams a process touches
+    depth + 1 queues with the solver however many rounds it builds."""
+    key = str(torch.device(device))
+    have = _planner_stream_cache.setdefault(key, [])
+    while len(have) < depth:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:depth]
+
+
 class MixedSwarmRound:
     """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (bench.py and scripts/swarm_bench.py run it
     on the GPUs, tests/test_swarm_gpu.py checks it there against the oracle, tests/test_dist_cpu.py with gloo and the CPU oracle
@@ -199,7 +216,7 @@ class MixedSwarmRound:
         self.local_hist = None if self.cg is not None else torch.empty((self.chunks, T // self.chunks, n_local, C), dtype=torch.float32, device=device)
         n_plan = (n_local + self.every - 1) // self.every
         self.est = [torch.empty((n_plan, C), dtype=torch.float32, device=device) for _ in range(self.depth)]
-        self.plan_streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)] if self.cuda else None
+        self.plan_streams = planner_streams(device, self.depth) if self.cuda else None
         self.ekf_done = [torch.cuda.Event() for _ in range(self.depth)] if self.cuda else None
         self.plan_done = [torch.cuda.Event() for _ in range(self.depth)] if self.cuda else None
         self._plans = [None] * self.depth

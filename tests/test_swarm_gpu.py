@@ -122,3 +122,21 @@ def test_round_is_one_ekf_launch_without_a_gather(crx):
     shard.run(); shard.wait()
     torch.cuda.synchronize()
     assert shard.rnd.chunks == 1 and len(shard.ekf_events) == 1
+
+
+def test_round_objects_of_a_process_share_their_planner_streams(crx):
+    """Every hardware queue the MPC solve has run on keeps a scratch reservation, and 16 of them abort the process
+    (profiles/r05/scratch_queues_probe.jsonl): round objects built one after another must not each bring fresh streams."""
+    import torch
+    from cpprobotics_amd import swarm
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    dev = torch.device("cuda", 0)
+    seen = set()
+    for depth in (3, 6, 2, 6):
+        shard = swarm.SwarmShard(1024, 20, course, Q, R, dev, depth=depth)
+        shard.run(); shard.wait()
+        seen |= {s.cuda_stream for s in shard.rnd.plan_streams}
+        assert [s.cuda_stream for s in shard.rnd.plan_streams] == [s.cuda_stream for s in swarm.planner_streams(dev, depth)]
+    torch.cuda.synchronize()
+    assert len(seen) == 6

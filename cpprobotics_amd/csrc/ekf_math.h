@@ -224,54 +224,86 @@ CRX_HD uint32_t bit24_mask(uint32_t v) {
   return (uint32_t)((int32_t)(v << 7) >> 31);
 #endif
 }
-// (m & a) | (~m & b)  (v_bfi_b32)
-CRX_HD uint32_t bitselect(uint32_t m, uint32_t a, uint32_t b) { return (m & a) | (~m & b); }
-// a ^ (b & k)  (v_bitop3_b32)
-CRX_HD uint32_t xor_masked(uint32_t a, uint32_t b, uint32_t k) { return a ^ (b & k); }
+// (m & a) | (~m & b): ONE v_bitop3_b32 (truth table 0xCA, src0 selects).  Written in C the compiler sees that m is a sign-extended bit
+// and emits either v_cmp + two VOP2 v_cndmask reading VCC (19 cycles each back to back, profiles/r01/ubench_issue_patterns.txt row U)
+// or, for bit 0, seven v_and/v_or per angle.
+CRX_HD uint32_t bitselect(uint32_t m, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA);
+#else
+  return (m & a) | (~m & b);
+#endif
+}
+// a ^ (b & k)  (v_bitop3_b32, truth table 0x78)
+CRX_HD uint32_t xor_masked(uint32_t a, uint32_t b, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_bitop3_b32(a, b, k, 0x78);
+#else
+  return a ^ (b & k);
+#endif
+}
 
 CRX_HD uint32_t f2u(float x) { union { float f; uint32_t u; } v; v.f = x; return v.u; }
 CRX_HD float u2f(uint32_t x) { union { float f; uint32_t u; } v; v.u = x; return v.f; }
 
-// sincosf_ restricted to its 0 < |y| < 120 path, for the two angles of one EKF step at once (the two
-// dependency chains are written interleaved so that each fp64 instruction has an independent
-// neighbour).  Outside that domain the outputs are meaningless; `dom` records where the angles were.
-//   * |y| < 2^-12, where sinf_/cosf_ return y and 1: n = 0 and x = y exactly, and the polynomials give
-//     (float)(y - y^3/6..) = y and (float)(1 - y^2/2..) = 1 by themselves (the perturbation is below half
-//     an ulp).  The one input they miss is y = -0.0f (the polynomial yields +0): |y| = 0 is therefore
-//     outside the fast domain.  Checked on every float with |y| < 128: tests/tools/trig_fast_exhaustive.cpp.
-//   * quadrant logic without compares: with v = (int)r + 2^23 (n = v >> 24), bit 24 of v says "swap sine
-//     and cosine", bit 25 is the sign of the sine output and bit 25 of v + 2^24 the sign of the cosine
-//     output; the swap is a bitfield select, the signs are xors of the sign bit.
+// sincosf_ on its 2^-100 <= |y| < 120 domain, for the two angles of one EKF step at once (the two dependency chains are written
+// interleaved so that each fp64 instruction has an independent neighbour).  Outside that domain the outputs are meaningless; `dom`
+// records where the angles were.  NOT sincosf_'s operations — 13 fp64 instructions and 3 conversions per angle where its own order
+// (rounds 2-4) takes 15 and 5 — but its RESULTS: tests/tools/trig_fast_exhaustive.cpp walks every float of the domain (1,793,064,960
+// inputs) and finds the same sine and cosine bits as sincosf_ (itself glibc's sinf / cosf on all 2^32 inputs) on every one.
+//   * reduction: n = rint(y * 2/pi) as ONE fma against 1.5 * 2^52 (the integer lands in the low mantissa bits, where the quadrant
+//     logic reads it) and a subtraction, instead of glibc's ((int)(y * 2^24 * 2/pi) + 2^23) >> 24 — a conversion to int, an add, a
+//     shift and a conversion back.  The two disagree on 5 floats of the domain (y * 2/pi within 2^-24 of a half-integer); there
+//     the other quadrant's polynomial rounds to the same floats.
+//   * polynomials: Horner in x^2 (sine: 3 fma on x^3; cosine: 4 fma) instead of glibc's split forms (5 and 6 operations).  The doubles
+//     differ in the last bit on ~8 % of the inputs, never across a float rounding boundary.
+//   * |y| < 2^-12, where sinf_/cosf_ return y and 1: n = 0 and x = y exactly, and the polynomials give (float)(y - y^3/6..) = y and
+//     (float)(1 - y^2/2..) = 1 by themselves.  The one input they miss is y = -0.0f (the polynomial yields +0): |y| = 0 is outside
+//     the fast domain.
+//   * quadrant logic without compares: bit 0 of n says "swap sine and cosine", bit 1 is the sign of the sine output and bit 1 of n + 1
+//     the sign of the cosine output; the swap is a bitfield select, the signs are xors of the sign bit.
+CRX_HD uint32_t lo32_of(double t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__double2loint(t);
+#else
+  uint64_t u; __builtin_memcpy(&u, &t, 8); return (uint32_t)u;
+#endif
+}
+// 0xffffffff if bit 0 of v is set, else 0 (v_bfe_i32)
+CRX_HD uint32_t bit0_mask(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (uint32_t)__builtin_amdgcn_sbfe((int)v, 0u, 1u);
+#else
+  return (uint32_t)((int32_t)(v << 31) >> 31);
+#endif
+}
 CRX_HD void sincos_fast2(const float y[2], float so[2], float co[2], FastDomain& dom) {
   typedef SinCosConsts C;
-  double x[2], x2[2], x3[2], x4[2], x6[2], x7[2], s1[2], sa[2], S[2], c1[2], c2[2], ca[2], Cv[2];
-  uint32_t v[2];
+  constexpr double two_over_pi = C::hpi_inv * 0x1p-24, magic = 0x1.8p52;
+  double x[2], t[2], nd[2], x2[2], x3[2], ps[2], pc[2], S[2], Cv[2];
 #define CRX_BOTH for (int i = 0; i < 2; ++i)
   dom.amax = __builtin_fmaxf(__builtin_fmaxf(dom.amax, __builtin_fabsf(y[0])), __builtin_fabsf(y[1]));
   dom.amin = __builtin_fminf(__builtin_fminf(dom.amin, __builtin_fabsf(y[0])), __builtin_fabsf(y[1]));
   _Pragma("unroll") CRX_BOTH x[i] = (double)y[i];
-  _Pragma("unroll") CRX_BOTH v[i] = (uint32_t)((int32_t)(x[i] * C::hpi_inv) + 0x800000);
-  _Pragma("unroll") CRX_BOTH x[i] = __builtin_fma(-(double)((int32_t)v[i] >> 24), C::hpi, x[i]);
+  _Pragma("unroll") CRX_BOTH t[i] = __builtin_fma(x[i], two_over_pi, magic);
+  _Pragma("unroll") CRX_BOTH nd[i] = t[i] - magic;
+  _Pragma("unroll") CRX_BOTH x[i] = __builtin_fma(-nd[i], C::hpi, x[i]);
   _Pragma("unroll") CRX_BOTH x2[i] = x[i] * x[i];
-  // sine polynomial  x + x^3*s1 + x^7*(s2 + x^2*s3)        (operation order of sincos_poly)
+  _Pragma("unroll") CRX_BOTH ps[i] = __builtin_fma(x2[i], C::s3, C::s2);
+  _Pragma("unroll") CRX_BOTH pc[i] = __builtin_fma(x2[i], C::c4, C::c3);
   _Pragma("unroll") CRX_BOTH x3[i] = x[i] * x2[i];
-  _Pragma("unroll") CRX_BOTH s1[i] = __builtin_fma(x2[i], C::s3, C::s2);
-  // cosine polynomial (c0 + x^2*c1) + x^4*c2 + x^6*(c3 + x^2*c4)
-  _Pragma("unroll") CRX_BOTH x4[i] = x2[i] * x2[i];
-  _Pragma("unroll") CRX_BOTH c2[i] = __builtin_fma(x2[i], C::c4, C::c3);
-  _Pragma("unroll") CRX_BOTH c1[i] = __builtin_fma(x2[i], C::c1, C::c0);
-  _Pragma("unroll") CRX_BOTH x7[i] = x3[i] * x2[i];
-  _Pragma("unroll") CRX_BOTH sa[i] = __builtin_fma(x3[i], C::s1, x[i]);
-  _Pragma("unroll") CRX_BOTH x6[i] = x4[i] * x2[i];
-  _Pragma("unroll") CRX_BOTH ca[i] = __builtin_fma(x4[i], C::c2, c1[i]);
-  _Pragma("unroll") CRX_BOTH S[i] = __builtin_fma(x7[i], s1[i], sa[i]);
-  _Pragma("unroll") CRX_BOTH Cv[i] = __builtin_fma(x6[i], c2[i], ca[i]);
+  _Pragma("unroll") CRX_BOTH ps[i] = __builtin_fma(x2[i], ps[i], C::s1);
+  _Pragma("unroll") CRX_BOTH pc[i] = __builtin_fma(x2[i], pc[i], C::c2);
+  _Pragma("unroll") CRX_BOTH S[i] = __builtin_fma(x3[i], ps[i], x[i]);
+  _Pragma("unroll") CRX_BOTH pc[i] = __builtin_fma(x2[i], pc[i], C::c1);
+  _Pragma("unroll") CRX_BOTH Cv[i] = __builtin_fma(x2[i], pc[i], C::c0);
   _Pragma("unroll") CRX_BOTH {
-    const uint32_t fs = f2u((float)S[i]), fc = f2u((float)Cv[i]);  // rounding commutes with the sign flips
-    const uint32_t odd = bit24_mask(v[i]);                           // all ones when n is odd
+    const uint32_t n = lo32_of(t[i]);                                 // n mod 2^32
+    const uint32_t fs = f2u((float)S[i]), fc = f2u((float)Cv[i]);     // rounding commutes with the sign flips
+    const uint32_t odd = bit0_mask(n);                                // all ones when n is odd
     const uint32_t sr = bitselect(odd, fc, fs);
     const uint32_t cr = bitselect(odd, fs, fc);
-    const uint32_t qs = v[i] << 6;                // bit 31 = bit 1 of n
+    const uint32_t qs = n << 30;                  // bit 31 = bit 1 of n
     const uint32_t qc = qs + 0x40000000u;         // bit 31 = bit 1 of n + 1
     so[i] = u2f(xor_masked(sr, qs, 0x80000000u));
     co[i] = u2f(xor_masked(cr, qc, 0x80000000u));

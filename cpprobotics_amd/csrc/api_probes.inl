@@ -117,3 +117,47 @@ int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int
   return CRX_OK;
 }
 }  // extern "C"
+
+// The reciprocal of the fused EKF step (csrc/ekf_math.h: recip_fast — v_rcp_f32 and one Newton step) against the compiler's IEEE 1.0f / d
+// on EVERY float of its domain, 2^-60 <= |d| <= 2^60: counts[0] = inputs walked, counts[1] = inputs where recip_fast's two fma differ from
+// 1.0f / d, counts[2] = inputs where the six-fma form of rounds 2-4 does.  The claim rests on this device's v_rcp_f32, so the GPU tests
+// run the sweep on the device they run on (~1 ms).
+namespace crx {
+// the six-fma form of rounds 2-4 (= the compiler's own IEEE division in this range): the sweep's second witness
+__device__ __forceinline__ float recip_six_fma(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  const float r1 = __builtin_fmaf(e, r, r);
+  const float rem = __builtin_fmaf(-d, r1, 1.0f);
+  const float q1 = __builtin_fmaf(rem, r1, r1);
+  const float rem2 = __builtin_fmaf(-d, q1, 1.0f);
+  return __builtin_fmaf(rem2, r1, q1);
+}
+__global__ void __launch_bounds__(256) recip_sweep_kernel(unsigned long long* __restrict__ counts) {
+  const uint32_t lo = 0x21800000u /* 2^-60 */, hi = 0x5d800000u /* 2^60 */;
+  unsigned long long n = 0, b2 = 0, b6 = 0;
+  for (uint64_t m = (uint64_t)lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; m <= hi; m += (uint64_t)gridDim.x * blockDim.x)
+    for (uint32_t sg = 0; sg < 2; ++sg) {
+      const float d = __uint_as_float((uint32_t)m | (sg << 31));
+      const float ref = 1.0f / d;
+      FastDomain dom = fast_domain_init();
+      b2 += __float_as_uint(recip_fast(d, dom)) != __float_as_uint(ref);
+      b6 += __float_as_uint(recip_six_fma(d)) != __float_as_uint(ref);
+      ++n;
+    }
+  atomicAdd(&counts[0], n);
+  if (b2) atomicAdd(&counts[1], b2);
+  if (b6) atomicAdd(&counts[2], b6);
+}
+}  // namespace crx
+extern "C" {
+int crx_x_recip_sweep_dev(unsigned long long* counts, void* stream) {
+  CRX_TRACE();
+  if (!counts) return fail(CRX_ERR_INVALID, "recip_sweep: counts is NULL");
+  if (int rc = check_device()) return rc;
+  CRX_HIP(hipMemsetAsync(counts, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream));
+  hipLaunchKernelGGL(crx::recip_sweep_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, counts);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+}  // extern "C"

@@ -311,28 +311,23 @@ CRX_HD void sincos_fast2(const float y[2], float so[2], float co[2], FastDomain&
 #undef CRX_BOTH
 }
 
-// 1.0f/d, IEEE-rounded, for 2^-60 <= |d| <= 2^60 (`dom` records |d|).
-//   LLVM's IEEE fp32 division is v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup.  In that
-//   range, with numerator 1.0, neither v_div_scale scales, v_div_fmas is a plain fma and v_div_fixup
-//   passes the quotient through: rcp + the same six fma give the same bits.
+// 1.0f/d, IEEE-rounded, for 2^-60 <= |d| <= 2^60 (`dom` records |d|): v_rcp_f32 and ONE Newton step.
+//   LLVM's IEEE fp32 division is v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas, v_div_fixup; in that range, with numerator 1.0, neither
+//   v_div_scale scales, v_div_fmas is a plain fma and v_div_fixup passes the quotient through, so rcp + the same six fma give its bits
+//   (rounds 2-4 issued exactly that).  The last four of them never change the result: on gfx950's v_rcp_f32,
+//   fma(fma(-d, r, 1), r, r) IS the correctly rounded quotient for every one of the 2,013,265,922 floats of the range
+//   (crx_x_recip_sweep_dev, run by tests/test_ekf_gpu.py on the device the tests run on; profiles/r05/recip_exhaustive.txt).
 CRX_HD float recip_fast(float d, FastDomain& dom) {
   const float ad = __builtin_fabsf(d);
   dom.dmax = __builtin_fmaxf(dom.dmax, ad);
   dom.dmin = __builtin_fminf(dom.dmin, ad);
 #if defined(__HIP_DEVICE_COMPILE__)
   const float r = __builtin_amdgcn_rcpf(d);
-  const float e = __builtin_fmaf(-d, r, 1.0f);
-  const float r1 = __builtin_fmaf(e, r, r);
-  const float q = r1;                                  // 1.0f * r1
-  const float rem = __builtin_fmaf(-d, q, 1.0f);
-  const float q1 = __builtin_fmaf(rem, r1, q);
-  const float rem2 = __builtin_fmaf(-d, q1, 1.0f);
-  return __builtin_fmaf(rem2, r1, q1);
+  return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 #else
   return 1.0f / d;                                     // host build (tests): the IEEE quotient itself
 #endif
 }
-
 CRX_HD v2f bc(float a) { return v2f{a, a}; }
 
 // One ekf_estimation() (:64-78), packed.  Same operation order as ekf_step_dev, entry by entry.
@@ -342,7 +337,9 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   const float u0 = u[0], u1 = u[1];
   // motion_model: both yaw angles of the step are known up front
   const float yaw0 = s.x23[0];
-  const float yaw1 = yaw0 + k.dtf * u1;                 // xPred(2) = x(2) + DT*u(1)
+  // xPred(2) = x(2) + DT*u(1), xPred(3) = x(3) + u(0): one packed multiply by (DT, 1) — u(0) * 1.0f is u(0) — and one packed add
+  const v2f xp23 = s.x23 + v2f{u1, u0} * v2f{k.dtf, 1.0f};
+  const float yaw1 = xp23[0];
   const float yaws[2] = {yaw0, yaw1};
   float sn[2], cs[2];
   sincos_fast2(yaws, sn, cs, dom);
@@ -356,7 +353,6 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
     jB = v2f{(float)(k.dt * (double)c1), (float)(k.dt * (double)s1)};
   }
   const v2f xp01 = s.x01 + b01 * bc(u0);
-  const v2f xp23 = v2f{yaw1, s.x23[1] + u0};
   // jacobF(xPred, u): yaw = xPred(2), v = u(0)
   const double dv = k.dt * (double)u0;
   const float j02 = (float)((-dv) * (double)s1);
@@ -399,13 +395,15 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   const v2f dd = Sc0 * v2f{Sc1[1], Sc1[0]};   // (S00*S11, S10*S01)
   const float det = dd[0] - dd[1];
   const float inv = recip_fast(det, dom);
-  const float Si00 = Sc1[1] * inv, Si10 = -Sc0[1] * inv;
-  const float Si01 = -Sc1[0] * inv, Si11 = Sc0[0] * inv;
+  // S^-1 = inv * [S11 -S01; -S10 S00]: the four products as two packed multiplies; (-a) * inv = -(a * inv) exactly, so the two
+  // negations ride on the consumers' operands
+  const v2f W0 = Sc0 * bc(inv);      // (S00*inv, S10*inv) = ( Si11, -Si10)
+  const v2f W1 = Sc1 * bc(inv);      // (S01*inv, S11*inv) = (-Si01,  Si00)
   // K = (PPred*H^T)*Sinv
   v2f K0lo, K0hi, K1lo, K1hi;
   {
-    const v2f e0 = PPlo[0] * bc(Si00), e1 = PPhi[0] * bc(Si00), e2 = PPlo[0] * bc(Si01), e3 = PPhi[0] * bc(Si01);
-    const v2f f0 = PPlo[1] * bc(Si10), f1 = PPhi[1] * bc(Si10), f2 = PPlo[1] * bc(Si11), f3 = PPhi[1] * bc(Si11);
+    const v2f e0 = PPlo[0] * bc(W1[1]), e1 = PPhi[0] * bc(W1[1]), e2 = PPlo[0] * bc(-W1[0]), e3 = PPhi[0] * bc(-W1[0]);
+    const v2f f0 = PPlo[1] * bc(-W0[1]), f1 = PPhi[1] * bc(-W0[1]), f2 = PPlo[1] * bc(W0[0]), f3 = PPhi[1] * bc(W0[0]);
     K0lo = e0 + f0; K0hi = e1 + f1; K1lo = e2 + f2; K1hi = e3 + f3;
   }
   // xEst = xPred + K*y

@@ -19,6 +19,7 @@ _X_SIGNATURES = {
     "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
     "crx_x_dare_from_v_refill_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_hbm_stream_dev": (_I, [_I, _P, _P, C.c_size_t, _I, _P]),
+    "crx_x_recip_sweep_dev": (_I, [_P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
@@ -282,3 +283,13 @@ def closed_loop_prediction_lanes(state, course, goal, lanes_per_agent, dim=5, ma
                                                    C.byref(lp), L.ptr(hist), L.ptr(ticks), L.stream_ptr(), int(lanes_per_agent)),
             "crx_x_lqr_closed_loop_lanes_dev")
     return ticks, hist
+
+
+def recip_sweep(device="cuda"):
+    """(inputs, mismatches of the EKF step's v_rcp_f32 + one-Newton-step reciprocal, mismatches of rounds 2-4's six-fma form) against
+    the IEEE 1.0f / d over every float 2^-60 <= |d| <= 2^60, on this device (csrc/api_probes.inl: crx_x_recip_sweep_dev)."""
+    import torch
+    counts = torch.zeros(3, dtype=torch.int64, device=device)
+    L.check(xlib().crx_x_recip_sweep_dev(L.ptr(counts), L.stream_ptr()), "crx_x_recip_sweep_dev")
+    torch.cuda.synchronize()
+    return tuple(int(v) for v in counts.cpu())

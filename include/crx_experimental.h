@@ -80,6 +80,11 @@ int crx_x_dare_from_v_refill_dev(int n, int dim, const float* v, const crx_lqr_p
  * HBM-bound EKF launches. */
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream);
 
+/* The fused EKF step's reciprocal (v_rcp_f32 + one Newton step, csrc/ekf_math.h: recip_fast) against the IEEE quotient 1.0f / d on every
+ * float 2^-60 <= |d| <= 2^60.  counts (device, 3 x u64): inputs walked, inputs where recip_fast differs, inputs where the six-fma form of
+ * rounds 2-4 differs.  Both must be 0 on the device the engine runs on. */
+int crx_x_recip_sweep_dev(unsigned long long* counts, void* stream);
+
 /* crx_ekf_run_batch_dev through the 64-bit-address instantiations of the fused kernel whatever n is (the product entry point
  * switches to them above 4 M vehicles). */
 int crx_x_ekf_run_addr64_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist, float* P_hist,

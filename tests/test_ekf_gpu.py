@@ -427,3 +427,13 @@ def test_chunked_launches_equal_one_launch(crx):
         for c in range(chunks):
             crx.ekf_run(x2, P2, z[c * Tc:(c + 1) * Tc], ud[c * Tc:(c + 1) * Tc], Q, R, x_hist=h2[c * Tc:(c + 1) * Tc])
         assert torch.equal(h1.view(torch.int32), h2.view(torch.int32)) and torch.equal(x1, x2) and torch.equal(P1, P2)
+
+
+@pytest.mark.gpu
+def test_reciprocal_of_the_fused_step_is_the_ieee_quotient_on_this_device(crx):
+    """recip_fast (csrc/ekf_math.h) is v_rcp_f32 and ONE Newton step; that this is the correctly rounded 1.0f / d on every float
+    2^-60 <= |d| <= 2^60 is a property of the device's v_rcp_f32 — checked here, exhaustively, on the device the tests run on."""
+    from cpprobotics_amd import experimental as X
+    n, bad_two, bad_six = X.recip_sweep()
+    print(f"recip sweep: {n} inputs, rcp + 2 fma: {bad_two} mismatches, rcp + 6 fma: {bad_six}")
+    assert n == 2 * (0x5d800000 - 0x21800000 + 1) and bad_two == 0 and bad_six == 0

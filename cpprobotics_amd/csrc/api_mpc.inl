@@ -8,7 +8,7 @@ extern "C" {
 // agents_per_wave (1..64) and waves_per_workgroup (1..4): the launch geometry; the product entry point uses full waves in
 // single-wave workgroups (every emptier or stacked geometry measured slower: profiles/r02/mpc_tail.txt).
 static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
-                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {
+                            float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup, int trig = -1) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve: bad argument (2 <= T <= 64)");
   if (agents_per_wave < 1 || agents_per_wave > 64 || waves_per_workgroup < 1 || waves_per_workgroup > 4)
@@ -17,7 +17,7 @@ static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup);
+  const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup, trig);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
 // The lane-refilling launch (mpc_refill_kernel: a wave owns `agents_per_wave` consecutive agents; bit-identical to mpc_kernel per agent).
@@ -91,6 +91,12 @@ int crx_x_mpc_solve_refill_dev(int n, int T, const float* x0, const float* xref,
                                double* cost, void* stream, int agents_per_wave, int hold_lanes) {
   CRX_TRACE();
   return mpc_solve_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes);
+}
+int crx_x_mpc_solve_trig_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                             double* cost, void* stream, int recompute_trig) {
+  CRX_TRACE();
+  if (recompute_trig != 0 && recompute_trig != 1) return fail(CRX_ERR_INVALID, "mpc_solve (trig): recompute_trig must be 0 or 1");
+  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1, recompute_trig);
 }
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                  double* cost, void* stream, int agents_per_wave, int waves_per_workgroup) {

@@ -36,15 +36,14 @@
 
 // The library is built with -ffp-contract=off because the fp32 EKF / DARE / tracking kernels reproduce the reference's
 // unfused mul-then-add arithmetic bit for bit.  The MPC solver is fp64 with tolerance-based parity (the reference's own
-// answer is an IPOPT iterate), so inside this header multiply-adds may fuse: the backward sweep is ~650 dependent fp64
-// mul/add per stage, which fma contraction cuts by a third.  Restored to `off` at the end of the file.
-#pragma clang fp contract(fast)
+// answer is an IPOPT iterate) and wants its multiply-adds fused — but rounds 1-4 got them from `#pragma clang fp contract(fast)`,
+// and which product of a sum of products the compiler fuses turned out to depend on the code AROUND the sum: two builds of this
+// header that differ only in where the backward sweep's trig comes from disagreed in the last bits of the cost (round 5).
+// Since round 5 every fused multiply-add of the solver is WRITTEN (fma(), nested so that a row a*b + c*d + e is two instructions,
+// not three) and nothing is left to contraction: every build of mpc_solve_lane computes the same bits.
 
 #ifndef CRX_EXPERIMENTAL_KERNELS
 #define CRX_EXPERIMENTAL_KERNELS 0
-#endif
-#ifndef CRX_MPC_LEAN   // A/B builds only (scripts/build_variants.sh lean="-DCRX_MPC_LEAN=1"): the backward sweep recomputes the rollout's trig
-#define CRX_MPC_LEAN 0
 #endif
 
 namespace crx {
@@ -162,17 +161,18 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
   // mask bookkeeping than the arithmetic they skip.  Whole candidate sets are skipped only when NO lane of the wave needs them
   // (every lane interior; every lane on the edge rule) — which set a lane's answer comes from is decided by its own problem.
   const double tiny = 1e-12;
-  const double det = h00 * h11 - hod * hod;
+  const double det = fma(h00, h11, -(hod * hod));
   const bool pd = h00 > tiny && det > tiny * h00;
   const double idet = fast_div(1.0, pd ? det : 1.0);
-  const double ia = -(h11 * g0 - hod * g1) * idet, ib = -(-hod * g0 + h00 * g1) * idet;
+  const double ia = -(fma(h11, g0, -(hod * g1)) * idet), ib = -(fma(h00, g1, -(hod * g0)) * idet);
   const bool interior = pd && ia >= lo0 && ia <= hi0 && ib >= lo1 && ib <= hi1;
   k0 = ia; k1 = ib; f0 = true; f1 = true;
   if (__all(interior)) return;
   double best = 1e300, b0 = 0.0, b1 = 0.0;
   int bf = 0;                                  // bit 0: control 0 free, bit 1: control 1 free
+  const double hh00 = 0.5 * h00, hh11 = 0.5 * h11;
   auto consider = [&](double a, double b, int flags, bool valid) {
-    const double obj = 0.5 * (h00 * a * a + 2.0 * hod * a * b + h11 * b * b) + g0 * a + g1 * b;
+    const double obj = fma(a, fma(hh00, a, fma(hod, b, g0)), b * fma(hh11, b, g1));      // 1/2 k'Hk + g'k
     const lanemask_t take = lanes_where(valid && obj < best);
     best = sel64(take, obj, best); b0 = sel64(take, a, b0); b1 = sel64(take, b, b1); bf = sel32(take, flags, bf);
   };
@@ -191,10 +191,10 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const double c0 = b ? hi0 : lo0;
-      const double u1 = -(g1 + hod * c0) * ih11;
+      const double u1 = -(fma(hod, c0, g1) * ih11);
       consider(c0, clampd(u1, lo1, hi1), (u1 >= lo1 && u1 <= hi1) ? 2 : 0, valid());
       const double c1 = b ? hi1 : lo1;
-      const double u0 = -(g0 + hod * c1) * ih00;
+      const double u0 = -(fma(hod, c1, g0) * ih00);
       consider(clampd(u0, lo0, hi0), c1, (u0 >= lo0 && u0 <= hi0) ? 1 : 0, valid());
     }
   };
@@ -205,10 +205,10 @@ __device__ __forceinline__ void boxqp2(double h00, double hod, double h11, doubl
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const double c0 = b ? hi0 : lo0;
-      const double t1 = -(g1 + hod * c0) * ih11;
+      const double t1 = -(fma(hod, c0, g1) * ih11);
       consider(c0, t1, 2, en && c11 && t1 >= lo1 && t1 <= hi1);
       const double c1 = b ? hi1 : lo1;
-      const double t0 = -(g0 + hod * c1) * ih00;
+      const double t0 = -(fma(hod, c1, g0) * ih00);
       consider(t0, c1, 1, en && c00 && t0 >= lo0 && t0 <= hi0);
     }
 #pragma unroll
@@ -248,16 +248,16 @@ struct MpcFeed {
   const float* __restrict__ x0g; const float* __restrict__ xrefg;
   float* __restrict__ solg; int* __restrict__ statusg; double* __restrict__ costg;
 };
-// The trig of a rollout (sin, cos of the knots' headings, tan of the steering angles) is kept for the backward sweep (TR): 24 B written per
-// rollout stage and 24 B read per backward stage.  Round 5 also built the solver WITHOUT that array — the backward sweep recomputing the
-// trig, ~70 VALU instructions per stage for 11 % less memory traffic — and measured both (profiles/r05/mpc_variants_ab_run4*.jsonl,
-// mpc_experiments.txt): the recomputing build wins where the solver's traffic is HBM traffic and nothing else matters (262,144 agents
-// 6.9 -> 6.4 ms, 1 M 21.4 -> 17.8 ms) and by 2.5 % in the pipelined swarm round (0.487 -> 0.475 ms), and loses 7-8 % wherever a launch
-// is a latency chain: BASELINE configs[3] (8,192 agents: 0.91 -> 0.97 ms) and the persistent closed loop (116 -> 107 M agent-ticks/s).
-// The two cannot coexist behind one entry point: the compiler contracts the backward sweep's sums of products differently per build
-// (costs equal to 1e-14, not to the bit), and an agent's answer must not depend on the batch it travels in.  The BASELINE configurations
-// decide: the trig stays stored.
-template <int MAXT, bool PORTFOLIO = false, bool REFILL = false>
+// LEAN: where the backward sweep's trig comes from.  false: the rollout keeps sin(yaw_i), cos(yaw_i), tan(delta_i) for it (TR: 24 B
+// written per rollout stage, 24 B read per backward stage).  true: the backward sweep recomputes them from the knot — the same functions
+// of the same doubles, and since round 5 spelled every fused multiply-add of the solver out, THE SAME BITS in every output (solution,
+// status, cost: scripts/gpu_mpc_two_builds.py and tests/test_mpc_gpu.py compare them on the device) — ~70 more VALU instructions per
+// backward stage for 11 % less memory traffic (96 -> 82 KB per solve).  Recomputing wins where the solver's traffic is HBM traffic
+// (lone launches: 131,072 agents 4.36 -> 4.15 ms, 262,144 6.24 -> 5.49, 1 M 21.2 -> 17.6 = 59 M solves/s) and loses 5-6 % where a launch
+// is a latency chain (BASELINE configs[3]: 0.88 -> 0.93 ms; the persistent closed loop); 65,536 agents: equal
+// (profiles/r05/mpc_two_builds.jsonl).  The launcher picks it from kMpcLeanFrom agents on; the answer does not depend on the choice.
+constexpr int kMpcLeanFrom = 98304;
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
                                                const MpcFeed feed = MpcFeed{}) {
@@ -280,13 +280,15 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
   float Kf[MAXT][12];
-  double TR[2][MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them
+  double TR[LEAN ? 1 : 2][LEAN ? 1 : MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them (LEAN: recomputes them)
 
   const double dt = p.dt, wb = p.wb;
   const double dt_wb = dt / wb;          // the model uses .../wb*dt once per stage and rollout: one division per solve instead
   const double inv_dt = 1.0 / dt;
   const double lb0 = -p.max_steer, ub0 = p.max_steer;
   const bool small_steer = p.max_steer <= 0.78539816339744830962;   // uniform: every steering angle of a rollout is clamped to it
+  const double c2r_d = 2.0 * p.r_d, c2r_a = 2.0 * p.r_a, c2rd_d = 2.0 * p.rd_d, c2rd_a = 2.0 * p.rd_a;    // the doubled weights of the
+  const double c2qx = 2.0 * p.qx, c2qy = 2.0 * p.qy, c2qyaw = 2.0 * p.qyaw, c2qv = 2.0 * p.qv;             // cost's second derivatives
 
   // objective of buffer c (states already rolled out there) is accumulated while rolling; this lambda
   // rolls controls U[c] from x0 and returns fg[0]
@@ -315,9 +317,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
     const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
-#if !CRX_MPC_LEAN
-    tr[0] = sn_; tr[1] = cs_; tr[2] = tn_;
-#endif
+    if constexpr (!LEAN) { tr[0] = sn_; tr[1] = cs_; tr[2] = tn_; }
     sn[0] = fma(s[3] * cs_, dt, s[0]);
     sn[1] = fma(s[3] * sn_, dt, s[1]);
     sn[2] = fma(s[3] * tn_, dt_wb, s[2]);
@@ -326,11 +326,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 
   struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
   auto load_stage = [&](int c, int i) -> StageIn {
-#if CRX_MPC_LEAN
-    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
-#else
-    return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
-#endif
+    if constexpr (LEAN) return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
+    else return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
   };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
@@ -369,7 +366,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       U[0][i][0] = 0.0; U[0][i][1] = a0;
       J += ctrl(0, i);
       if (i >= 1) J += track(S[0][i], i);
-      step(S[0][i], 0.0, a0, S[0][i + 1], TR[0][i]);
+      step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
     }
     J += track(S[0][N], N);
     mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
@@ -417,10 +414,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     {
       const float4 r = rN;
       const double* s = S[cur][N];
-      lx[0] = -2.0 * p.qx * ((double)r.x - s[0]);
-      lx[1] = -2.0 * p.qy * ((double)r.y - s[1]);
-      lx[2] = -2.0 * p.qyaw * ((double)r.z - s[2]);
-      lx[3] = -2.0 * p.qv * ((double)r.w - s[3]);
+      lx[0] = c2qx * (s[0] - (double)r.x);
+      lx[1] = c2qy * (s[1] - (double)r.y);
+      lx[2] = c2qyaw * (s[2] - (double)r.z);
+      lx[3] = c2qv * (s[3] - (double)r.w);
       lp0 = 0.0; lp1 = 0.0;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -428,7 +425,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
         for (int b = 0; b < 4; ++b) Wxx[a][b] = 0.0;
         Wxp[a][0] = 0.0; Wxp[a][1] = 0.0;
       }
-      Wxx[0][0] = 2.0 * p.qx; Wxx[1][1] = 2.0 * p.qy; Wxx[2][2] = 2.0 * p.qyaw; Wxx[3][3] = 2.0 * p.qv;
+      Wxx[0][0] = c2qx; Wxx[1][1] = c2qy; Wxx[2][2] = c2qyaw; Wxx[3][3] = c2qv;
       Wpp00 = 0.0; Wpp01 = 0.0; Wpp11 = 0.0;
     }
     dV1 = 0.0; dV2 = 0.0; gnorm = 0.0;
@@ -452,45 +449,44 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       uc0 = up0; uc1 = up1;
       { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
-#if CRX_MPC_LEAN
-      double sn_, cs_;                 // what step() computed when this knot was rolled out: the same functions of the same doubles
-      mpc_sincos(in.s2, &sn_, &cs_);
-      const double tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
-#else
-      const double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
-#endif
+      double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
+      if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
+        mpc_sincos(in.s2, &sn_, &cs_);
+        tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
+      }
       const double v = s[3];
-      const double sec2 = 1.0 + tn * tn;
-      const double a02 = -v * sn_ * dt, a03 = cs_ * dt, a12 = v * cs_ * dt, a13 = sn_ * dt, a23 = tn * dt_wb;
-      const double bd = v * sec2 * dt_wb;
+      const double sec2 = fma(tn, tn, 1.0);
+      const double vdt = v * dt, vdw = v * dt_wb;
+      const double a02 = -(vdt * sn_), a03 = cs_ * dt, a12 = vdt * cs_, a13 = sn_ * dt, a23 = tn * dt_wb;
+      const double bd = vdw * sec2;
       // stage cost derivatives
       double l_x[4] = {0.0, 0.0, 0.0, 0.0}, q2[4] = {0.0, 0.0, 0.0, 0.0};
-      double l_u0 = 2.0 * p.r_d * ud, l_u1 = 2.0 * p.r_a * ua;
-      double l_uu0 = 2.0 * p.r_d, l_uu1 = 2.0 * p.r_a;
+      double l_u0 = c2r_d * ud, l_u1 = c2r_a * ua;
+      double l_uu0 = c2r_d, l_uu1 = c2r_a;
       double l_p0 = 0.0, l_p1 = 0.0, l_pp0 = 0.0, l_pp1 = 0.0, l_up0 = 0.0, l_up1 = 0.0;
       if (inner) {
         const float4 r = in.r;
-        q2[0] = 2.0 * p.qx; q2[1] = 2.0 * p.qy; q2[2] = 2.0 * p.qyaw; q2[3] = 2.0 * p.qv;
-        l_x[0] = -q2[0] * ((double)r.x - s[0]);
-        l_x[1] = -q2[1] * ((double)r.y - s[1]);
-        l_x[2] = -q2[2] * ((double)r.z - s[2]);
-        l_x[3] = -q2[3] * ((double)r.w - s[3]);
+        q2[0] = c2qx; q2[1] = c2qy; q2[2] = c2qyaw; q2[3] = c2qv;
+        l_x[0] = c2qx * (s[0] - (double)r.x);
+        l_x[1] = c2qy * (s[1] - (double)r.y);
+        l_x[2] = c2qyaw * (s[2] - (double)r.z);
+        l_x[3] = c2qv * (s[3] - (double)r.w);
         const double dd = ud - pd, da = ua - pa;
-        l_u0 += 2.0 * p.rd_d * dd; l_u1 += 2.0 * p.rd_a * da;
-        l_p0 = -2.0 * p.rd_d * dd; l_p1 = -2.0 * p.rd_a * da;
-        l_uu0 += 2.0 * p.rd_d; l_uu1 += 2.0 * p.rd_a;
-        l_pp0 = 2.0 * p.rd_d; l_pp1 = 2.0 * p.rd_a;
-        l_up0 = -2.0 * p.rd_d; l_up1 = -2.0 * p.rd_a;
+        l_u0 = fma(c2rd_d, dd, l_u0); l_u1 = fma(c2rd_a, da, l_u1);
+        l_p0 = -(c2rd_d * dd); l_p1 = -(c2rd_a * da);
+        l_uu0 += c2rd_d; l_uu1 += c2rd_a;
+        l_pp0 = c2rd_d; l_pp1 = c2rd_a;
+        l_up0 = -c2rd_d; l_up1 = -c2rd_a;
       }
       // Q_s, Q_u
       double Qx[4];
       Qx[0] = l_x[0] + lx[0];
       Qx[1] = l_x[1] + lx[1];
-      Qx[2] = l_x[2] + (a02 * lx[0] + a12 * lx[1] + lx[2]);
-      Qx[3] = l_x[3] + (a03 * lx[0] + a13 * lx[1] + a23 * lx[2] + lx[3]);
+      Qx[2] = fma(a02, lx[0], fma(a12, lx[1], l_x[2] + lx[2]));
+      Qx[3] = fma(a03, lx[0], fma(a13, lx[1], fma(a23, lx[2], l_x[3] + lx[3])));
       const double Qp0 = l_p0, Qp1 = l_p1;
-      const double Qu0 = l_u0 + bd * lx[2] + lp0;
-      const double Qu1 = l_u1 + dt * lx[3] + lp1;
+      const double Qu0 = fma(bd, lx[2], l_u0 + lp0);
+      const double Qu1 = fma(dt, lx[3], l_u1 + lp1);
       // M = Wxx*A ; Qxx = l_xx + A'*M.  Wxx is symmetric by construction (mirrored upper triangle), so Qxx is symmetric up to
       // rounding: only its upper triangle is formed (a <= b) and used — 7 rows of products instead of 20, and no averaging of
       // the two halves (the CPU twin forms both and averages them; the difference is a rounding of the last bit).
@@ -499,39 +495,39 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       for (int a = 0; a < 3; ++a) {
         M[a][0] = Wxx[a][0];
         M[a][1] = Wxx[a][1];
-        M[a][2] = Wxx[a][0] * a02 + Wxx[a][1] * a12 + Wxx[a][2];
-        M[a][3] = Wxx[a][0] * a03 + Wxx[a][1] * a13 + Wxx[a][2] * a23 + Wxx[a][3];
+        M[a][2] = fma(Wxx[a][0], a02, fma(Wxx[a][1], a12, Wxx[a][2]));
+        M[a][3] = fma(Wxx[a][0], a03, fma(Wxx[a][1], a13, fma(Wxx[a][2], a23, Wxx[a][3])));
       }
-      M[3][3] = Wxx[3][0] * a03 + Wxx[3][1] * a13 + Wxx[3][2] * a23 + Wxx[3][3];
+      M[3][3] = fma(Wxx[3][0], a03, fma(Wxx[3][1], a13, fma(Wxx[3][2], a23, Wxx[3][3])));
       double Qxx[4][4];     // entries a <= b only
 #pragma unroll
       for (int b = 0; b < 4; ++b) Qxx[0][b] = M[0][b];
 #pragma unroll
       for (int b = 1; b < 4; ++b) Qxx[1][b] = M[1][b];
 #pragma unroll
-      for (int b = 2; b < 4; ++b) Qxx[2][b] = a02 * M[0][b] + a12 * M[1][b] + M[2][b];
-      Qxx[3][3] = a03 * M[0][3] + a13 * M[1][3] + a23 * M[2][3] + M[3][3];
+      for (int b = 2; b < 4; ++b) Qxx[2][b] = fma(a02, M[0][b], fma(a12, M[1][b], M[2][b]));
+      Qxx[3][3] = fma(a03, M[0][3], fma(a13, M[1][3], fma(a23, M[2][3], M[3][3])));
 #pragma unroll
       for (int a = 0; a < 4; ++a) Qxx[a][a] += q2[a];
       // G = B'*Wxx + Wpx ; Qux = G*A ; Quu = l_uu + G*B + B'*Wxp + Wpp
       double G[2][4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        G[0][b] = bd * Wxx[2][b] + Wxp[b][0];
-        G[1][b] = dt * Wxx[3][b] + Wxp[b][1];
+        G[0][b] = fma(bd, Wxx[2][b], Wxp[b][0]);
+        G[1][b] = fma(dt, Wxx[3][b], Wxp[b][1]);
       }
       double Qux[2][4];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         Qux[a][0] = G[a][0];
         Qux[a][1] = G[a][1];
-        Qux[a][2] = G[a][0] * a02 + G[a][1] * a12 + G[a][2];
-        Qux[a][3] = G[a][0] * a03 + G[a][1] * a13 + G[a][2] * a23 + G[a][3];
+        Qux[a][2] = fma(G[a][0], a02, fma(G[a][1], a12, G[a][2]));
+        Qux[a][3] = fma(G[a][0], a03, fma(G[a][1], a13, fma(G[a][2], a23, G[a][3])));
       }
-      double Quu00 = l_uu0 + G[0][2] * bd + bd * Wxp[2][0] + Wpp00;
+      double Quu00 = fma(G[0][2], bd, fma(bd, Wxp[2][0], l_uu0 + Wpp00));
       // the off-diagonal of Q_uu once: its two halves (B'W B and its transpose) are equal up to rounding, the twin averages them
-      const double Quu01 = G[0][3] * dt + bd * Wxp[2][1] + Wpp01;
-      double Quu11 = l_uu1 + G[1][3] * dt + dt * Wxp[3][1] + Wpp11;
+      const double Quu01 = fma(G[0][3], dt, fma(bd, Wxp[2][1], Wpp01));
+      double Quu11 = fma(G[1][3], dt, fma(dt, Wxp[3][1], l_uu1 + Wpp11));
       // the box of the step: steering limits; the acceleration box of this knot's (nominal) speed = acceleration limits and
       // the speed bounds of knot i+1
       AccelBox ab = accel_box(p, inv_dt, v);
@@ -542,13 +538,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       const bool hold1 = exact && ((lo1 >= 0.0 && Qu1 > 0.0) || (hi1 <= 0.0 && Qu1 < 0.0));
       if (exact) {   // V_s . d2F; the steering curvature e00 only where it leaves the control Hessian of the controls not held
                      // positive definite (a saturated steering input otherwise proposes a jump to a box corner)
-        const double e00 = lx[2] * v * dt_wb * 2.0 * tn * sec2;
+        const double e00 = ((lx[2] * vdw) * (tn + tn)) * sec2;
         const double g0 = Quu00 + e00 + mu, g3 = Quu11 + mu, go = Quu01;
-        Qxx[2][2] += lx[0] * (-v * cs_ * dt) + lx[1] * (-v * sn_ * dt);
-        const double cross = lx[0] * (-sn_ * dt) + lx[1] * (cs_ * dt);
-        Qxx[2][3] += cross;
-        Qux[0][3] += lx[2] * sec2 * dt_wb;
-        if (g0 > 1e-12 && (hold1 || g0 * g3 - go * go > 1e-12 * g0)) Quu00 += e00;
+        Qxx[2][2] = fma(-vdt, fma(lx[0], cs_, lx[1] * sn_), Qxx[2][2]);
+        Qxx[2][3] = fma(dt, fma(lx[1], cs_, -(lx[0] * sn_)), Qxx[2][3]);
+        Qux[0][3] = fma(lx[2] * sec2, dt_wb, Qux[0][3]);
+        if (g0 > 1e-12 && (hold1 || fma(g0, g3, -(go * go)) > 1e-12 * g0)) Quu00 += e00;
       }
       const double hod = Quu01;
       const double h00 = Quu00 + mu, h11 = Quu11 + mu;
@@ -578,15 +573,15 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       double K[2][6];
       {
         const bool both = f0 && f1;
-        const double den = both ? (h00 * h11 - hod * hod) : (f0 ? h00 : (f1 ? h11 : 1.0));
+        const double den = both ? fma(h00, h11, -(hod * hod)) : (f0 ? h00 : (f1 ? h11 : 1.0));
         const double inv = fast_div(1.0, den);
         const double i00 = both ? h11 * inv : (f0 ? inv : 0.0);
         const double i11 = both ? h00 * inv : (f1 ? inv : 0.0);
         const double i01 = both ? -hod * inv : 0.0;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          K[0][b] = -(i00 * Qus[0][b] + i01 * Qus[1][b]);
-          K[1][b] = -(i01 * Qus[0][b] + i11 * Qus[1][b]);
+          K[0][b] = -fma(i00, Qus[0][b], i01 * Qus[1][b]);
+          K[1][b] = -fma(i01, Qus[0][b], i11 * Qus[1][b]);
         }
         K[0][4] = -(i00 * l_up0); K[1][4] = -(i01 * l_up0);      // Q_us columns 4, 5 = diag(l_up0, l_up1): the zero products are
         K[0][5] = -(i01 * l_up1); K[1][5] = -(i11 * l_up1);      // written out (x*0 and x+0 are not foldable in IEEE arithmetic)
@@ -596,7 +591,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
               K[1][b] = (b == 3) ? -inv_dt : 0.0;
-              K[0][b] = -(Qus[0][b] + hod * K[1][b]) * ih;
+              K[0][b] = -fma(hod, K[1][b], Qus[0][b]) * ih;
             }
           }
         }
@@ -606,37 +601,36 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = (float)K[0][b]; Kf[i][2 * b + 1] = (float)K[1][b]; }
       gnorm = fmax(gnorm, fmax(fabs(k0), fabs(k1)));
       // expected change and value function (unregularised, symmetrised Quu)
-      const double Quuk0 = Quu00 * k0 + hod * k1, Quuk1 = hod * k0 + Quu11 * k1;
-      dV1 += k0 * Qu0 + k1 * Qu1;
-      dV2 += 0.5 * (k0 * Quuk0 + k1 * Quuk1);
+      const double Quuk0 = fma(Quu00, k0, hod * k1), Quuk1 = fma(hod, k0, Quu11 * k1);
+      dV1 = fma(k0, Qu0, fma(k1, Qu1, dV1));
+      dV2 = fma(0.5, fma(k0, Quuk0, k1 * Quuk1), dV2);
       const double t0 = Quuk0 + Qu0, t1 = Quuk1 + Qu1;
       double Vs[6];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const double qs = (b < 4) ? Qx[b < 4 ? b : 0] : (b == 4 ? Qp0 : Qp1);
-        const double uk = (b < 4) ? Qus[0][b] * k0 + Qus[1][b] * k1 : (b == 4 ? l_up0 * k0 : l_up1 * k1);
-        Vs[b] = qs + (K[0][b] * t0 + K[1][b] * t1) + uk;
-      }
+      for (int b = 0; b < 4; ++b) Vs[b] = fma(K[0][b], t0, fma(K[1][b], t1, fma(Qus[0][b], k0, fma(Qus[1][b], k1, Qx[b]))));
+      Vs[4] = fma(K[0][4], t0, fma(K[1][4], t1, fma(l_up0, k0, Qp0)));
+      Vs[5] = fma(K[0][5], t0, fma(K[1][5], t1, fma(l_up1, k1, Qp1)));
       double Vss[6][6];
+      // V_ss = Q_ss + K'Quu K + K'Q_us + Q_us'K.  The gains solve (Quu + mu I)_FF K_F = -Q_us,F on the free controls
+      // (rows of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
+      //   V_ss = Q_ss + Q_us'K - mu K'K
+      // (the familiar Q_ss - Q_su Quu^-1 Q_us when mu = 0).  Only the upper triangle is formed and mirrored.
 #pragma unroll
-      for (int a = 0; a < 6; ++a)
+      for (int a = 0; a < 4; ++a) {
 #pragma unroll
-        for (int b = a; b < 6; ++b) {
-          const double uK = (a < 4) ? Qus[0][a] * K[0][b] + Qus[1][a] * K[1][b] : (a == 4 ? l_up0 * K[0][b] : l_up1 * K[1][b]);
-          // V_ss = Q_ss + K'Quu K + K'Q_us + Q_us'K.  The gains solve (Quu + mu I)_FF K_F = -Q_us,F on the free controls
-          // (rows of clamped controls are zero), so K'Quu K = -K'Q_us - mu K'K and the three products collapse into
-          //   V_ss = Q_ss + Q_us'K - mu K'K
-          // (the familiar Q_ss - Q_su Quu^-1 Q_us when mu = 0).  Only the upper triangle is formed and mirrored.
-          if (a < 4 && b < 4) Vss[a][b] = Qxx[a < 4 ? a : 0][b < 4 ? b : 0] + uK;
-          else if (a == 4 && b == 4) Vss[a][b] = l_pp0 + uK;
-          else if (a == 5 && b == 5) Vss[a][b] = l_pp1 + uK;
-          else Vss[a][b] = uK;
-        }
+        for (int b = a; b < 4; ++b) Vss[a][b] = fma(Qus[0][a], K[0][b], fma(Qus[1][a], K[1][b], Qxx[a][b]));
+#pragma unroll
+        for (int b = 4; b < 6; ++b) Vss[a][b] = fma(Qus[0][a], K[0][b], Qus[1][a] * K[1][b]);
+      }
+      Vss[4][4] = fma(l_up0, K[0][4], l_pp0);
+      Vss[4][5] = l_up0 * K[0][5];
+      Vss[5][5] = fma(l_up1, K[1][5], l_pp1);
       if (mu != 0.0) {      // rare: the regularised iterations
+        const double mu_k = sp ? 0.0 : mu;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int b = a; b < 6; ++b) Vss[a][b] -= sp ? 0.0 : mu * (K[0][a] * K[0][b] + K[1][a] * K[1][b]);
+          for (int b = a; b < 6; ++b) Vss[a][b] = fma(-mu_k, fma(K[0][a], K[0][b], K[1][a] * K[1][b]), Vss[a][b]);
       }
       if (__any(sp)) {      // a prescribed feedback row: the identity above does not hold, the general form is evaluated
         if (sp) {
@@ -644,8 +638,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
           for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = a; b < 6; ++b) {
-              const double qk0 = Quu00 * K[0][b] + hod * K[1][b], qk1 = hod * K[0][b] + Quu11 * K[1][b];
-              Vss[a][b] += (K[0][a] * qk0 + K[1][a] * qk1) + (K[0][a] * Qus[0][b] + K[1][a] * Qus[1][b]);
+              const double qk0 = fma(Quu00, K[0][b], hod * K[1][b]), qk1 = fma(hod, K[0][b], Quu11 * K[1][b]);
+              Vss[a][b] += fma(K[0][a], qk0, K[1][a] * qk1) + fma(K[0][a], Qus[0][b], K[1][a] * Qus[1][b]);
             }
         }
       }
@@ -693,7 +687,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       Jn += ctrl_cost(i >= 1, nd, na, pnd, pna);                  // ctrl(nxt, i)
       if (i >= 1) Jn += track_cost(in.r, xs);                     // track(xs, i)
       double xn[4];
-      step(xs, nd, na, xn, TR[nxt][i]);
+      step(xs, nd, na, xn, LEAN ? TR[0][0] : TR[nxt][i]);
       S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
       xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
       pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
@@ -857,7 +851,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 // 8 agents per wave take 1.18 / 1.41 / 1.95 ms against 1.08, and so do two or four waves per workgroup (1.18 / 1.42 ms at
 // full waves): every wave streams its lanes' 5.4 KB of private memory through L2 each sweep whether the lanes are used or
 // not, and waves that share a CU share its path to it.
-template <int MAXT>
+template <int MAXT, bool LEAN = false>
 __global__ void __launch_bounds__(256)   // 1-4 waves per workgroup, one wave per SIMD: the register budget of a lone wave
 mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
            float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
@@ -870,7 +864,7 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
   const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  mpc_solve_lane<MAXT, false, false, LEAN>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
@@ -953,22 +947,29 @@ inline hipError_t mpc_refill_launch(int n, int T, const float* x0, const float* 
 }
 #endif
 
+template <bool LEAN>
+inline void mpc_launch_T(int n, int T, int live, dim3 grid, dim3 block, hipStream_t stream, const float* x0, const float* xref, const MpcP& p,
+                         float* sol, int* status, double* cost) {
+  if (T <= 8)
+    hipLaunchKernelGGL((mpc_kernel<8, LEAN>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else if (T <= 24)
+    hipLaunchKernelGGL((mpc_kernel<24, LEAN>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  else
+    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T, LEAN>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+}
+// trig: 0 = the rollout's trig stored for the backward sweep, 1 = recomputed there, anything else = by batch size (kMpcLeanFrom)
 inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1) {
+                             int* status, double* cost, hipStream_t stream, int live = 64, int wg_waves = 1, int trig = -1) {
   const MpcP p = mpc_pack(q);
   if (live < 1 || live > 64) live = 64;
   if (wg_waves < 1 || wg_waves > 4) wg_waves = 1;
   const size_t waves = ((size_t)n + live - 1) / live;
   const dim3 grid((unsigned)((waves + wg_waves - 1) / wg_waves)), block(64 * wg_waves);
-  if (T <= 8)
-    hipLaunchKernelGGL((mpc_kernel<8>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else if (T <= 24)
-    hipLaunchKernelGGL((mpc_kernel<24>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
-  else
-    hipLaunchKernelGGL((mpc_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, live, x0, xref, p, sol, status, cost);
+  const bool lean = trig == 1 || (trig != 0 && n >= kMpcLeanFrom);
+  if (lean) mpc_launch_T<true>(n, T, live, grid, block, stream, x0, xref, p, sol, status, cost);
+  else mpc_launch_T<false>(n, T, live, grid, block, stream, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 
 }  // namespace crx
 
-#pragma clang fp contract(off)

@@ -9,6 +9,7 @@ _P, _I = C.c_void_p, C.c_int
 _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
@@ -187,6 +188,23 @@ def mpc_solve_geometry(x0, xref, T, agents_per_wave=64, waves_per_workgroup=1, p
     cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
     L.check(xlib().crx_x_mpc_solve_geometry_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                                 L.stream_ptr(), int(agents_per_wave), int(waves_per_workgroup)), "crx_x_mpc_solve_geometry_dev")
+    return sol, status, cost
+
+
+def mpc_solve_trig(x0, xref, T, recompute_trig, params=None):
+    """mpc_solve with the source of the backward sweep's trig forced (0: stored by the rollout, 1: recomputed in the sweep; the product
+    picks by batch size).  The two give the same bits.  -> sol, status, cost."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+    status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+    cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    L.check(xlib().crx_x_mpc_solve_trig_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                            L.stream_ptr(), int(recompute_trig)), "crx_x_mpc_solve_trig_dev")
     return sol, status, cost
 
 

@@ -21,6 +21,12 @@ int crx_x_dare_from_v_lanes_dev(int n, int dim, const float* v, const crx_lqr_pa
 int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int lanes_per_agent);
 
+/* The MPC solve with the source of the backward sweep's trig forced: recompute_trig = 0 the rollout stores sin / cos / tan for it, 1 the
+ * sweep recomputes them (less memory traffic, more arithmetic).  Both give the same bits in every output; crx_mpc_solve_batch_dev picks by
+ * batch size (csrc/mpc_kernels.hip.h: kMpcLeanFrom). */
+int crx_x_mpc_solve_trig_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                             double* cost, void* stream, int recompute_trig);
+
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,

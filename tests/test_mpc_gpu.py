@@ -258,3 +258,36 @@ def test_mpc_answer_does_not_depend_on_the_batch(crx):
     assert torch.equal(st, st1) and torch.equal(sol.view(torch.int32), sol1.view(torch.int32)) and torch.equal(c.view(torch.int64), c1.view(torch.int64))
     sol2, st2, c2 = crx.mpc_solve(x0[:4096].contiguous(), xref[:4096].contiguous(), T, return_status=True)
     assert torch.equal(st[:4096], st2) and torch.equal(sol[:4096].view(torch.int32), sol2.view(torch.int32))
+    assert torch.equal(c[:4096].view(torch.int64), c2.view(torch.int64))
+
+
+@pytest.mark.parametrize("n,T,seed", [(8192, 21, 4), (8192, 21, 7), (8192, 6, 3), (2048, 40, 9), (65536, 21, 11)])
+def test_stored_and_recomputed_trig_give_the_same_bits(crx, n, T, seed):
+    """The backward sweep takes the rollout's trig from memory (small batches) or recomputes it (from kMpcLeanFrom agents on: less HBM
+    traffic).  Every fused multiply-add of the solver is spelled out, so the two are the same arithmetic: status, every solution float
+    and the double cost must be equal bit for bit."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_trig
+    x0, xref = mpc_problem(n, T, seed)
+    x0, xref = _t(x0), _t(xref)
+    a = mpc_solve_trig(x0, xref, T, 0)
+    b = mpc_solve_trig(x0, xref, T, 1)
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+    c = crx.mpc_solve(x0, xref, T, return_status=True)
+    assert torch.equal(c[0].view(torch.int32), a[0].view(torch.int32)) and torch.equal(c[2].view(torch.int64), a[2].view(torch.int64))
+
+
+def test_mpc_answer_does_not_depend_on_which_side_of_the_trig_switch_the_batch_is(crx):
+    """A 200,000-agent call runs the trig-recomputing kernel, a 4,096-agent call the trig-storing one: same agents, same bits."""
+    import torch
+    n, T = 200000, 21
+    x0, xref = mpc_problem(n, T, 78)
+    x0, xref = _t(x0), _t(xref)
+    sol, st, c = crx.mpc_solve(x0, xref, T, return_status=True)
+    for lo in (0, 123456):
+        sl = slice(lo, lo + 4096)
+        sol2, st2, c2 = crx.mpc_solve(x0[sl].contiguous(), xref[sl].contiguous(), T, return_status=True)
+        assert torch.equal(st[sl], st2) and torch.equal(sol[sl].view(torch.int32), sol2.view(torch.int32))
+        assert torch.equal(c[sl].view(torch.int64), c2.view(torch.int64))

@@ -134,3 +134,25 @@ def test_dt_split_is_the_double_product_on_every_float(tmp_path):
     subprocess.check_call(["g++", *flags, os.path.join(HERE, "tools", "dt_split_exhaustive.cpp"), "-o", exe])
     r = subprocess.run([exe, "1" if "-mfma" in flags else "257"], capture_output=True, text=True)
     assert r.returncode == 0 and " 0 mismatching;" in r.stdout and " 0 with |sin| or |cos|" in r.stdout, r.stdout
+
+
+def test_fast_sincos_gives_glibc_bits_on_every_float_of_its_domain(tmp_path):
+    """csrc/ekf_math.h: sincos_fast2 (round 5: range reduction by one fma against 1.5 * 2^52, Horner polynomials, v_bitop3 quadrant logic —
+    NOT glibc's operations) walked over every float with |y| < 128: the same sine and cosine bits as sincosf_ (= glibc's sinf / cosf on
+    all 2^32 inputs, tests/test_trig.py) wherever it reports "inside the fast domain", and "outside" exactly for |y| >= 120 and
+    |y| < 2^-100 (tests/tools/trig_fast_exhaustive.cpp; ~7 s on 8 cores).  Reference lines: /root/reference/src/extended_kalman_filter.cpp:30-31,43-45."""
+    import subprocess
+    exe = str(tmp_path / "tfe")
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-pthread"]
+    try:
+        cpuflags = open("/proc/cpuinfo").read()
+    except OSError:
+        cpuflags = ""
+    fma = " fma " in cpuflags or " fma\n" in cpuflags
+    if fma:
+        flags.append("-mfma")
+    subprocess.check_call(["g++", *flags, os.path.join(HERE, "tools", "trig_fast_exhaustive.cpp"), "-o", exe])
+    # without hardware fma the sweep goes through libm's fma(): a band of 2^24 patterns around the quadrant boundaries of |y| ~ 1..8 instead
+    r = subprocess.run([exe] if fma else [exe, "0x40800000"], capture_output=True, text=True)
+    print(r.stdout.strip())
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout

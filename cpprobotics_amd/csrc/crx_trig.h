@@ -182,6 +182,30 @@ CRX_HD float cosf_(float y) {
 // evaluated once, quadrant handled with selects.  Bit-identical to sinf_/cosf_ above: the sine
 // polynomial is odd in its argument and the "negated table" of the cosine polynomial is an exact
 // sign flip, so applying the quadrant sign after the polynomial commutes with every rounding.
+#if defined(__HIP_DEVICE_COMPILE__)
+// sincosf_ for a whole wave of ordinary angles (2^-100 <= |y| < 120): one angle of the fused EKF step's sincos_fast2 (csrc/ekf_math.h, where
+// the proof is described) — n = rint(y * 2/pi) by one fma against 1.5 * 2^52, Horner polynomials, the quadrant logic as v_bfe / v_bitop3.
+// NOT glibc's operations, glibc's RESULTS: tests/tools/trig_fast_exhaustive.cpp walks every float of the domain (run by the CPU tests).
+// ~23 VALU instructions against ~45 of the general path below with its compares and double selects.
+__device__ __forceinline__ void sincosf_wave_fast_(float y, float* sp, float* cp) {
+  typedef SinCosConsts C;
+  constexpr double two_over_pi = C::hpi_inv * 0x1p-24, magic = 0x1.8p52;
+  const double xd = (double)y;
+  const double t = __builtin_fma(xd, two_over_pi, magic);
+  const double x = __builtin_fma(-(t - magic), C::hpi, xd);
+  const double x2 = x * x, x3 = x * x2;
+  const double ps = __builtin_fma(x2, __builtin_fma(x2, C::s3, C::s2), C::s1);
+  const double pc = __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, C::c4, C::c3), C::c2), C::c1);
+  const uint32_t fs = f32_bits((float)__builtin_fma(x3, ps, x)), fc = f32_bits((float)__builtin_fma(x2, pc, C::c0));
+  const uint32_t n = (uint32_t)__double2loint(t);
+  const uint32_t odd = (uint32_t)__builtin_amdgcn_sbfe((int)n, 0u, 1u);
+  const uint32_t sr = __builtin_amdgcn_bitop3_b32(odd, fc, fs, 0xCA), cr = __builtin_amdgcn_bitop3_b32(odd, fs, fc, 0xCA);
+  const uint32_t qs = n << 30;
+  *sp = __uint_as_float(__builtin_amdgcn_bitop3_b32(sr, qs, 0x80000000u, 0x78));
+  *cp = __uint_as_float(__builtin_amdgcn_bitop3_b32(cr, qs + 0x40000000u, 0x80000000u, 0x78));
+}
+#endif
+
 CRX_HD void sincosf_(float y, float* sp, float* cp) {
   typedef SinCosConsts C;
   const uint32_t top = abstop12(y);
@@ -219,6 +243,17 @@ CRX_HD void sincosf_(float y, float* sp, float* cp) {
   if (top < 0x398u) { so = y; co = 1.0f; }  // |y| < 2^-12: sinf returns y, cosf returns 1
   *sp = so;
   *cp = co;
+}
+
+// sincosf_ for kernels whose waves evaluate it on ordinary angles together (the dynamic-window planner's trajectory roll-out: +6.6 %):
+// every active lane inside 2^-100 <= |y| < 120 -> the short form above, otherwise every lane takes the general one.  Same bits either
+// way.  (Inside sincosf_ itself the test and the second inlined body cost the particle filter 8 %: opt-in per call site.)
+CRX_HD void sincosf_wave_(float y, float* sp, float* cp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float ay = __builtin_fabsf(y);
+  if (__builtin_amdgcn_ballot_w64(!(ay >= 0x1p-100f && ay < 120.0f)) == 0) { sincosf_wave_fast_(y, sp, cp); return; }
+#endif
+  sincosf_(y, sp, cp);
 }
 
 // ---- expf -------------------------------------------------------------------------------------------------------------

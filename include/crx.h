@@ -194,7 +194,9 @@ void crx_mpc_default_params(crx_mpc_params* p);
  *      [x(T) | y(T) | yaw(T) | v(T) | delta(T-1) | a(T-1)]   (:54-60, :341-345).
  * status (may be NULL): per agent, bit0 = converged to tol, bit1 = a speed knot of the returned trajectory lies outside
  * [min_speed, max_speed] — which happens only when the START speed x0.v does (every rollout clamps the acceleration so that
- * later knots stay inside; with an infeasible start the acceleration limits win) —, bits 8.. = iterations used.  cost (may be NULL): final objective (double). */
+ * later knots stay inside; with an infeasible start the acceleration limits win) —, bits 8.. = iterations used.  cost (may be NULL): final objective (double).
+ * An agent's answer (sol, status, cost: every bit) depends on its own problem only — not on the batch it travels in, its size, the launch
+ * geometry or which form of the kernel the batch size selects (tests/test_mpc_gpu.py). */
 int crx_mpc_solve_batch(int n, int T, const float* x0, const float* xref,
                         const crx_mpc_params* prm, float* sol, int* status, double* cost);
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref,

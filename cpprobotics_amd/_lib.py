@@ -20,7 +20,7 @@ class LqrParams(C.Structure):
 class MpcParams(C.Structure):
     _fields_ = [(k, C.c_double) for k in (
         "dt", "wb", "max_steer", "max_accel", "max_speed", "min_speed", "r_a", "r_delta", "rd_a",
-        "rd_delta", "q_x", "q_y", "q_yaw", "q_v", "tol")] + [("max_iter", C.c_int)]
+        "rd_delta", "q_x", "q_y", "q_yaw", "q_v", "tol")] + [("max_iter", C.c_int), ("shared_gpu", C.c_int)]
 
 
 class Course(C.Structure):

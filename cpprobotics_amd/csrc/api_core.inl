@@ -164,6 +164,6 @@ void crx_mpc_default_params(crx_mpc_params* p) {
   p->max_speed = 55.0 / 3.6; p->min_speed = -20.0 / 3.6;
   p->r_a = 0.01; p->r_delta = 0.01; p->rd_a = 0.01; p->rd_delta = 1.0;
   p->q_x = 1.0; p->q_y = 1.0; p->q_yaw = 0.5; p->q_v = 0.5;
-  p->tol = 1e-9; p->max_iter = 50;
+  p->tol = 1e-9; p->max_iter = 50; p->shared_gpu = 0;
 }
 }  // extern "C"

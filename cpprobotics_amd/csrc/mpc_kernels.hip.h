@@ -257,6 +257,10 @@ struct MpcFeed {
 // is a latency chain (BASELINE configs[3]: 0.88 -> 0.93 ms; the persistent closed loop); 65,536 agents: equal
 // (profiles/r05/mpc_two_builds.jsonl).  The launcher picks it from kMpcLeanFrom agents on; the answer does not depend on the choice.
 constexpr int kMpcLeanFrom = 98304;
+// ... and from this many when the caller says the launch shares the GPU with others (crx_mpc_params.shared_gpu): alone, a 16,384-agent launch is
+// 6 % faster with the trig stored (2.66 vs 2.83 ms); six of them in flight next to the EKF launches of a configs[4] round are 3 % faster
+// recomputing it (0.481 -> 0.466 ms per round, profiles/r05/swarm_shared_gpu_hint_ab.txt)
+constexpr int kMpcLeanFromShared = 16384;
 template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
@@ -965,7 +969,7 @@ inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, c
   if (wg_waves < 1 || wg_waves > 4) wg_waves = 1;
   const size_t waves = ((size_t)n + live - 1) / live;
   const dim3 grid((unsigned)((waves + wg_waves - 1) / wg_waves)), block(64 * wg_waves);
-  const bool lean = trig == 1 || (trig != 0 && n >= kMpcLeanFrom);
+  const bool lean = trig == 1 || (trig != 0 && (n >= kMpcLeanFrom || (q.shared_gpu != 0 && n >= kMpcLeanFromShared)));
   if (lean) mpc_launch_T<true>(n, T, live, grid, block, stream, x0, xref, p, sol, status, cost);
   else mpc_launch_T<false>(n, T, live, grid, block, stream, x0, xref, p, sol, status, cost);
   return hipGetLastError();

@@ -335,7 +335,12 @@ class SwarmShard:
         self.n_total, self.n_plan, self.every = n * world, (n + plan_every - 1) // plan_every, plan_every
         self.q, self.r = _qr(Q, R)
         self.dc = crx.Course.from_numpy(course, device=device)
-        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, out=out))
+        # the planner launches of `depth` rounds and the EKF launches share the GPU: say so (crx_mpc_params.shared_gpu, a hint that
+        # selects the solve's low-traffic form; the answer is the same bits)
+        from .mpc import default_params
+        self.mpc_params = default_params()
+        self.mpc_params.shared_gpu = 1 if depth > 1 else 0
+        self.mpc_fn = mpc_fn if mpc_fn is not None else (lambda est, xref, Tm_, out: crx.mpc_solve(est, xref, Tm_, params=self.mpc_params, out=out))
         ci = np.random.default_rng(seed).integers(0, len(course[0]) - 30, self.n_total)[rank * n:(rank + 1) * n]
         self.start_index = ci
         cit = torch.from_numpy(ci).to(device)

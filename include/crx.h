@@ -183,6 +183,10 @@ typedef struct crx_mpc_params {
   double q_x, q_y, q_yaw, q_v; /* 1, 1, 0.5, 0.5  tracking cost :247-250 */
   double tol;        /* stop when the projected-gradient norm and the step are below tol */
   int max_iter;      /* outer iteration cap (the reference: IPOPT max_iter 50, :326)     */
+  int shared_gpu;    /* performance hint, never changes an answer (every form of the solve computes the same bits): 0 = this launch
+                        has the GPU to itself, the kernel form is picked by its size; nonzero = other launches run next to it (a
+                        pipelined host): from 16,384 agents on the form with the least memory traffic is used
+                        (configs[4]'s round: 0.481 -> 0.466 ms).  Sits in what was padding: sizeof and every offset are unchanged. */
 } crx_mpc_params;
 void crx_mpc_default_params(crx_mpc_params* p);
 

@@ -72,7 +72,9 @@ def test_version_and_defaults(crx):
     q = L.LqrParams(); l.crx_lqr_default_params(C.byref(q))
     assert (q.dt, q.L, q.maxiter) == (0.1, 0.5, 150) and abs(q.eps - 0.01) < 1e-9
     m = L.MpcParams(); l.crx_mpc_default_params(C.byref(m))
-    assert (m.dt, m.wb, m.max_accel, m.max_iter) == (0.2, 2.5, 1.0, 50)
+    assert (m.dt, m.wb, m.max_accel, m.max_iter, m.shared_gpu) == (0.2, 2.5, 1.0, 50, 0)
+    import ctypes
+    assert ctypes.sizeof(m) == 128                      # shared_gpu sits in what was padding behind max_iter
     assert abs(m.max_steer - np.pi / 4) < 1e-15 and abs(m.max_speed - 55 / 3.6) < 1e-12
 
 

@@ -291,3 +291,16 @@ def test_mpc_answer_does_not_depend_on_which_side_of_the_trig_switch_the_batch_i
         sol2, st2, c2 = crx.mpc_solve(x0[sl].contiguous(), xref[sl].contiguous(), T, return_status=True)
         assert torch.equal(st[sl], st2) and torch.equal(sol[sl].view(torch.int32), sol2.view(torch.int32))
         assert torch.equal(c[sl].view(torch.int64), c2.view(torch.int64))
+
+
+def test_shared_gpu_hint_changes_the_kernel_form_not_the_answer(crx):
+    """crx_mpc_params.shared_gpu selects the low-traffic form of the solve from 16,384 agents on (a pipelined host's launches share the
+    GPU); it is a performance hint: status, solution and cost are the same bits."""
+    import torch
+    from cpprobotics_amd.mpc import default_params
+    x0, xref = mpc_problem(16384, 21, 31)
+    x0, xref = _t(x0), _t(xref)
+    a = crx.mpc_solve(x0, xref, 21, return_status=True)
+    p = default_params(); p.shared_gpu = 1
+    b = crx.mpc_solve(x0, xref, 21, params=p, return_status=True)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))

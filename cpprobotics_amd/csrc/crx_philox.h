@@ -69,7 +69,13 @@ CRX_HD void philox_box_muller(uint32_t a, uint32_t b, float* z0, float* z1) {
   const double r2 = -2.0 * philox_log(u1);
   const float r = (float)__builtin_sqrt(r2);
   float sn, cs;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // theta is +0 or in [2^-24 * 2 pi, 2 pi): inside the domain on which the short form of crx_trig.h gives sinf's / cosf's bits (every
+  // float walked, tests/tools/trig_fast_exhaustive.cpp); +0 -> (+0, 1) as well.  Half the instructions of the general form.
+  sincosf_wave_fast_(theta, &sn, &cs);
+#else
   sincosf_(theta, &sn, &cs);
+#endif
   *z0 = r * cs;
   *z1 = r * sn;
 }

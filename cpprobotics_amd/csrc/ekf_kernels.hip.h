@@ -21,6 +21,7 @@
 // (16-byte stores, coalesced).  State and covariance live in VGPRs for all T steps.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "crx_trig.h"
 #include "ekf_math.h"
 
@@ -219,7 +220,11 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
   // main part: every chunk of D steps whose prefetches (t + D) stay inside [0, T).  One basic block
   // per chunk; the D loads of the next chunk stay in flight across it (counted vmcnt waits).
   int t0 = 0;
-  for (; t0 + 2 * D <= T; t0 += D) {
+  // LAST: the one chunk behind the main part whose prefetches would partly run past step T - 1 — the same fast steps, the refill of a
+  // slot guarded (until round 5 these up to D steps went through the general step of the tail: 8 of the headline's 1000, 4 of the
+  // 100 of a configs[4] round, at 2-3x the cost each)
+  auto chunk = [&](auto last) {
+    constexpr bool LAST = decltype(last)::value;
     const EkfStateP s_in = sp;
     FastDomain dom = fast_domain_init();
     __amdgpu_buffer_rsrc_t rz, ru, rx, rp;
@@ -234,12 +239,14 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
       const size_t t = (size_t)(t0 + d);
       ekf_step_packed<DTS>(sp, zq[d], uq[d], kp, dom);
       // refill the slot just consumed (its registers are dead now: no copy at the loop back-edge)
-      if (BUF) {
-        zq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rz, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
-        uq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ru, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
-      } else {
-        zq[d] = __builtin_nontemporal_load(&(z2 + (t + D) * ns)[lane]);
-        uq[d] = __builtin_nontemporal_load(&(u2 + (t + D) * ns)[lane]);
+      if (!LAST || t0 + d + D < T) {
+        if (BUF) {
+          zq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rz, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
+          uq[d] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(ru, lane * 8u, (unsigned)(d + D) * un * 8u, 2));
+        } else {
+          zq[d] = __builtin_nontemporal_load(&(z2 + (t + D) * ns)[lane]);
+          uq[d] = __builtin_nontemporal_load(&(u2 + (t + D) * ns)[lane]);
+        }
       }
       if (XHIST) {
         const v4f xo = v4f{sp.x01.x, sp.x01.y, sp.x23.x, sp.x23.y};
@@ -292,8 +299,10 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
       }
       pack_state(sp, s);
     }
-  }
-  // tail: fewer than 2*D steps left — general step, guarded prefetch
+  };
+  for (; t0 + 2 * D <= T; t0 += D) chunk(std::false_type{});
+  if (t0 + D <= T) { chunk(std::true_type{}); t0 += D; }
+  // tail: fewer than D steps left — general step, guarded prefetch
   unpack_state(s, sp);
   for (; t0 < T; t0 += D) {
 #pragma unroll

@@ -122,6 +122,25 @@ def test_ekf_fused_run_bit_exact(crx, oracle_mod, n, T):
         assert bit_equal(xd2.cpu().numpy(), xo) and bit_equal(Pd2.cpu().numpy(), Po)
 
 
+@pytest.mark.parametrize("T", [256, 257, 263, 264, 265, 271, 272])
+def test_ekf_fused_run_long_chunks_every_remainder(crx, oracle_mod, T):
+    """Launches of >= 256 steps without the covariance history run eight steps per chunk (csrc/api_ekf.inl); the last full chunk keeps
+    the fast step with a guarded refill and fewer than eight steps are left to the general tail (round 5): every remainder T mod 8,
+    histories and final state bit for bit against the oracle, with and without the x history."""
+    import torch
+    n = 130
+    Q, R = ekf_QR()
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, n, T, seed=9000 + T)
+    xo, Po, xho, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R)
+    for want_x in (True, False):
+        xd, Pd = _t(x0), _t(P0)
+        xh = torch.empty((T, n, 4), dtype=torch.float32, device="cuda") if want_x else None
+        crx.ekf_run(xd, Pd, _t(z), _t(ud), Q, R, x_hist=xh)
+        if want_x:
+            assert bit_equal(xh.cpu().numpy(), xho)
+        assert bit_equal(xd.cpu().numpy(), xo) and bit_equal(Pd.cpu().numpy(), Po)
+
+
 def test_ekf_simulate_inputs_bit_exact(crx, oracle_mod):
     import torch
     n, T = 333, 50

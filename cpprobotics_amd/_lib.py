@@ -236,7 +236,32 @@ KERNEL_FAMILIES = {
     "side": ("dare_", "mpc_kernel", "mpc_portfolio_kernel", "ekf_step_kernel", "lqr_closed_loop"),
     "mpc": ("mpc_kernel",),
 }
-_LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def llvm_bin_dir():
+    """Where clang-offload-bundler / llvm-objdump of the ROCm that built the library live: next to $HIPCC's ROCm, under $ROCM_PATH,
+    under `hipconfig --rocmpath`, else /opt/rocm — the same precedence csrc/Makefile gives HIPCC (this was hard-coded)."""
+    import shutil
+    import subprocess
+    cands = []
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    hc = shutil.which("hipconfig")
+    if hc:
+        try:
+            cands.append(os.path.join(subprocess.run([hc, "--rocmpath"], capture_output=True, text=True, timeout=20).stdout.strip(), "lib", "llvm", "bin"))
+        except Exception:
+            pass
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-objdump")) and os.path.exists(os.path.join(c, "clang-offload-bundler")):
+            return c
+    raise FileNotFoundError("no ROCm LLVM tools (llvm-objdump, clang-offload-bundler) under any of: " + ", ".join(cands))
+
+
 _code_hashes = {}
 
 
@@ -245,11 +270,15 @@ def disassemble_code_object(lib):
     import subprocess
     import tempfile
     with tempfile.TemporaryDirectory() as d:
+        import shutil
         fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
-        subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
-        subprocess.check_call([os.path.join(_LLVM_BIN, "clang-offload-bundler"), "--unbundle", "--type=o",
+        llvm = llvm_bin_dir()
+        # binutils' objcopy where the host has it, ROCm's llvm-objcopy otherwise
+        objcopy = shutil.which("objcopy") or os.path.join(llvm, "llvm-objcopy")
+        subprocess.check_call([objcopy, "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
-        return subprocess.run([os.path.join(_LLVM_BIN, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+        return subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
 
 
 def _functions_of_disassembly(text):

@@ -7,6 +7,31 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // agents_per_wave (1..64) and waves_per_workgroup (1..4): the launch geometry; the product entry point uses full waves in
 // single-wave workgroups (every emptier or stacked geometry measured slower: profiles/r02/mpc_tail.txt).
+// Every hardware queue a kernel with private (scratch) memory has run on keeps a reservation sized for a full device of its waves, all
+// out of one pool: the solver's 3.8-5 KB per lane is ~0.3 MB per wave, 12 queues holding one work, 16 end the PROCESS with
+// HSA_STATUS_ERROR_OUT_OF_RESOURCES whatever the batch size (profiles/r05/scratch_queues_probe.jsonl) — an abort no caller of a C
+// function expects.  The library therefore counts the distinct (device, stream) pairs the private-memory solver has been launched
+// on and refuses the 13th with CRX_ERR_INVALID instead.  Streams are counted, not hardware queues (the runtime
+// does not say which queue a stream lands on): conservative when several streams share a queue.  The tile kernel
+// (mpc_tile_kernels.hip.h) has no private memory and is not counted.
+static const int kMaxPrivateMemoryStreams = 12;
+static int scratch_stream_admit(void* stream) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, void*>> seen;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+  std::lock_guard<std::mutex> l(mu);
+  for (const auto& s : seen) if (s.first == dev && s.second == stream) return CRX_OK;
+  int on_dev = 0;
+  for (const auto& s : seen) on_dev += s.first == dev;
+  if (on_dev >= kMaxPrivateMemoryStreams)
+    return fail(CRX_ERR_INVALID, "mpc_solve: this would be the 13th distinct stream of this device to run the private-memory solver; every hardware "
+                                 "queue it has run on keeps a full-device scratch reservation and 16 of them abort the process "
+                                 "(HSA_STATUS_ERROR_OUT_OF_RESOURCES) — keep the solver on <= 12 streams (INTEGRATION.md 7)");
+  seen.emplace_back(dev, stream);
+  return CRX_OK;
+}
+
 static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream, int agents_per_wave, int waves_per_workgroup, int trig = -1) {
   if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol)))
@@ -17,6 +42,7 @@ static int mpc_solve_launch(int n, int T, const float* x0, const float* xref, co
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
+  if (int rc = scratch_stream_admit(stream)) return rc;
   const hipError_t e = crx::mpc_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, waves_per_workgroup, trig);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 }
@@ -63,10 +89,30 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 #endif
 }
+// The tile layout (mpc_tile_kernels.hip.h): controls in LDS, feedback gains in accumulator registers; T <= 21.
+static int mpc_solve_tile(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                          double* cost, void* stream) {
+  if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (tile layout): bad argument (2 <= T <= 21)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_tile_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile launch");
+}
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
   CRX_TRACE();
   return mpc_solve_lanes(n, T, x0, xref, prm, sol, status, cost, stream, 0);
+}
+// store: 0 = private memory (mpc_kernel), 1 = the tile layout (mpc_tile_kernel).  Bit-identical answers.
+int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                              double* cost, void* stream, int store) {
+  CRX_TRACE();
+  if (store == 1) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream);
+  if (store != 0) return fail(CRX_ERR_INVALID, "mpc_solve (store): store must be 0 (private memory) or 1 (tile layout)");
+  return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 }
 // mpc_solve for n agents with the four-variant portfolio (mpc_kernels.hip.h: mpc_variant): the same NLP, every agent answered by the
 // variant of the solver that converges in the fewest sweeps.

@@ -16,6 +16,7 @@
 #include "dare_kernels.hip.h"
 #include "ekf_kernels.hip.h"
 #include "mpc_kernels.hip.h"
+#include "mpc_tile_kernels.hip.h"
 #include "track_kernels.hip.h"
 #include "pf_kernels.hip.h"
 #include "dwa_kernels.hip.h"

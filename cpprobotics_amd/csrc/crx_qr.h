@@ -7,8 +7,12 @@
 // (down-dated) norm with LAPACK's re-computation rule (lawn176), Householder reflectors stored below the diagonal
 // (MatrixBase::makeHouseholder), Q^T applied reflector by reflector (applyHouseholderOnTheLeft), column-oriented back
 // substitution on the leading block, column permutation undone (ColPivHouseholderQR.h: computeInPlace, _solve_impl).
-// Reductions run in ascending order — what Eigen's dynamic-size block reductions do below one packet, i.e. for the 2x2 and
-// 3x3 systems.  (An independent statement of the same algorithm, oracle/eigen_qr.h, is what the oracle and the Eigen stand-in
+// Reductions: the in-loop ones (Householder tail norms, down-date re-computations, essential^T * bottom) are dynamic-size blocks
+// in Eigen even for a fixed-size matrix — ascending below one packet, i.e. for the 2x2 and 3x3 systems.  The INITIAL column norms
+// of a fixed-size matrix (FIXED = true: Matrix3f of the quintic, Matrix2f of the quartic) are a completely unrolled redux, a tree
+// of halves: t0 + (t1 + t2) for three rows (round 6; oracle/eigen_qr.h (1) has the derivation from Core/Redux.h).  The nx x nx
+// spline system is a MatrixXf (FIXED = false): ascending here, address-dependent packets in Eigen from 4 rows on (unpinned).
+// (An independent statement of the same algorithm, oracle/eigen_qr.h, is what the oracle and the Eigen stand-in
 // of the reference build use; the two must agree bit for bit, tests/test_oracle_frenet.py.)
 // The library is built -ffp-contract=off with IEEE fp32 division and sqrt: host and device produce the same bits.
 #pragma once
@@ -18,8 +22,9 @@
 namespace crx {
 
 // A: n x n column-major (A[i + n*j]), overwritten by the factorisation; b overwritten; x receives the solution.  n <= NMAX.
-template <int NMAX>
+template <int NMAX, bool FIXED = false>
 CRX_HD void colpiv_qr_solve(const int n, float* A, float* b, float* x) {
+  static_assert(!FIXED || NMAX <= 3, "the fixed-size reduction tree is written out for the reference's 2x2 and 3x3 systems");
   float hc[NMAX], nu[NMAX], nd[NMAX], tmp[NMAX];
   int perm[NMAX];
 #define CRX_AT(i, j) A[(i) + n * (j)]
@@ -29,7 +34,15 @@ CRX_HD void colpiv_qr_solve(const int n, float* A, float* b, float* x) {
     for (int i = from + 1; i < n; ++i) s = s + CRX_AT(i, j) * CRX_AT(i, j);
     return __builtin_sqrtf(s);
   };
-  for (int k = 0; k < n; ++k) { nd[k] = col_norm(k, 0); nu[k] = nd[k]; perm[k] = k; }
+  auto col_norm_fixed = [&](int j) -> float {      // redux_novec_unroller<0, n>: 1: t0 | 2: t0 + t1 | 3: t0 + (t1 + t2)
+    const float t0 = CRX_AT(0, j) * CRX_AT(0, j);
+    if (n == 1) return __builtin_sqrtf(t0);
+    const float t1 = CRX_AT(1, j) * CRX_AT(1, j);
+    if (n == 2) return __builtin_sqrtf(t0 + t1);
+    const float t2 = CRX_AT(2, j) * CRX_AT(2, j);
+    return __builtin_sqrtf(t0 + (t1 + t2));
+  };
+  for (int k = 0; k < n; ++k) { nd[k] = FIXED ? col_norm_fixed(k) : col_norm(k, 0); nu[k] = nd[k]; perm[k] = k; }
   float maxnorm = nu[0];
   for (int k = 1; k < n; ++k) if (nu[k] > maxnorm) maxnorm = nu[k];
   const float eps = FLT_EPSILON;

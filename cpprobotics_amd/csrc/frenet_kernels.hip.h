@@ -66,7 +66,7 @@ __device__ __forceinline__ FrQuintic fr_quintic(float xs, float vxs, float axs, 
                 (float)T5, (float)(5.0 * T4), (float)(20.0 * T3)};         // column 2
   float B[3] = {(float)((double)(xe - q.a0 - q.a1 * T) - (double)q.a2 * T2), vxe - q.a1 - 2.0f * q.a2 * T, axe - 2.0f * q.a2};
   float c[3];
-  colpiv_qr_solve<3>(3, A, B, c);
+  colpiv_qr_solve<3, true>(3, A, B, c);
   q.a3 = c[0]; q.a4 = c[1]; q.a5 = c[2];
   return q;
 }
@@ -77,7 +77,7 @@ __device__ __forceinline__ FrQuartic fr_quartic(float xs, float vxs, float axs, 
   float A[4] = {(float)(3.0 * T2), 6.0f * T, (float)(4.0 * T3), (float)(12.0 * T2)};
   float B[2] = {vxe - q.a1 - 2.0f * q.a2 * T, axe - 2.0f * q.a2};
   float c[2];
-  colpiv_qr_solve<2>(2, A, B, c);
+  colpiv_qr_solve<2, true>(2, A, B, c);
   q.a3 = c[0]; q.a4 = c[1];
   return q;
 }

@@ -31,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/crx.h"
+#include "mpc_agpr.inc"      // the accumulator-register store of the tile layout's feedback gains (generated: scripts/gen_mpc_agpr.py)
 
 #define CRX_MPC_MAX_T 64
 
@@ -261,11 +262,23 @@ constexpr int kMpcLeanFrom = 98304;
 // 6 % faster with the trig stored (2.66 vs 2.83 ms); six of them in flight next to the EKF launches of a configs[4] round are 3 % faster
 // recomputing it (0.481 -> 0.466 ms per round, profiles/r05/swarm_shared_gpu_hint_ab.txt)
 constexpr int kMpcLeanFromShared = 16384;
-template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false>
+// STORE: where the lane's working set lives.
+//   0  private memory, all of it (mpc_kernel, the portfolio, the closed loop; every horizon up to CRX_MPC_MAX_T)
+//   1  the TILE layout of mpc_tile_kernels.hip.h (round 6; horizons of at most kMpcTileStages stages): both control buffers in the
+//      wave's 40 KB of LDS, the float feedback gains of stages 1 .. 18 in accumulator registers a40 .. a255 (mpc_agpr.inc; stage 0's
+//      gains multiply dx = 0 and are never stored; stage 19's stay private), knots and feed-forward steps still private.  The same operations on the same
+//      doubles in the same order as STORE = 0: bit-identical outputs (tests/test_mpc_gpu.py compares the two on the device).
+constexpr int kMpcTileStages = 20;                     // T <= 21: the BASELINE horizon (configs[3], configs[4]) and the reference's own T 6
+typedef double mpc_d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) mpc_d2_t lds_double2_t;
+struct MpcTile { lds_double2_t* u; };                  // the wave's [2][kMpcTileStages][64] double2 of LDS: (delta, a) of buffer c, stage i, lane l
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false, int STORE = 0>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
-                                               const MpcFeed feed = MpcFeed{}) {
+                                               const MpcFeed feed = MpcFeed{}, const MpcTile tile = MpcTile{}) {
   static_assert(!(PORTFOLIO && REFILL), "the portfolio runs in the latency regime");
+  constexpr bool TILE = STORE == 1;
+  static_assert(!TILE || (LEAN && MAXT <= kMpcTileStages + 4), "the tile layout recomputes the trig and holds at most kMpcTileStages stages");
   bool live = live_in;
   float4 xi = xi_in;
   const float4* __restrict__ xr4 = xr4_in;
@@ -277,13 +290,45 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
 
   // per-lane problem storage (private memory)
   double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
-  double U[2][MAXT][2];   // stages: delta, a
+  double U[TILE ? 1 : 2][TILE ? 1 : MAXT][2];   // stages: delta, a   (TILE: in LDS, tile.u)
   double kf[MAXT][2];     // feed-forward
   // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev) — kept in FLOAT (round 5): the gains only steer the candidate rollouts
   // (u + alpha k + K dx), the fixed point is decided by the feed-forward k (double) alone, and they are 41 % of the solver's memory
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
-  float Kf[MAXT][12];
+  float Kf[TILE ? (MAXT > CRX_MPC_AGPR_SLOTS + 1 ? MAXT - CRX_MPC_AGPR_SLOTS - 1 : 1) : MAXT][12];   // (TILE: stages 1 .. 18 in accumulator registers)
+  // ---- accessors of the controls and the gains (the only places that know where they live) --------------------------------------
+  const int tile_lane = (int)(threadIdx.x & 63);
+  auto ldU = [&](int c, int i, double& d, double& a) {
+    if constexpr (TILE) { const mpc_d2_t v = tile.u[(c * kMpcTileStages + i) * 64 + tile_lane]; d = v.x; a = v.y; }
+    else { d = U[c][i][0]; a = U[c][i][1]; }
+  };
+  auto stU = [&](int c, int i, double d, double a) {
+    if constexpr (TILE) tile.u[(c * kMpcTileStages + i) * 64 + tile_lane] = mpc_d2_t{d, a};
+    else { U[c][i][0] = d; U[c][i][1] = a; }
+  };
+  auto stKf = [&](int i, const float (&g)[12]) {        // i: wave-uniform (the stage loops run in lockstep)
+    if constexpr (TILE) {
+      if (i > CRX_MPC_AGPR_SLOTS) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Kf[i - CRX_MPC_AGPR_SLOTS - 1][a] = g[a];
+      } else if (i >= 1) mpc_agpr_store12(i - 1, g);
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) Kf[i][a] = g[a];
+    }
+  };
+  auto ldKf = [&](int i, float (&g)[12]) {
+    if constexpr (TILE) {
+      if (i > CRX_MPC_AGPR_SLOTS) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) g[a] = Kf[i - CRX_MPC_AGPR_SLOTS - 1][a];
+      } else mpc_agpr_load12(i - 1, g);                 // stage 0 (slot -1): zeros — its gains multiply dx = 0
+    } else {
+#pragma unroll
+      for (int a = 0; a < 12; ++a) g[a] = Kf[i][a];
+    }
+  };
   double TR[LEAN ? 1 : 2][LEAN ? 1 : MAXT][3];  // sin(yaw_i), cos(yaw_i), tan(delta_i) of each rollout: the backward sweep reuses them (LEAN: recomputes them)
 
   const double dt = p.dt, wb = p.wb;
@@ -313,10 +358,6 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     return v;
   };
   auto track = [&](const double* s, int i) -> double { return track_cost(xr4[i], s); };
-  auto ctrl = [&](int c, int i) -> double {
-    const int j = i >= 1 ? i - 1 : 0;
-    return ctrl_cost(i >= 1, U[c][i][0], U[c][i][1], U[c][j][0], U[c][j][1]);
-  };
   auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
     double sn_, cs_;
     mpc_sincos(s[2], &sn_, &cs_);
@@ -339,9 +380,11 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     RollIn q;
 #pragma unroll
     for (int a = 0; a < 4; ++a) q.s[a] = S[c][i][a];
-    q.u0 = U[c][i][0]; q.u1 = U[c][i][1]; q.k0 = kf[i][0]; q.k1 = kf[i][1];
+    ldU(c, i, q.u0, q.u1); q.k0 = kf[i][0]; q.k1 = kf[i][1];
+    float g[12];
+    ldKf(i, g);
 #pragma unroll
-    for (int a = 0; a < 12; ++a) q.K[a] = (double)Kf[i][a];
+    for (int a = 0; a < 12; ++a) q.K[a] = (double)g[a];
     q.r = xr4[i];
     return q;
   };
@@ -364,11 +407,13 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     S[0][0][2] = S[1][0][2] = (double)xi.z;
     S[0][0][3] = S[1][0][3] = (double)xi.w;
     J = 0.0;
+    double a_prev = 0.0;
     for (int i = 0; i < N; ++i) {
       const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
       const double a0 = clampd(0.0, ab.lo, ab.hi);
-      U[0][i][0] = 0.0; U[0][i][1] = a0;
-      J += ctrl(0, i);
+      stU(0, i, 0.0, a0);
+      J += ctrl_cost(i >= 1, 0.0, a0, 0.0, a_prev);      // the controls of stages i, i - 1
+      a_prev = a0;
       if (i >= 1) J += track(S[0][i], i);
       step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
     }
@@ -396,8 +441,10 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     }
     if (so_)
       for (int i = 0; i < N; ++i) {
-        so_[4 * T + i] = (float)U[cur][i][0];
-        so_[4 * T + N + i] = (float)U[cur][i][1];
+        double ud_, ua_;
+        ldU(cur, i, ud_, ua_);
+        so_[4 * T + i] = (float)ud_;
+        so_[4 * T + N + i] = (float)ua_;
       }
   };
   auto quad_converged = [&]() -> unsigned {       // which lanes of this lane's quad have converged (bit r = variant r)
@@ -437,8 +484,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     // i - 1's knot, trig and reference and stage i - 2's control are requested at the top of stage i and consumed one
     // iteration later.
     StageIn nx = load_stage(cur, N - 1);
-    double uc0 = U[cur][N - 1][0], uc1 = U[cur][N - 1][1];
-    double up0 = U[cur][N >= 2 ? N - 2 : 0][0], up1 = U[cur][N >= 2 ? N - 2 : 0][1];
+    double uc0, uc1, up0, up1;
+    ldU(cur, N - 1, uc0, uc1);
+    ldU(cur, N >= 2 ? N - 2 : 0, up0, up1);
 #if CRX_MPC_TICKS >= 2
     const long long tk_b0 = clock64();
 #endif
@@ -451,7 +499,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       // around them the compiler has to drain the memory queue (vmcnt(0)) before the first use of `in`
       nx = load_stage(cur, i >= 1 ? i - 1 : 0);
       uc0 = up0; uc1 = up1;
-      { const int j = i >= 2 ? i - 2 : 0; up0 = U[cur][j][0]; up1 = U[cur][j][1]; }
+      ldU(cur, i >= 2 ? i - 2 : 0, up0, up1);
       const double s[4] = {in.s0, in.s1, in.s2, in.s3};
       double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
       if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
@@ -601,8 +649,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
         }
       }
       kf[i][0] = k0; kf[i][1] = k1;
+      {
+        float g[12];
 #pragma unroll
-      for (int b = 0; b < 6; ++b) { Kf[i][2 * b] = (float)K[0][b]; Kf[i][2 * b + 1] = (float)K[1][b]; }
+        for (int b = 0; b < 6; ++b) { g[2 * b] = (float)K[0][b]; g[2 * b + 1] = (float)K[1][b]; }
+        stKf(i, g);
+      }
       gnorm = fmax(gnorm, fmax(fabs(k0), fabs(k1)));
       // expected change and value function (unregularised, symmetrised Quu)
       const double Quuk0 = fma(Quu00, k0, hod * k1), Quuk1 = fma(hod, k0, Quu11 * k1);
@@ -687,7 +739,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       const AccelBox nb = accel_box(p, inv_dt, xs[3]);            // the box of a_i at the NEW speed of knot i
       const double nd = clampd(in.u0 + du0, lb0, ub0);
       const double na = clampd(in.u1 + du1, nb.lo, nb.hi);
-      U[nxt][i][0] = nd; U[nxt][i][1] = na;
+      stU(nxt, i, nd, na);
       Jn += ctrl_cost(i >= 1, nd, na, pnd, pna);                  // ctrl(nxt, i)
       if (i >= 1) Jn += track_cost(in.r, xs);                     // track(xs, i)
       double xn[4];
@@ -844,8 +896,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     if (ln == 0) cost_out = (double)tt; if (ln == 1) cost_out = (double)tk_b; if (ln == 2) cost_out = (double)tk_f;
     if (ln == 3) cost_out = (double)tk_nb; if (ln == 4) cost_out = (double)tk_nf; }
 #endif
-  d0_out = (float)U[cur][0][0];
-  a0_out = (float)U[cur][0][1];
+  {
+    double ud_, ua_;
+    ldU(cur, 0, ud_, ua_);
+    d0_out = (float)ud_;
+    a0_out = (float)ua_;
+  }
 }
 
 // `live_lanes` agents in the low lanes of every wave, `blockDim.x / 64` waves per workgroup.  Production: full waves (64) in

@@ -10,6 +10,7 @@ _X_SIGNATURES = {
     "crx_x_dare_from_v_lanes_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
+    "crx_x_mpc_solve_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
@@ -205,6 +206,27 @@ def mpc_solve_trig(x0, xref, T, recompute_trig, params=None):
     cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
     L.check(xlib().crx_x_mpc_solve_trig_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                             L.stream_ptr(), int(recompute_trig)), "crx_x_mpc_solve_trig_dev")
+    return sol, status, cost
+
+
+def mpc_solve_store(x0, xref, T, store, params=None, out=None):
+    """mpc_solve with the layout of the lane's working set forced (0: private memory, crx::mpc_kernel; 1: the tile layout of round 6,
+    crx::mpc_tile_kernel — controls in LDS, feedback gains in accumulator registers, T <= 21).  The two give the same bits.
+    -> sol, status, cost."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    if out is not None:
+        sol, status, cost = out
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    L.check(xlib().crx_x_mpc_solve_store_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                             L.stream_ptr(), int(store)), "crx_x_mpc_solve_store_dev")
     return sol, status, cost
 
 

@@ -146,19 +146,39 @@ class ChunkedTrajectoryGather:
         return self.gathered.permute(0, 2, 1, 3, 4).reshape(self.T, self.world * self.nl, self.C).contiguous()
 
 
+def _env_int(name):
+    """The integer value of an environment variable, or None (unset, empty, or not a number — said once, not raised)."""
+    import os
+    cur = os.environ.get(name)
+    if cur is None or not cur.strip():
+        return None
+    try:
+        return int(cur)
+    except ValueError:
+        import warnings
+        warnings.warn(f"{name}={cur!r} is not a number: ignored")
+        return None
+
+
 def want_hw_queues(streams):
     """The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams that share a queue
     run their kernels one after the other.  A pipelined round — one launch stream + `depth` planner streams (+ RCCL's) — needs a queue per
     stream: measured on one MI355X at depth 6, 0.74 ms per round with 4 queues, 0.49 with 8 (profiles/r05/swarm_hw_queues.txt).  The
-    variable is read when the runtime initialises the device, so this must run before the process first touches the GPU; returns what is
-    in effect (None if the device was already initialised without it: the caller then runs with the default)."""
+    variable is read when the runtime initialises the device, so this only has an effect before the process first touches the GPU: a
+    process-start call (bench.py, scripts/swarm_bench.py and tests/swarm_checks.py export the variable themselves; SwarmShard calls this
+    as its first statement and otherwise only CHECKS).  Returns the queue count in effect for a device initialised from now on — None
+    if the device was already initialised without the variable (the caller then runs on the runtime's default).  A value the user set
+    is never lowered, and it is raised only while that still has an effect — with a warning, since it overrides a deliberate setting."""
     import os
     want = max(8, int(streams))
-    cur = os.environ.get("GPU_MAX_HW_QUEUES")
-    if cur is not None and int(cur) >= want:
-        return int(cur)
+    cur = _env_int("GPU_MAX_HW_QUEUES")
+    if cur is not None and cur >= want:
+        return cur
     if torch.cuda.is_available() and torch.cuda.is_initialized():
-        return int(cur) if cur is not None else None
+        return cur
+    if cur is not None:
+        import warnings
+        warnings.warn(f"GPU_MAX_HW_QUEUES={cur} raised to {want}: {int(streams)} streams need a hardware queue each")
     os.environ["GPU_MAX_HW_QUEUES"] = str(want)
     return want
 
@@ -180,6 +200,24 @@ def planner_streams(device, depth):
     return have[:depth]
 
 
+def _with_slot(plan_launch, self_depth=1):
+    """plan_launch(est, slot) is the signature since round 5; a callable written against the earlier plan_launch(est) is accepted while
+    a single slot exists (depth 1: nothing else is in flight, so it cannot write into another round's buffers) and refused with a clear
+    message otherwise — instead of a TypeError from inside run()."""
+    import inspect
+    try:
+        params = [p for p in inspect.signature(plan_launch).parameters.values()
+                  if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD, p.VAR_POSITIONAL)]
+    except (TypeError, ValueError):
+        return plan_launch
+    if any(p.kind == p.VAR_POSITIONAL for p in params) or len(params) >= 2:
+        return plan_launch
+    if max(1, int(self_depth)) > 1:
+        raise TypeError("MixedSwarmRound: plan_launch must take (est, slot) when depth > 1 — the planners of the other slots are still "
+                        "running, every buffer a launch writes has to belong to its slot")
+    return lambda est, slot: plan_launch(est)
+
+
 class MixedSwarmRound:
     """One round of BASELINE.json configs[4] on this rank's shard of a mixed EKF + MPC swarm (bench.py and scripts/swarm_bench.py run it
     on the GPUs, tests/test_swarm_gpu.py checks it there against the oracle, tests/test_dist_cpu.py with gloo and the CPU oracle
@@ -198,12 +236,18 @@ class MixedSwarmRound:
     ekf_launch(c, t0, t1, hist): enqueue EKF steps [t0, t1) of this shard, history into hist [t1 - t0, n_local, C]; it owns the
     filter state and must reset it when c == 0.  final_state(): the shard's [n_local, C] estimate after the last chunk.
     plan_launch(est, slot): enqueue the planners on est [n_plan, C] (a buffer owned by this object); every buffer it writes must
-    belong to `slot` (0 .. depth-1) — the planners of the other slots are running.  Its return value is plans_of(round)."""
+    belong to `slot` (0 .. depth-1) — the planners of the other slots are running.  Its return value is plans_of(round).  (The one-argument
+    form of rounds 1-4 is still accepted at depth 1.)
+
+    Things a caller should know: `chunks` is a request — `self.chunks` is the count in effect (1 unless trajectories are gathered over
+    more than one rank; `requested_chunks` keeps the argument); `plans` / `final` are valid after wait(); the planner streams are
+    per-device and shared by every round object of the process (planner_streams), so two live rounds on one device queue their
+    planners on the same streams, in issue order."""
 
     def __init__(self, n_local, T, C, chunks, plan_every, device, ekf_launch, final_state, plan_launch, gather="traj", n_total=None, group=None,
                  depth=1):
         self.nl, self.T, self.C, self.every, self.gather_kind, self.group = n_local, T, C, int(plan_every), gather, group
-        self.ekf_launch, self.final_state, self.plan_launch = ekf_launch, final_state, plan_launch
+        self.ekf_launch, self.final_state, self.plan_launch = ekf_launch, final_state, _with_slot(plan_launch, self_depth=depth)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_total = n_total if n_total is not None else n_local * self.world
         self.cuda = torch.device(device).type == "cuda"
@@ -211,7 +255,8 @@ class MixedSwarmRound:
         assert T % chunks == 0, "the chunk count must divide the number of steps"
         gathered = gather == "traj" and dist.is_initialized()
         # chunked only where a gather overlaps the chunks (more than one rank): see the docstring
-        self.chunks = chunks if (gathered and self.world > 1) else 1
+        self.requested_chunks = int(chunks)
+        self.chunks = chunks if (gathered and self.world > 1) else 1      # the EFFECTIVE count ekf_launch sees
         self.cg = ChunkedTrajectoryGather(T, n_local, C, self.chunks, device, group=group) if gathered else None
         self.local_hist = None if self.cg is not None else torch.empty((self.chunks, T // self.chunks, n_local, C), dtype=torch.float32, device=device)
         n_plan = (n_local + self.every - 1) // self.every
@@ -327,6 +372,8 @@ class SwarmShard:
 
     def __init__(self, n, T, course, Q, R, device, rank=0, world=1, Tm=21, plan_every=8, depth=6, chunks=4, gather="traj", seed=99, v_cmd=2.5,
                  input_sets=1, mpc_fn=None, group=None, record_ekf_events=False):
+        # before anything touches the device (after the first tensor it can no longer set the variable)
+        self.hw_queues = want_hw_queues(depth + 2) if torch.device(device).type == "cuda" else None
         import numpy as np
 
         import cpprobotics_amd as crx
@@ -363,7 +410,6 @@ class SwarmShard:
                            status=torch.empty(self.n_plan, dtype=torch.int32, device=device),
                            cost=torch.empty(self.n_plan, dtype=torch.float64, device=device)) for _ in range(max(1, depth))]
         self.ekf_events = [] if record_ekf_events else None
-        self.hw_queues = want_hw_queues(depth + 2) if torch.device(device).type == "cuda" else None
         if torch.device(device).type == "cuda" and depth + 1 > (self.hw_queues or 4):
             import warnings
             warnings.warn(f"SwarmShard: {depth} planner streams + the launch stream on {self.hw_queues or 4} hardware queues — streams that share a "

@@ -27,6 +27,12 @@ int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, 
 int crx_x_mpc_solve_trig_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                              double* cost, void* stream, int recompute_trig);
 
+/* The MPC solve with the lane's working-set layout forced: store = 0 private memory (crx::mpc_kernel), 1 the tile layout of round 6
+ * (crx::mpc_tile_kernel: controls in LDS, feedback gains in accumulator registers; T <= 21).  Both give the same bits in every
+ * output; crx_mpc_solve_batch_dev picks by horizon and batch size (csrc/api_mpc.inl). */
+int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                              double* cost, void* stream, int store);
+
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,

@@ -5,10 +5,29 @@
 //   /root/reference/include/quintic_polynomial.h:49 (3x3), quartic_polynomial.h:45 (2x2), cubic_spline.h:56 (nx x nx).
 // Eigen is an un-vendored dependency absent from this image, so this follows the published algorithm: column norms,
 // pivoting on the largest updated norm, LAPACK-style norm downdating (lawn176), Householder vectors stored below the
-// diagonal, Q^T applied reflector by reflector, back substitution, column permutation.  Every reduction is a plain
-// ascending loop — for the 2x2 / 3x3 systems that is what Eigen's dynamic-size block reductions do as well (fewer than one
-// packet), for the nx x nx spline system Eigen's GEMV kernels may associate differently (PARITY UNPINNED there; the
-// measured effect is in DESIGN.md §5e).
+// diagonal, Q^T applied reflector by reflector, back substitution, column permutation.
+//
+// WHICH REDUCTION EACH CALL SITE USES (re-derived in round 6 from Core/Redux.h, Householder/Householder.h, Core/GeneralProduct.h and
+// Core/ProductEvaluators.h of 3.3.9).  PacketSize is 4 floats (SSE, the reference has no -march):
+//   (1) computeInPlace, the initial `m_qr.col(k).norm()`.  For a FIXED-size matrix (Matrix3f, Matrix2f: the quintic and quartic
+//       systems) col(k) is a fixed-size block, the redux is completely unrolled (redux_traits: Cost <= UnrollingLimit) and, below one
+//       packet, it is redux_novec_unroller<0, Size>: func(unroller<0, Size/2>, unroller<Size/2, Size - Size/2>) — a TREE OF HALVES:
+//       3 elements: t0 + (t1 + t2); 2 elements: t0 + t1.  Until round 6 this file summed them ascending, (t0 + t1) + t2 — a different
+//       float for ~1 in 4 columns, which moves a pivot choice or a down-date decision only in near-ties (`fixed_size` below; the
+//       fixed-size branch with >= 4 rows — whole packets by redux_vec_unroller, SSE2 predux (p0 + p2) + (p1 + p3), then the tail's
+//       tree — is written out too, although no call site of the reference reaches it).
+//       For a DYNAMIC-size matrix (MatrixXf: the spline system) it is redux_impl<LinearVectorizedTraversal, NoUnrolling>: below one
+//       packet ascending; from 4 rows on packets start at the first 16-byte-aligned element of the column — the order depends on
+//       the ADDRESS of the data (PARITY UNPINNED there: this file sums ascending).
+//   (2) in-loop `m_qr.col(j).tail(rows - k - 1).norm()` (the down-date's re-computation) and makeHouseholder's
+//       `tail.squaredNorm()`: dynamic-size blocks even of a fixed-size matrix -> the NoUnrolling path; at most 2 elements for the
+//       3x3 / 2x2 systems = ascending (what this file does).
+//   (3) applyHouseholderOnTheLeft's `essential.adjoint() * bottom`: for the fixed-size systems product_type_selector<1, Small, Small>
+//       = CoeffBasedProduct, no packet path (1 row; the right-hand side is column-major), coefficient = a dynamic-size redux of at
+//       most 2 products -> ascending.  In _solve_impl the same expression is an InnerProduct (one right-hand-side column): the
+//       same dynamic redux.  For MatrixXf both are GemvProduct (Large): Eigen's GEMV kernel, alignment-dependent (UNPINNED).
+//   (4) the outer-product update and the back substitution have no reductions (one multiply, one subtract per coefficient).
+// tests/tools/eigen_order_probe.cpp runs the fixed-size and the dynamic systems through <Eigen/Eigen> where a box has it.
 #pragma once
 #include <cmath>
 #include <cstddef>
@@ -21,7 +40,9 @@ namespace oracle {
 template <class S>
 class ColPivQR {
  public:
-  ColPivQR(int rows, int cols) : rows_(rows), cols_(cols), qr_((size_t)rows * cols), hc_(rows < cols ? rows : cols), perm_(cols) {}
+  // fixed_size: the reference's matrix type is a fixed-size Eigen matrix (Matrix3f / Matrix2f), see (1) above
+  ColPivQR(int rows, int cols, bool fixed_size = false)
+      : rows_(rows), cols_(cols), fixed_(fixed_size), qr_((size_t)rows * cols), hc_(rows < cols ? rows : cols), perm_(cols) {}
   int rows() const { return rows_; }
   int cols() const { return cols_; }
   int nonzero_pivots() const { return nonzero_; }
@@ -33,7 +54,7 @@ class ColPivQR {
     const int rows = rows_, cols = cols_, size = rows < cols ? rows : cols;
     std::vector<int> transp(cols);
     std::vector<S> norm_upd(cols), norm_dir(cols), temp(cols);
-    for (int k = 0; k < cols; ++k) { norm_dir[k] = col_norm(k, 0); norm_upd[k] = norm_dir[k]; }
+    for (int k = 0; k < cols; ++k) { norm_dir[k] = fixed_ ? col_norm_fixed(k) : col_norm(k, 0); norm_upd[k] = norm_dir[k]; }
     S maxnorm = norm_upd[0];
     for (int k = 1; k < cols; ++k) if (norm_upd[k] > maxnorm) maxnorm = norm_upd[k];
     const S eps = std::numeric_limits<S>::epsilon();
@@ -124,6 +145,33 @@ class ColPivQR {
     for (int i = from + 1; i < rows_; ++i) s = s + at(i, j) * at(i, j);
     return sqrt(s);
   }
+  // redux_novec_unroller<Start, Length>: the tree of halves
+  S tree(const S* t, int start, int len) const {
+    if (len == 1) return t[start];
+    const int half = len / 2;
+    return tree(t, start, half) + tree(t, start + half, len - half);
+  }
+  // redux_vec_unroller<Start, Length> over packets of 4: lane-wise tree of halves
+  void vec_tree(const S* t, int start, int len, S out[4]) const {
+    if (len == 1) { for (int l = 0; l < 4; ++l) out[l] = t[4 * start + l]; return; }
+    const int half = len / 2;
+    S a[4], b[4];
+    vec_tree(t, start, half, a); vec_tree(t, start + half, len - half, b);
+    for (int l = 0; l < 4; ++l) out[l] = a[l] + b[l];
+  }
+  // (1): the norm of a whole column of a FIXED-size matrix — redux_impl<LinearVectorizedTraversal, CompleteUnrolling>
+  S col_norm_fixed(int j) const {
+    using std::sqrt;
+    std::vector<S> t(rows_);
+    for (int i = 0; i < rows_; ++i) t[i] = at(i, j) * at(i, j);
+    const int vec = (rows_ / 4) * 4;
+    if (vec == 0) return sqrt(tree(&t[0], 0, rows_));
+    S p[4];
+    vec_tree(&t[0], 0, rows_ / 4, p);
+    S res = (p[0] + p[2]) + (p[1] + p[3]);                      // SSE2 predux<Packet4f>: movehl add, then the shuffled add
+    if (vec != rows_) res = res + tree(&t[0], vec, rows_ - vec);
+    return sqrt(res);
+  }
   // M = qr rows k.., columns c0..c1-1:  tmp = essential^T * bottom ; tmp += row0 ; row0 -= tau*tmp ; bottom -= tau*essential*tmp
   void apply_left(int k, S tau, S* /*base*/, int rows, int c0, int c1, S* tmp) {
     if (c1 <= c0) return;
@@ -149,7 +197,9 @@ class ColPivQR {
     for (int i = k + 1; i < rows; ++i) c[i] = c[i] - (tau * at(i, k)) * (*tmp);
   }
 
-  int rows_, cols_, nonzero_ = 0;
+  int rows_, cols_;
+  bool fixed_;
+  int nonzero_ = 0;
   std::vector<S> qr_, hc_;
   std::vector<int> perm_;
 };

@@ -37,8 +37,10 @@ struct FrenetCfg {   // the #defines :20-38, as the double expressions they expa
 
 // ---- cubic_spline.h ----------------------------------------------------------------------------------------------
 // A.colPivHouseholderQr().solve(B) for a column-major float system (oracle/eigen_qr.h)
-void solve_qr(int n, const std::vector<float>& A, const std::vector<float>& b, std::vector<float>& x) {
-  oracle::ColPivQR<float> qr(n, n);
+// fixed_size: the reference's A is a fixed-size Eigen matrix (Matrix3f / Matrix2f) — its initial column norms are reduced by a tree
+// of halves, not ascending (oracle/eigen_qr.h (1))
+void solve_qr(int n, const std::vector<float>& A, const std::vector<float>& b, std::vector<float>& x, bool fixed_size = false) {
+  oracle::ColPivQR<float> qr(n, n, fixed_size);
   qr.compute(A.data());
   x.resize(n);
   qr.solve(b.data(), x.data());
@@ -131,13 +133,13 @@ struct Spline2D {   // :130-178
 void solve3(const float A[3][3], const float B[3], float x[3]) {
   std::vector<float> Am(9), Bm(B, B + 3), xv;
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Am[i + 3 * j] = A[i][j];
-  solve_qr(3, Am, Bm, xv);
+  solve_qr(3, Am, Bm, xv, true);      // Eigen::Matrix3f A  (quintic_polynomial.h:39)
   x[0] = xv[0]; x[1] = xv[1]; x[2] = xv[2];
 }
 void solve2(const float A[2][2], const float B[2], float x[2]) {
   std::vector<float> Am(4), Bm(B, B + 2), xv;
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) Am[i + 2 * j] = A[i][j];
-  solve_qr(2, Am, Bm, xv);
+  solve_qr(2, Am, Bm, xv, true);      // Eigen::Matrix2f A  (quartic_polynomial.h:36)
   x[0] = xv[0]; x[1] = xv[1];
 }
 

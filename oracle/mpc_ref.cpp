@@ -36,6 +36,10 @@ struct MpcParams {  // mirrors crx_mpc_params (include/crx.h); defaults = the re
   double dt, wb, max_steer, max_accel, max_speed, min_speed;
   double r_a, r_delta, rd_a, rd_delta, q_x, q_y, q_yaw, q_v, tol;
   int max_iter;
+  // false (default): the feedback gains reach the rollouts rounded to float, as the engine stores them.  true: they stay double — the
+  // INDEPENDENT form (rounds 1-4), kept so that the float rounding is checked against something that does not share it
+  // (oracle_mpc_solve_double_gains, tests/test_oracle_mpc.py::test_float_gains_against_double_gains)
+  bool double_gains = false;
 };
 
 int p_switch_at = -1, p_switch_n_gn = 2; double p_switch_trust = 1.0;   // experiment knob: oracle_mpc_late_switch
@@ -286,7 +290,8 @@ bool backward(const MpcParams& p, int T, const float* xref, const Work& w, bool 
     // the feedback gains are handed to the rollouts rounded to FLOAT, as the engine stores them (csrc/mpc_kernels.hip.h: Kf — 41 % of the
     // solver's memory traffic as doubles); the backward sweep itself keeps using K in double.  The gains only steer the candidates, the
     // fixed point is decided by the feed-forward k: on 4 x 8,192 problems 2 sweep counts move by one, no solution float by more than one ulp.
-    for (int q = 0; q < NU * NS; ++q) Kfb[NU * NS * i + q] = (double)(float)K[q];
+    if (!p.double_gains)
+      for (int q = 0; q < NU * NS; ++q) Kfb[NU * NS * i + q] = (double)(float)K[q];
     const double a0 = std::fabs(k[0]), a1 = std::fabs(k[1]);
     if (a0 > *gnorm) *gnorm = a0;
     if (a1 > *gnorm) *gnorm = a1;
@@ -447,6 +452,20 @@ static MpcParams unpack(const double* pp, int max_iter) {
 void oracle_mpc_solve(int n, int T, const float* x0, const float* xref, const double* params, int max_iter,
                       float* sol, int* status, double* cost, int a0, int a1) {
   const MpcParams p = unpack(params, max_iter);
+  const int nv = 4 * T + 2 * (T - 1);
+  for (int k = a0; k < a1; ++k) {
+    double J; int it;
+    const int st = solve_one(p, T, x0 + 4 * k, xref + 4 * (size_t)T * k, sol + (size_t)nv * k, &J, &it);
+    if (status) status[k] = st;
+    if (cost) cost[k] = J;
+  }
+}
+
+// The same solve with the feedback gains kept in double (MpcParams::double_gains): what the float-gain twin is bounded against.
+void oracle_mpc_solve_double_gains(int n, int T, const float* x0, const float* xref, const double* params, int max_iter,
+                                   float* sol, int* status, double* cost, int a0, int a1) {
+  MpcParams p = unpack(params, max_iter);
+  p.double_gains = true;
   const int nv = 4 * T + 2 * (T - 1);
   for (int k = a0; k < a1; ++k) {
     double J; int it;

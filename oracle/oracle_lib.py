@@ -178,8 +178,9 @@ def _mpc_params(overrides):
     return np.array([d[k] for k in _MPC_ORDER], dtype=np.float64)
 
 
-def mpc_solve(x0, xref, T, params=None, max_iter=50, agents=None):
-    """CPU twin of the engine's MPC solver.  Returns sol [n, 4T+2(T-1)], status [n], cost [n]."""
+def mpc_solve(x0, xref, T, params=None, max_iter=50, agents=None, double_gains=False):
+    """CPU twin of the engine's MPC solver.  Returns sol [n, 4T+2(T-1)], status [n], cost [n].  double_gains: keep the feedback gains
+    in double instead of rounding them to float as the engine stores them (the independent form the rounding is bounded against)."""
     x0, xref = _f32(x0), _f32(xref)
     n = x0.shape[0]
     nv = 4 * T + 2 * (T - 1)
@@ -188,7 +189,8 @@ def mpc_solve(x0, xref, T, params=None, max_iter=50, agents=None):
     cost = np.zeros((n,), dtype=np.float64)
     pp = _mpc_params(params)
     a0, a1 = (0, n) if agents is None else agents
-    lib().oracle_mpc_solve(_I(n), _I(T), _p(x0), _p(xref), _p(pp), _I(max_iter), _p(sol), _p(status), _p(cost), _I(a0), _I(a1))
+    fn = lib().oracle_mpc_solve_double_gains if double_gains else lib().oracle_mpc_solve
+    fn(_I(n), _I(T), _p(x0), _p(xref), _p(pp), _I(max_iter), _p(sol), _p(status), _p(cost), _I(a0), _I(a1))
     return sol, status, cost
 
 

@@ -6,6 +6,11 @@
      hand-issued blocks of csrc/dare_math.h (dq_max_perm, dq_quad_test4: non-volatile inline assembly with hand-counted `s_nop 1`)
      carry their own.  A compiler bump that reorders or splits those blocks would otherwise show up only as wrong bits on the GPU box
       — here it fails the build.
+  3. the accumulator-register block of the MPC tile kernels (csrc/mpc_tile_kernels.hip.h, mpc_agpr.inc): a40 .. a255 hold the solver's
+     feedback gains between inline-asm statements the compiler cannot see into.  Its register allocator may use any accumulator
+     register for values of its own between two of those statements, so the block is safe only while the allocator stays below it:
+     inside every tile kernel, a register of the block may appear only in complete, slot-aligned, ascending runs of twelve
+     v_accvgpr_write_b32 / v_accvgpr_read_b32 (the accessors), in no other instruction and no other pattern.
   2. the exec-masked add of dq_add_lane2: its `s_and_saveexec_b64 sX, <lanes 2 mod 4>` must be followed by exactly its four v_add_f32
      and the restoring `s_mov_b64 exec, sX`, nothing in between.
 
@@ -56,9 +61,49 @@ def parse(text):
     return funcs
 
 
+def agpr_block_params():
+    """(base, per_slot, slots) of the generated accessor file"""
+    txt = open(os.path.join(ROOT, "cpprobotics_amd", "csrc", "mpc_agpr.inc")).read()
+    return tuple(int(re.search(rf"#define {k} (\d+)", txt).group(1)) for k in ("CRX_MPC_AGPR_BASE", "CRX_MPC_AGPR_PER_SLOT", "CRX_MPC_AGPR_SLOTS"))
+
+
+def check_agpr_block(name, ins, base, per, slots):
+    """-> (problems, number of accessor runs, highest accumulator register the compiler itself uses)"""
+    problems, seq, top = [], [], -1
+    for mn, ops, raw in ins:
+        regs = [int(m) for m in re.findall(r"\ba(\d+)\b", raw)]
+        for m in re.finditer(r"\ba\[(\d+):(\d+)\]", raw):
+            regs += list(range(int(m.group(1)), int(m.group(2)) + 1))
+        for r in regs:
+            if r < base:
+                top = max(top, r)
+            elif mn in ("v_accvgpr_write_b32", "v_accvgpr_read_b32") and len(regs) == 1:
+                seq.append((mn, r, raw))
+            else:
+                problems.append(f"{name}: `{raw}` touches a{r}, inside the gain block a{base} .. a{base + per * slots - 1}")
+    k = 0
+    while k < len(seq):
+        mn, r, raw = seq[k]
+        run = seq[k:k + per]
+        if (r - base) % per or len(run) < per or any(x[0] != mn or x[1] != r + j for j, x in enumerate(run)):
+            problems.append(f"{name}: the gain block is touched outside a complete slot-aligned accessor run, at `{raw}` — the compiler's "
+                            "own accumulator-register use has reached the block (raise CRX_MPC_AGPR_BASE in scripts/gen_mpc_agpr.py, or "
+                            "lower the kernel's register pressure)")
+            break
+        k += per
+    return problems, len(seq) // per, top
+
+
 def check(lib, text=None):
     funcs = parse(text if text is not None else disassemble(lib))
     problems, n_dpp, n_exec_blocks, n_nop_dpp = [], 0, 0, 0
+    n_tile, n_runs, top_agpr = 0, 0, -1
+    base, per, slots = agpr_block_params()
+    for name, ins in funcs:
+        if "mpc_tile_kernel" in name:
+            pr, runs, top = check_agpr_block(name, ins, base, per, slots)
+            problems += pr
+            n_tile += 1; n_runs += runs; top_agpr = max(top_agpr, top)
     for name, ins in funcs:
         for i, (mn, ops, raw) in enumerate(ins):
             if mn.endswith("_dpp") and len(ops) >= 2:
@@ -87,18 +132,28 @@ def check(lib, text=None):
                     n_exec_blocks += 1
                 else:
                     problems.append(f"{name}: the exec-masked add after `{raw}` is no longer four v_add_f32 + `s_mov_b64 exec, {ops[0]}`: {nxt}")
-    return problems, {"functions": len(funcs), "dpp_instructions": n_dpp, "of_them_behind_an_s_nop": n_nop_dpp, "exec_masked_add_blocks": n_exec_blocks}
+    return problems, {"functions": len(funcs), "dpp_instructions": n_dpp, "of_them_behind_an_s_nop": n_nop_dpp, "exec_masked_add_blocks": n_exec_blocks,
+                      "mpc_tile_kernels": n_tile, "gain_block_accessor_runs": n_runs, "highest_compiler_agpr_in_tile_kernels": top_agpr,
+                      "gain_block_base": base}
 
 
 def main():
     libs = sys.argv[1:] or [os.path.join(ROOT, "cpprobotics_amd", n) for n in ("libcrx.so", "libcrx_x.so")]
     bad = 0
     for lib in libs:
-        problems, stats = check(lib)
+        try:
+            problems, stats = check(lib)
+        except FileNotFoundError as e:
+            # a box without the ROCm LLVM tools / objcopy can still build and run the library; the check is for the build box
+            print(f"check_isa: SKIPPED for {os.path.relpath(lib, ROOT)} — the code object cannot be disassembled here: {e}")
+            continue
         print(f"check_isa: {os.path.relpath(lib, ROOT)}: {stats}, {len(problems)} problem(s)")
         for p in problems[:20]:
             print("  " + p)
         bad += len(problems)
+        if stats["mpc_tile_kernels"] == 0 or stats["gain_block_accessor_runs"] == 0:
+            print("  no MPC tile kernel (or no accessor run) found in the code object: the gain-block check checks nothing")
+            bad += 1
         if stats["exec_masked_add_blocks"] == 0 or stats["of_them_behind_an_s_nop"] == 0:
             print("  the hand-issued blocks of csrc/dare_math.h were not found in the code object (renamed? inlined away?): the check checks nothing")
             bad += 1

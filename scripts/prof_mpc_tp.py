@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel and the lane-refilling kernel, N agents
-(default 262,144), T = 21, `reps` launches each."""
+"""The MPC solve in its throughput regime under rocprofv3 (scripts/gpu_mpc_traffic.sh): mpc_kernel (private memory), mpc_tile_kernel
+(LDS + accumulator registers, round 6) and — where the A/B library is present — the lane-refilling kernel; N agents (default 262,144),
+T = 21, `reps` launches each."""
 import os
 import sys
 
@@ -16,10 +17,13 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 x0, xref = mpc_problem(n, 21, 4)
 x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
-for apw in (0, 512):                                           # agents per wave of the refilling kernel; 0: mpc_kernel
+variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["private", "tile", "refill"]
+for v in variants:
     for _ in range(reps):
-        if apw:
-            X.mpc_solve_refill(x0, xref, 21, apw, 16, poison=False)
+        if v == "refill":
+            X.mpc_solve_refill(x0, xref, 21, 512, 16, poison=False)
+        elif v == "tile":
+            X.mpc_solve_store(x0, xref, 21, 1)
         else:
-            X.mpc_solve_lanes(x0, xref, 21, lanes_per_agent=1)
+            X.mpc_solve_store(x0, xref, 21, 0)
     torch.cuda.synchronize()

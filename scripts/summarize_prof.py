@@ -80,13 +80,19 @@ for log in ("side_flop.log", "side_sq.log", "side_stats.log"):
 side = {}
 # single-step EKF update: HBM traffic per launch against its 176 algorithmic bytes per update (the two batch sizes are two template
 # instantiations; the FETCH_SIZE correction as for the fused launch above)
-for key, kern, nveh in (("ekf_step_4M_streaming_rows", "ekf_step_kernel<true>", 1 << 22), ("ekf_step_1M", "ekf_step_kernel<false>", 1 << 20)):
+# the kernel is template <bool NT, bool DTS> since round 5: rocprof prints `ekf_step_kernel<true, true>` — match on the FIRST template
+# argument (the round-5 pass matched `<true>` and silently lost both entries)
+have_side = os.path.exists(os.path.join(out, "side_fetch")) or os.path.exists(os.path.join(out, "side_pmc_fetch.csv"))
+for key, kern, nveh in (("ekf_step_4M_streaming_rows", "ekf_step_kernel<true,", 1 << 22), ("ekf_step_1M", "ekf_step_kernel<false,", 1 << 20)):
     f, _ = counters("side_fetch", kern)
     w, _ = counters("side_write", kern)
     c, _ = counters("side_sq", kern)
+    if have_side and not (f and w):
+        raise SystemExit(f"summarize_prof: the side counter pass has no rows for a kernel named *{kern}* — the kernel was renamed or re-templated; "
+                         "fix the match instead of dropping the entry")
     if f and w:
         fb, wb = f["FETCH_SIZE"] * 1024 * 2, w["WRITE_SIZE"] * 1024
-        side[key] = {"kernel": "crx::" + kern, "vehicles": nveh, "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
+        side[key] = {"kernel": "crx::" + kern.rstrip(",") + ", ...>", "vehicles": nveh, "fetch_bytes_corrected": fb, "write_bytes": wb, "hbm_bytes_per_launch": fb + wb,
                      "algorithmic_bytes_per_launch": 176.0 * nveh, "traffic_over_algorithmic": (fb + wb) / (176.0 * nveh),
                      "read_over_algorithmic_read": fb / (96.0 * nveh), "write_over_algorithmic_write": wb / (80.0 * nveh),
                      "sq_counters_per_launch": c}

@@ -99,6 +99,9 @@ def test_committed_counters_are_bound_to_the_kernel_code(crx):
     import warnings
     from cpprobotics_amd._lib import kernel_code_hash
     h = {f: kernel_code_hash(f) for f in ("ekf", "side", "mpc")}
+    if not any(h.values()):
+        pytest.skip("the code object cannot be disassembled on this host (no ROCm LLVM tools): kernel_code_hash is None, bench.py prints "
+                    "the committed counters as null")
     assert all(v and len(v) == 16 for v in h.values()) and len(set(h.values())) == 3
     assert h == {f: kernel_code_hash(f) for f in h}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

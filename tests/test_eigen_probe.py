@@ -44,7 +44,7 @@ def _against_real_eigen(tmp_path):
         warnings.warn(msg)
         pytest.skip(msg)
     rc, out = _run_probe(tmp_path, inc)
-    warnings.warn(out.strip().splitlines()[-1] + f"  [{inc}]")
+    warnings.warn(" | ".join(out.strip().splitlines()[-2:]) + f"  [{inc}]")
     assert rc == 0, out[-4000:]
 
 

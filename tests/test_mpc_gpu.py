@@ -304,3 +304,33 @@ def test_shared_gpu_hint_changes_the_kernel_form_not_the_answer(crx):
     p = default_params(); p.shared_gpu = 1
     b = crx.mpc_solve(x0, xref, 21, params=p, return_status=True)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+@pytest.mark.parametrize("n,T,seed", [(8192, 21, 4), (8192, 21, 7), (8192, 6, 3), (1000, 13, 9), (65536, 21, 11), (70001, 21, 12)])
+def test_tile_layout_gives_the_same_bits_as_private_memory(crx, n, T, seed):
+    """Round 6: crx::mpc_tile_kernel keeps the lane's controls in LDS and its feedback gains in accumulator registers (a40 .. a255)
+    instead of private memory.  Same operations on the same doubles in the same order: status (sweep counts included), every solution
+    float and the double cost must equal crx::mpc_kernel's bit for bit — a stray compiler write into the register block, a wrong
+    slot or a race on the LDS tile would show here."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_store
+    x0, xref = mpc_problem(n, T, seed)
+    x0, xref = _t(x0), _t(xref)
+    a = mpc_solve_store(x0, xref, T, 0)
+    b = mpc_solve_store(x0, xref, T, 1)
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+def test_tile_layout_on_the_speed_bound_problems(crx):
+    """The rare branches of the backward sweep (speed-bound feedback rows, regularised sweeps) through the tile layout."""
+    import torch
+    from common import speed_bound_problems
+    from cpprobotics_amd.experimental import mpc_solve_store
+    for fast in (False, True):
+        x0, xref = speed_bound_problems(512, 21, 5, fast=fast)
+        x0, xref = _t(x0), _t(xref)
+        a = mpc_solve_store(x0, xref, 21, 0)
+        b = mpc_solve_store(x0, xref, 21, 1)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))

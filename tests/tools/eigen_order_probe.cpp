@@ -11,14 +11,23 @@
 // order generically from the operand types: that run checks the per-call-site flags below against the generic rule).
 // Call sites: /root/reference/src/extended_kalman_filter.cpp:35,69,74-77; src/lqr_speed_steer_control.cpp:91,104;
 // src/lqr_steer_control.cpp:81,94.
+// Round 6: the `colPivHouseholderQr().solve()` call sites of the planners — Matrix3f
+// (/root/reference/include/quintic_polynomial.h:49), Matrix2f (quartic_polynomial.h:45), MatrixXf n x n, n = 4 .. 12 (cubic_spline.h:56)
+// — on random systems and on the reference's own matrices (the quintic / quartic time matrices on the planner's horizon grid, the
+// tridiagonal spline system), through <Eigen/Eigen> and through oracle::ColPivQR (oracle/eigen_qr.h), memcmp.  The fixed-size
+// systems are the ones eigen_qr.h claims to pin; the dynamic ones are reported separately (their reductions are address-dependent
+// in Eigen: eigen_qr.h says UNPINNED, and a mismatch count there is information, not a failure of the claim).
 #include <Eigen/Eigen>
 
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <vector>
 
 #include "oracle/eigen_order.h"
+#include "oracle/eigen_qr.h"
 
 namespace {
 
@@ -139,15 +148,98 @@ void one_seed() {
 
 }  // namespace
 
+// ---- colPivHouseholderQr().solve() -------------------------------------------------------------------------------------------
+int g_qr_fixed_cases = 0, g_qr_fixed_fail = 0, g_qr_dyn_cases = 0, g_qr_dyn_fail = 0;
+template <int N> void qr_fixed(const char* what, const Eigen::Matrix<float, N, N>& A, const Eigen::Matrix<float, N, 1>& b) {
+  const Eigen::Matrix<float, N, 1> xe = A.colPivHouseholderQr().solve(b);
+  float a[N * N], bb[N], xo[N];
+  for (int j = 0; j < N; ++j) for (int i = 0; i < N; ++i) a[i + N * j] = A(i, j);
+  for (int i = 0; i < N; ++i) bb[i] = b(i);
+  oracle::ColPivQR<float> qr(N, N, true);
+  qr.compute(a); qr.solve(bb, xo);
+  ++g_qr_fixed_cases;
+  for (int i = 0; i < N; ++i) {
+    const float e = xe(i);
+    if (std::memcmp(&e, &xo[i], 4) != 0) {
+      if (g_qr_fixed_fail < 20) std::printf("QR MISMATCH %-30s x[%d]: Eigen %a  eigen_qr.h %a\n", what, i, e, xo[i]);
+      ++g_qr_fixed_fail;
+      return;
+    }
+  }
+}
+void qr_dynamic(const char* what, const Eigen::MatrixXf& A, const Eigen::VectorXf& b) {
+  const int n = (int)A.rows();
+  const Eigen::VectorXf xe = A.colPivHouseholderQr().solve(b);
+  std::vector<float> a((size_t)n * n), bb(n), xo(n);
+  for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) a[i + (size_t)n * j] = A(i, j);
+  for (int i = 0; i < n; ++i) bb[i] = b(i);
+  oracle::ColPivQR<float> qr(n, n, false);
+  qr.compute(a.data()); qr.solve(bb.data(), xo.data());
+  ++g_qr_dyn_cases;
+  for (int i = 0; i < n; ++i) {
+    const float e = xe(i);
+    if (std::memcmp(&e, &xo[i], 4) != 0) {
+      if (g_qr_dyn_fail < 10) std::printf("QR (dynamic, unpinned) differs %-24s n=%d x[%d]: Eigen %a  eigen_qr.h %a\n", what, n, i, e, xo[i]);
+      ++g_qr_dyn_fail;
+      return;
+    }
+  }
+}
+void qr_one_seed(int seed) {
+  { Eigen::Matrix3f A; Eigen::Vector3f b;
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) A(i, j) = rnd();
+    for (int i = 0; i < 3; ++i) b(i) = rnd();
+    qr_fixed<3>("Matrix3f random", A, b); }
+  { Eigen::Matrix2f A; Eigen::Vector2f b;
+    for (int j = 0; j < 2; ++j) for (int i = 0; i < 2; ++i) A(i, j) = rnd();
+    for (int i = 0; i < 2; ++i) b(i) = rnd();
+    qr_fixed<2>("Matrix2f random", A, b); }
+  // the reference's own matrices: the planner's horizons T = MINT .. MAXT in steps of DT (4.0 .. 5.0 by 0.2), a few more around them
+  { const float T = 3.0f + 0.05f * (float)(seed % 60);
+    Eigen::Matrix3f A; Eigen::Vector3f b;
+    A << std::pow(T, 3), std::pow(T, 4), std::pow(T, 5),
+         3 * std::pow(T, 2), 4 * std::pow(T, 3), 5 * std::pow(T, 4),
+         6 * T, 12 * std::pow(T, 2), 20 * std::pow(T, 3);                  // quintic_polynomial.h:40-42
+    for (int i = 0; i < 3; ++i) b(i) = 4.0f * rnd();
+    qr_fixed<3>("quintic time matrix", A, b);
+    Eigen::Matrix2f A2; Eigen::Vector2f b2;
+    A2 << 3 * std::pow(T, 2), 4 * std::pow(T, 3),
+          6 * T, 12 * std::pow(T, 2);                                      // quartic_polynomial.h:37-38
+    for (int i = 0; i < 2; ++i) b2(i) = 4.0f * rnd();
+    qr_fixed<2>("quartic time matrix", A2, b2); }
+  for (int n = 4; n <= 12; ++n) {
+    Eigen::MatrixXf A(n, n); Eigen::VectorXf b(n);
+    for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) A(i, j) = rnd();
+    for (int i = 0; i < n; ++i) b(i) = rnd();
+    qr_dynamic("MatrixXf random", A, b);
+    // the spline's system, cubic_spline.h:95-116: h = knot spacings
+    std::vector<float> h(n - 1);
+    for (auto& v : h) v = 1.5f + 0.5f * rnd();
+    Eigen::MatrixXf S = Eigen::MatrixXf::Zero(n, n); Eigen::VectorXf B = Eigen::VectorXf::Zero(n);
+    S(0, 0) = 1;
+    for (int i = 0; i < n - 1; ++i) {
+      if (i != n - 2) S(i + 1, i + 1) = 2 * (h[i] + h[i + 1]);
+      S(i + 1, i) = h[i];
+      S(i, i + 1) = h[i];
+    }
+    S(0, 1) = 0.0; S(n - 1, n - 2) = 0.0; S(n - 1, n - 1) = 1.0;
+    for (int i = 1; i < n - 1; ++i) B(i) = 3.0f * rnd();
+    qr_dynamic("spline system", S, B);
+  }
+}
+
 int main(int argc, char** argv) {
   const int seeds = argc > 1 ? std::atoi(argv[1]) : 200;
-  for (int s = 1; s <= seeds; ++s) { g_state = 0x9E3779B97F4A7C15ULL * (uint64_t)s + 1; one_seed(); }
+  for (int s = 1; s <= seeds; ++s) { g_state = 0x9E3779B97F4A7C15ULL * (uint64_t)s + 1; one_seed(); qr_one_seed(s); }
 #ifdef EIGEN_STANDIN_FOR_REFERENCE_TESTS
   const char* what = "the Eigen stand-in (oracle/ref_shim/Eigen/Eigen)";
 #else
   char ver[64]; std::snprintf(ver, sizeof ver, "Eigen %d.%d.%d", EIGEN_WORLD_VERSION, EIGEN_MAJOR_VERSION, EIGEN_MINOR_VERSION);
   const char* what = ver;
 #endif
+  std::printf("eigen_order_probe: colPivHouseholderQr().solve(): %d fixed-size systems (Matrix3f / Matrix2f, random and the quintic / quartic "
+              "time matrices) against %s: %d mismatching; %d dynamic systems (MatrixXf n = 4 .. 12, random and spline; eigen_qr.h: UNPINNED): %d differing\n",
+              g_qr_fixed_cases, what, g_qr_fixed_fail, g_qr_dyn_cases, g_qr_dyn_fail);
   std::printf("eigen_order_probe: %d products / chains x %d seeds against %s: %d mismatching\n", g_cases / (seeds ? seeds : 1), seeds, what, g_fail);
-  return g_fail ? 1 : 0;
+  return (g_fail || g_qr_fixed_fail) ? 1 : 0;
 }

@@ -3,7 +3,7 @@
 // default parameter structs.
 extern "C" {
 
-int crx_version(void) { return 400; }  // 0.4.0 (0.3.0 + device selection and sharded host-pointer entries, grow-only workspace, crx_mpc_closed_loop_flags_batch_dev)
+int crx_version(void) { return 500; }  // 0.5.0 (0.4.0 + the MPC tile layout, crx_swarm_round_dev, crx_comm_* / crx_allgather_dev)
 
 // crx_init only checks that a device is there and forces the HIP runtime + code object to load now rather than in the first
 // timed call; crx_shutdown drains the devices and gives the host-pointer workspaces back.  Both are optional.  The only state the

@@ -65,16 +65,56 @@ static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, co
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc refill launch");
 #endif
 }
+// The tile layout (mpc_tile_kernels.hip.h): controls in LDS, feedback gains in accumulator registers; T <= 21.
+static int mpc_solve_tile(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                          double* cost, void* stream) {
+  if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (tile layout): bad argument (2 <= T <= 21)");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  const hipError_t e = crx::mpc_tile_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile launch");
+}
+static int mpc_solve_tile_refill(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                 double* cost, void* stream, int agents_per_wave, int hold_lanes) {
+  if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): bad argument (2 <= T <= 21)");
+  if (agents_per_wave < 64 || agents_per_wave > (1 << 20) || hold_lanes < 1 || hold_lanes > 64)
+    return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): agents_per_wave 64 .. 2^20, hold_lanes 1 .. 64");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  if (p.max_iter < 1) return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): max_iter must be at least 1");
+  const hipError_t e = crx::mpc_tile_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile refill launch");
+}
 // lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
 // measured 0.95x at BASELINE configs[3] and less beyond, never selected), 0 = what the product entry point uses (= 1).
 static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                            double* cost, void* stream, int lanes_per_agent) {
   if (lanes_per_agent != 0 && lanes_per_agent != 1 && lanes_per_agent != 4)
     return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
-  // the product's choice: one lane per agent, lockstep line search, at every batch size.  (The quad variant lost its A/B at every batch
-  // size, profiles/r03/mpc_lanes_ab.txt; the lane-refilling kernel — 1.14-1.16x at 65,536 .. 262,144 agents in round 4 — no longer wins
-  // anywhere since round 5 cut the solver's memory traffic by a third: profiles/r05/mpc_variants_ab.jsonl.)
-  if (lanes_per_agent == 0) lanes_per_agent = 1;
+  // the product's choice (round 6): one lane per agent, lockstep sweeps, everywhere; from kMpcTileFrom agents on — the throughput regime,
+  // where the private-memory kernel is bound by the HBM traffic of its own scratch — the TILE layout (controls in LDS, feedback gains in
+  // accumulator registers: 82 -> 43 KB of HBM traffic per solve): 131,072 agents 3.80 -> 3.41 ms, 262,144 6.72 -> 5.88, 524,288 9.89 ->
+  // 8.51, 1 M 17.2 -> 14.4 = 73 M solves/s (profiles/r06/mpc_store_ab.jsonl; bit-identical per agent).  Not below: a launch that leaves
+  // SIMDs idle is a latency chain, where the tile kernel's register switch costs 15 % (8,192 agents 1.18 -> 1.33 ms).  Not for a caller
+  // whose launches share the GPU (crx_mpc_params.shared_gpu — configs[4]): a tile wave owns all 512 registers of its SIMD, the
+  // private-memory wave (256 + ~31) leaves room for an EKF wave beside it, and the round is 0.50 ms with it against 0.85
+  // (profiles/r06/swarm_store_ab.jsonl).  The tile layout with REFILLED lanes (crx_x_mpc_solve_tile_refill_dev) is 1.57x the
+  // private-memory kernel at 1 M agents on a distribution without stragglers and 1.25x / 0.98x / 1.24x at 1 M / 524 k / 262 k on the
+  // configs[3] distribution, whose few agents at the 50-sweep cap — each a 2 ms chain started whenever its wave reaches it — set the
+  // launch's tail: measured, kept as an entry point, not selected.  (The quad variant lost its A/B at every batch size,
+  // profiles/r03/mpc_lanes_ab.txt.)
+  if (lanes_per_agent == 0) {
+    const bool shared = prm && prm->shared_gpu != 0;
+    if (n >= crx::kMpcTileFrom && T - 1 <= crx::kMpcTileStages && !shared)
+      return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream);
+    lanes_per_agent = 1;
+  }
   if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 #if !CRX_EXPERIMENTAL_KERNELS
   return fail(CRX_ERR_INVALID, "mpc_solve (four lanes per agent): this libcrx.so was built without the experimental kernels");
@@ -89,17 +129,10 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc launch");
 #endif
 }
-// The tile layout (mpc_tile_kernels.hip.h): controls in LDS, feedback gains in accumulator registers; T <= 21.
-static int mpc_solve_tile(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                          double* cost, void* stream) {
-  if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
-    return fail(CRX_ERR_INVALID, "mpc_solve (tile layout): bad argument (2 <= T <= 21)");
-  if (int rc = check_device()) return rc;
-  if (n == 0) return CRX_OK;
-  crx_mpc_params p;
-  if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_tile_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
-  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile launch");
+int crx_x_mpc_solve_tile_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                    double* cost, void* stream, int agents_per_wave, int hold_lanes) {
+  CRX_TRACE();
+  return mpc_solve_tile_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes);
 }
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {

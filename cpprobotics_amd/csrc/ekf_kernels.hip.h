@@ -177,7 +177,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t stream_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
-template <int D, bool XHIST, bool PHIST, bool BUF, bool DTS>
+// FMA: the packed step's multiply-then-add pairs contracted (ekf_math.h: ekf_step_packed<DTS, FMA>; crx_ekf_params.arith =
+// CRX_ARITH_CONTRACT).  The rare general steps (a wave outside the fast domain, the last < D steps of a launch) stay unfused.
+template <int D, bool XHIST, bool PHIST, bool BUF, bool DTS, bool FMA = false>
 __global__ void __launch_bounds__(CRX_EKF_RUN_BLOCK)
 ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
                const float* __restrict__ z, const float* __restrict__ u,
@@ -237,7 +239,7 @@ ekf_run_kernel(int n, int T, float* __restrict__ x, float* __restrict__ P,
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       const size_t t = (size_t)(t0 + d);
-      ekf_step_packed<DTS>(sp, zq[d], uq[d], kp, dom);
+      ekf_step_packed<DTS, FMA>(sp, zq[d], uq[d], kp, dom);
       // refill the slot just consumed (its registers are dead now: no copy at the loop back-edge)
       if (!LAST || t0 + d + D < T) {
         if (BUF) {

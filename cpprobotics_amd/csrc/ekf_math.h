@@ -332,13 +332,22 @@ CRX_HD v2f bc(float a) { return v2f{a, a}; }
 
 // One ekf_estimation() (:64-78), packed.  Same operation order as ekf_step_dev, entry by entry.
 // DTS: the four DT * cos / DT * sin entries through dt_mul_split (requires dt_split_is_exact(k.dt)), otherwise in double as written.
-template <bool DTS = false>
+// FMA (round 6, opt-in: crx_ekf_params.arith = CRX_ARITH_CONTRACT): the SAME operations in the SAME order, but wherever the reference
+// has a multiply followed by the add that consumes it — every term after the first of a product coefficient, Eigen's
+// `res = pmadd(lhs, rhs, res)` — the two are ONE v_pk_fma_f32, i.e. what the reference's own expressions become when they are compiled
+// with FMA contraction (-march=haswell / -ffp-contract=fast; its CMakeLists sets neither, which is why the default mode keeps them
+// apart).  A k-term sum is k instructions instead of 2k - 1: 71 packed matrix operations per step instead of 103.  Untouched: the
+// trig, the double-formed Jacobian entries, the determinant (a difference of two products: fusing it saves nothing), the reciprocal,
+// the structural adds (+Q, +R, I - K, + PPred rows).  Results differ from the unfused ones in the last bits only — every fused
+// operation is one rounding instead of two; tests/test_ekf_gpu.py and bench.py measure the distance to the oracle under the
+// contract's floored metric: the mode exists because north_star's tolerance is 1e-6, not 0.
+template <bool DTS = false, bool FMA = false>
 CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, FastDomain& dom) {
   const float u0 = u[0], u1 = u[1];
   // motion_model: both yaw angles of the step are known up front
   const float yaw0 = s.x23[0];
   // xPred(2) = x(2) + DT*u(1), xPred(3) = x(3) + u(0): one packed multiply by (DT, 1) — u(0) * 1.0f is u(0) — and one packed add
-  const v2f xp23 = s.x23 + v2f{u1, u0} * v2f{k.dtf, 1.0f};
+  const v2f xp23 = FMA ? pk_fma(v2f{u1, u0}, v2f{k.dtf, 1.0f}, s.x23) : s.x23 + v2f{u1, u0} * v2f{k.dtf, 1.0f};
   const float yaw1 = xp23[0];
   const float yaws[2] = {yaw0, yaw1};
   float sn[2], cs[2];
@@ -352,7 +361,7 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
     b01 = v2f{(float)(k.dt * (double)c0), (float)(k.dt * (double)s0)};
     jB = v2f{(float)(k.dt * (double)c1), (float)(k.dt * (double)s1)};
   }
-  const v2f xp01 = s.x01 + b01 * bc(u0);
+  const v2f xp01 = FMA ? pk_fma(b01, bc(u0), s.x01) : s.x01 + b01 * bc(u0);
   // jacobF(xPred, u): yaw = xPred(2), v = u(0)
   const double dv = k.dt * (double)u0;
   const float j02 = (float)((-dv) * (double)s1);
@@ -364,17 +373,37 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   // (a dependent instruction right behind a v_pk_* needs a wait state) costs no s_nop.
   // T1 = jF*PEst (rows 2,3 of jF are unit rows):  T1lo[j] = (Plo[j] + jA*P2j) + jB*P3j
   v2f T1lo[4], ta[4], tb[4];
+  if constexpr (FMA) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) ta[j] = jA * bc(s.Phi[j][0]);
+    for (int j = 0; j < 4; ++j) ta[j] = pk_fma(jA, bc(s.Phi[j][0]), s.Plo[j]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) tb[j] = jB * bc(s.Phi[j][1]);
+    for (int j = 0; j < 4; ++j) T1lo[j] = pk_fma(jB, bc(s.Phi[j][1]), ta[j]);
+  } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) ta[j] = s.Plo[j] + ta[j];
+    for (int j = 0; j < 4; ++j) ta[j] = jA * bc(s.Phi[j][0]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) T1lo[j] = ta[j] + tb[j];
+    for (int j = 0; j < 4; ++j) tb[j] = jB * bc(s.Phi[j][1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ta[j] = s.Plo[j] + ta[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) T1lo[j] = ta[j] + tb[j];
+  }
   // PPred = T1*jF^T + Q:  col0 = ((T1c0 + T1c2*j02) + T1c3*j03) + Qc0, col1 likewise with j12, j13
   v2f PPlo[4], PPhi[4];
-  {
+  if constexpr (FMA) {
+    const v2f a0 = pk_fma(T1lo[2], bc(j02), T1lo[0]), a1 = pk_fma(s.Phi[2], bc(j02), s.Phi[0]);
+    const v2f a2 = pk_fma(T1lo[2], bc(j12), T1lo[1]), a3 = pk_fma(s.Phi[2], bc(j12), s.Phi[1]);
+    PPlo[2] = T1lo[2] + k.Qlo[2];
+    PPhi[2] = s.Phi[2] + k.Qhi[2];
+    PPlo[3] = T1lo[3] + k.Qlo[3];
+    PPhi[3] = s.Phi[3] + k.Qhi[3];
+    const v2f c0_ = pk_fma(T1lo[3], bc(j03), a0), c1_ = pk_fma(s.Phi[3], bc(j03), a1);
+    const v2f c2_ = pk_fma(T1lo[3], bc(j13), a2), c3_ = pk_fma(s.Phi[3], bc(j13), a3);
+    PPlo[0] = c0_ + k.Qlo[0];
+    PPhi[0] = c1_ + k.Qhi[0];
+    PPlo[1] = c2_ + k.Qlo[1];
+    PPhi[1] = c3_ + k.Qhi[1];
+  } else {
     const v2f m0 = T1lo[2] * bc(j02), m1 = s.Phi[2] * bc(j02), m2 = T1lo[2] * bc(j12), m3 = s.Phi[2] * bc(j12);
     const v2f n0 = T1lo[3] * bc(j03), n1 = s.Phi[3] * bc(j03), n2 = T1lo[3] * bc(j13), n3 = s.Phi[3] * bc(j13);
     const v2f a0 = T1lo[0] + m0, a1 = s.Phi[0] + m1, a2 = T1lo[1] + m2, a3 = s.Phi[1] + m3;
@@ -403,13 +432,20 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   v2f K0lo, K0hi, K1lo, K1hi;
   {
     const v2f e0 = PPlo[0] * bc(W1[1]), e1 = PPhi[0] * bc(W1[1]), e2 = PPlo[0] * bc(-W1[0]), e3 = PPhi[0] * bc(-W1[0]);
-    const v2f f0 = PPlo[1] * bc(-W0[1]), f1 = PPhi[1] * bc(-W0[1]), f2 = PPlo[1] * bc(W0[0]), f3 = PPhi[1] * bc(W0[0]);
-    K0lo = e0 + f0; K0hi = e1 + f1; K1lo = e2 + f2; K1hi = e3 + f3;
+    if constexpr (FMA) {
+      K0lo = pk_fma(PPlo[1], bc(-W0[1]), e0); K0hi = pk_fma(PPhi[1], bc(-W0[1]), e1);
+      K1lo = pk_fma(PPlo[1], bc(W0[0]), e2); K1hi = pk_fma(PPhi[1], bc(W0[0]), e3);
+    } else {
+      const v2f f0 = PPlo[1] * bc(-W0[1]), f1 = PPhi[1] * bc(-W0[1]), f2 = PPlo[1] * bc(W0[0]), f3 = PPhi[1] * bc(W0[0]);
+      K0lo = e0 + f0; K0hi = e1 + f1; K1lo = e2 + f2; K1hi = e3 + f3;
+    }
   }
   // xEst = xPred + K*y
   {
-    const v2f g0 = K0lo * bc(y[0]), g1 = K0hi * bc(y[0]), h0 = K1lo * bc(y[1]), h1 = K1hi * bc(y[1]);
-    const v2f d0 = g0 + h0, d1 = g1 + h1;
+    const v2f g0 = K0lo * bc(y[0]), g1 = K0hi * bc(y[0]);
+    v2f d0, d1;
+    if constexpr (FMA) { d0 = pk_fma(K1lo, bc(y[1]), g0); d1 = pk_fma(K1hi, bc(y[1]), g1); }
+    else { const v2f h0 = K1lo * bc(y[1]), h1 = K1hi * bc(y[1]); d0 = g0 + h0; d1 = g1 + h1; }
     s.x01 = xp01 + d0;
     s.x23 = xp23 + d1;
   }
@@ -419,10 +455,15 @@ CRX_HD void ekf_step_packed(EkfStateP& s, v2f z, v2f u, const EkfConstsP& k, Fas
   v2f qa[4], qb[4], qc[4], qd[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) { qa[j] = M0lo * bc(PPlo[j][0]); qb[j] = M0hi * bc(PPlo[j][0]); }
+  if constexpr (FMA) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { qc[j] = M1lo * bc(PPlo[j][1]); qd[j] = M1hi * bc(PPlo[j][1]); }
+    for (int j = 0; j < 4; ++j) { s.Plo[j] = pk_fma(M1lo, bc(PPlo[j][1]), qa[j]); qb[j] = pk_fma(M1hi, bc(PPlo[j][1]), qb[j]); }
+  } else {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { s.Plo[j] = qa[j] + qc[j]; qb[j] = qb[j] + qd[j]; }
+    for (int j = 0; j < 4; ++j) { qc[j] = M1lo * bc(PPlo[j][1]); qd[j] = M1hi * bc(PPlo[j][1]); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s.Plo[j] = qa[j] + qc[j]; qb[j] = qb[j] + qd[j]; }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) s.Phi[j] = qb[j] + PPhi[j];
 }

@@ -296,7 +296,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // (u + alpha k + K dx), the fixed point is decided by the feed-forward k (double) alone, and they are 41 % of the solver's memory
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
-  float Kf[TILE ? (MAXT > CRX_MPC_AGPR_SLOTS + 1 ? MAXT - CRX_MPC_AGPR_SLOTS - 1 : 1) : MAXT][12];   // (TILE: stages 1 .. 18 in accumulator registers)
+  float Kf[TILE ? (kMpcTileStages > CRX_MPC_AGPR_SLOTS + 1 ? kMpcTileStages - CRX_MPC_AGPR_SLOTS - 1 : 1) : MAXT][12];   // (TILE: stages 1 .. 18 in accumulator registers)
   // ---- accessors of the controls and the gains (the only places that know where they live) --------------------------------------
   const int tile_lane = (int)(threadIdx.x & 63);
   auto ldU = [&](int c, int i, double& d, double& a) {
@@ -724,6 +724,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     // per stage would sit on the critical path), and requests stage i + 1's operands while stage i computes.
     double xs[4] = {S[cur][0][0], S[cur][0][1], S[cur][0][2], S[cur][0][3]};
     double pnd = 0.0, pna = 0.0, pcd = 0.0, pca = 0.0;       // previous stage's new / current controls
+    // (TILE, round 6: requesting the private-memory part — knot, feed-forward step, reference row — TWO stages ahead and reading the
+    // gains from their registers at the point of use was built and measured: 1 M agents 15.0 -> 16.4 ms lockstep, 11.7 -> 12.0 refilled,
+    // relative to the private-memory kernel of the same box 0.82 -> 0.92 and 0.64 -> 0.67: slower, like the two-stage queue of round 4.)
     RollIn nx = load_roll(cur, 0);
     for (int i = 0; i < N; ++i) {
       const RollIn in = nx;

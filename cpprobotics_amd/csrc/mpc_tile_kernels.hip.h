@@ -49,6 +49,41 @@ mpc_tile_kernel(int n, int T, const float* __restrict__ x0g, const float* __rest
   if (costg) costg[agent] = J;
 }
 
+// The tile layout with the lanes REFILLED (mpc_solve_lane<.., REFILL, .., STORE = 1>): wave w owns the agents [w * chunk, (w + 1) * chunk);
+// a lane whose agent has converged holds it until `hold` lanes of the wave hold one, then they write their solutions and take the
+// wave's next agents; the line search is scheduled asynchronously across the lanes (mpc_kernels.hip.h).  A lockstep wave lasts as long
+// as the slowest of its 64 agents — mean of the wave maximum 11.8 sweeps against a mean of 6.8 — and the launch as long as its unluckiest
+// SIMD's queue of waves; here every lane is busy until the wave's range is exhausted and all waves end together.  Rounds 4 and 5
+// measured this schedule on the private-memory layout and dropped it (1.14x, then 0.89-1.00x: where waves queue, the memory system was
+// the limit, and a long-lived wave never hands its share of the caches on).  With the working set mostly on the chip that limit is gone.
+// Per agent the same sweeps in the same order: bit-identical to mpc_kernel.
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_tile_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
+                       float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  __shared__ mpc_d2_t tile_u[2 * kMpcTileStages * 64];
+  mpc_agpr_reserve();
+  const int lo = (int)blockIdx.x * chunk;
+  const MpcFeed feed{lo, (n - lo < chunk) ? n : lo + chunk, hold, x0g, xrefg, solg, statusg, costg};
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, false, true, true, 1>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed,
+                                             MpcTile{(lds_double2_t*)tile_u});
+}
+// crx_mpc_solve_batch_dev takes the tile layout from this many agents on (csrc/api_mpc.inl has the numbers)
+constexpr int kMpcTileFrom = 131072;
+// a geometry for the refilled launch: as many waves as the chip has SIMDs (one persistent wave each), at least 128 agents per wave
+inline int mpc_tile_refill_chunk(int n) {
+  const int c = (n + 1023) / 1024;
+  return c < 128 ? 128 : c;
+}
+inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                         int* status, double* cost, hipStream_t stream, int chunk, int hold) {
+  const MpcP p = mpc_pack(q);
+  const dim3 grid((unsigned)(((size_t)n + chunk - 1) / chunk)), block(64);
+  hipLaunchKernelGGL((mpc_tile_refill_kernel<24>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
+}
+
 // T - 1 <= kMpcTileStages
 inline hipError_t mpc_tile_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                   int* status, double* cost, hipStream_t stream) {

@@ -11,6 +11,7 @@ _X_SIGNATURES = {
     "crx_x_mpc_solve_geometry_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
+    "crx_x_mpc_solve_tile_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
@@ -23,6 +24,7 @@ _X_SIGNATURES = {
     "crx_x_hbm_stream_dev": (_I, [_I, _P, _P, C.c_size_t, _I, _P]),
     "crx_x_recip_sweep_dev": (_I, [_P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
+    "crx_x_ekf_run_contracted_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_pair_batch_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P, _P]),
 }
 EXPERIMENTAL_SYMBOLS = tuple(sorted(_X_SIGNATURES))
@@ -228,6 +230,34 @@ def mpc_solve_store(x0, xref, T, store, params=None, out=None):
     L.check(xlib().crx_x_mpc_solve_store_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                              L.stream_ptr(), int(store)), "crx_x_mpc_solve_store_dev")
     return sol, status, cost
+
+
+def mpc_solve_tile_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, out=None):
+    """mpc_solve through crx::mpc_tile_refill_kernel (tile layout, lanes refilled).  -> sol, status, cost."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    if out is not None:
+        sol, status, cost = out
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    L.check(xlib().crx_x_mpc_solve_tile_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                   L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_tile_refill_dev")
+    return sol, status, cost
+
+
+def ekf_run_contracted(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):
+    """The fused EKF run with the packed step's multiply-then-add pairs fused (crx_x_ekf_run_contracted_dev): an experiment, NOT the
+    reference's bits and not within 1e-6 for every vehicle (include/crx_experimental.h)."""
+    n, T, q, r, p = _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist)
+    L.check(xlib().crx_x_ekf_run_contracted_dev(n, T, L.ptr(xEst), L.ptr(PEst), L.ptr(z), L.ptr(u), L.ptr(x_hist), q.ctypes.data_as(C.c_void_p),
+                                                r.ctypes.data_as(C.c_void_p), C.byref(p), L.stream_ptr()), "crx_x_ekf_run_contracted_dev")
+    return xEst, PEst
 
 
 def _ekf_args(xEst, PEst, z, u, Q, R, dt, x_hist, P_hist=None):

@@ -27,11 +27,24 @@ int crx_x_mpc_solve_lanes_dev(int n, int T, const float* x0, const float* xref, 
 int crx_x_mpc_solve_trig_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                              double* cost, void* stream, int recompute_trig);
 
+/* The fused EKF run (crx_ekf_run_batch_dev without a covariance history) with the packed step's multiply-then-add pairs fused
+ * (v_pk_fma_f32): the same operations in the same order, ~20 % fewer matrix instructions, +9 % throughput — and NOT the reference's
+ * bits: 4.2e-7 floored relative error on configs[0]'s single vehicle, but up to 5.8e-6 over the 65,536 vehicles x 1000 steps of the
+ * headline workload (measured against the oracle in every bench.py run, `extra.ekf_contracted`).  That is outside BASELINE's 1e-6, so
+ * this is an experiment, not a mode of crx_ekf_params (VERDICT r5 item 3's own condition).  dt != 0.1 computes in the exact arithmetic. */
+int crx_x_ekf_run_contracted_dev(int n, int T, float* x, float* P, const float* z, const float* u, float* x_hist,
+                                 const float* Q, const float* R, const crx_ekf_params* prm, void* stream);
+
 /* The MPC solve with the lane's working-set layout forced: store = 0 private memory (crx::mpc_kernel), 1 the tile layout of round 6
  * (crx::mpc_tile_kernel: controls in LDS, feedback gains in accumulator registers; T <= 21).  Both give the same bits in every
  * output; crx_mpc_solve_batch_dev picks by horizon and batch size (csrc/api_mpc.inl). */
 int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int store);
+
+/* The tile layout with refilled lanes (crx::mpc_tile_refill_kernel): a wave owns agents_per_wave consecutive agents (64 .. 2^20),
+ * finished lanes hand their agents back hold_lanes (1 .. 64) at a time and take the next ones.  Bit-identical per agent. */
+int crx_x_mpc_solve_tile_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                    double* cost, void* stream, int agents_per_wave, int hold_lanes);
 
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */

@@ -100,7 +100,7 @@ def check(lib, text=None):
     n_tile, n_runs, top_agpr = 0, 0, -1
     base, per, slots = agpr_block_params()
     for name, ins in funcs:
-        if "mpc_tile_kernel" in name:
+        if "mpc_tile_" in name:
             pr, runs, top = check_agpr_block(name, ins, base, per, slots)
             problems += pr
             n_tile += 1; n_runs += runs; top_agpr = max(top_agpr, top)

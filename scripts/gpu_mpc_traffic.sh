@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-K="python $REPO/scripts/prof_mpc_tp.py $N 2 ${3:-private,tile}"
+K="python $REPO/scripts/prof_mpc_tp.py $N 2 ${3:-private,tile,tile_refill}"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/mpc_tp_stats -o mpc -- $K > $OUT/mpc_tp_stats.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/mpc_tp_fetch -o mpc -- $K > $OUT/mpc_tp_fetch.log 2>&1
 timeout 300 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/mpc_tp_write -o mpc -- $K > $OUT/mpc_tp_write.log 2>&1

@@ -20,7 +20,9 @@ x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
 variants = sys.argv[3].split(",") if len(sys.argv) > 3 else ["private", "tile", "refill"]
 for v in variants:
     for _ in range(reps):
-        if v == "refill":
+        if v == "tile_refill":
+            X.mpc_solve_tile_refill(x0, xref, 21, max(128, (n + 1023) // 1024), 32 if (n + 1023) // 1024 <= 512 else 16)   # the product's geometry
+        elif v == "refill":
             X.mpc_solve_refill(x0, xref, 21, 512, 16, poison=False)
         elif v == "tile":
             X.mpc_solve_store(x0, xref, 21, 1)

@@ -456,3 +456,50 @@ def test_reciprocal_of_the_fused_step_is_the_ieee_quotient_on_this_device(crx):
     n, bad_two, bad_six = X.recip_sweep()
     print(f"recip sweep: {n} inputs, rcp + 2 fma: {bad_two} mismatches, rcp + 6 fma: {bad_six}")
     assert n == 2 * (0x5d800000 - 0x21800000 + 1) and bad_two == 0 and bad_six == 0
+
+
+def _contract_err(crx, oracle_mod, x0, P0, z, ud, Q, R, dt=0.1):
+    """-> (floored error of the whole x history, covariance error under the max|P_ref| floor, fraction of history floats that differ)"""
+    import torch
+    from cpprobotics_amd.experimental import ekf_run_contracted
+    T, n = z.shape[0], x0.shape[0]
+    xo, Po, xho, _ = oracle_mod.ekf_run(x0, P0, z, ud, Q, R, dt=dt)
+    xd, Pd = _t(x0), _t(P0)
+    xh = torch.empty((T, n, 4), dtype=torch.float32, device="cuda")
+    ekf_run_contracted(xd, Pd, _t(z), _t(ud), Q, R, dt=dt, x_hist=xh)
+    xh = xh.cpu().numpy()
+    assert np.isfinite(xh).all() and bit_equal(xh[-1], xd.cpu().numpy())
+    return floored_rel_err(xh, xho, 1.0), float(np.max(np.abs(Pd.cpu().numpy() - Po)) / np.max(np.abs(Po))), float(np.mean(xh != xho))
+
+
+def test_contracted_arithmetic_experiment_single_vehicle_within_1e6(crx, oracle_mod):
+    """crx_x_ekf_run_contracted_dev (round 6): the packed step with its multiply-then-add pairs fused — an EXPERIMENT, not a product
+    mode.  On configs[0] — the reference's own single vehicle, 1000 steps — it is within north_star's 1e-6 (floored metric)."""
+    Q, R = ekf_QR()
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, 1, 1000, seed=0, single=True)
+    ex, eP, _ = _contract_err(crx, oracle_mod, x0, P0, z, ud, Q, R)
+    assert ex <= 1e-6 and eP <= 1e-6, (ex, eP)
+
+
+@pytest.mark.parametrize("n,T,seed", [(4096, 1000, 11), (65536, 200, 12), (1000, 999, 13)])
+def test_contracted_arithmetic_experiment_is_not_within_1e6_for_every_vehicle(crx, oracle_mod, n, T, seed):
+    """... and over a batch it is NOT: the worst vehicle of a few thousand leaves 1e-6 within a thousand steps (the filter's velocity
+    state integrates the noisy input — an undamped random walk — so a last-bit perturbation is carried, not contracted).  VERDICT r5
+    made "1e-6 for every vehicle" the condition for shipping the mode: this test RECORDS why it is not in crx_ekf_params.  What it
+    asserts: the fused kernel really computes something else than the exact one (the flag is honoured), stays close (a sanity bound,
+    NOT the contract: 5e-5), and — for the long runs — that the 1e-6 claim would indeed be false."""
+    Q, R = ekf_QR()
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, n, T, seed=seed)
+    ex, eP, differ = _contract_err(crx, oracle_mod, x0, P0, z, ud, Q, R)
+    assert differ > 0.0
+    assert ex <= 5e-5 and eP <= 5e-5, (ex, eP)
+    if T >= 999:
+        assert ex > 1e-6, f"the batch stayed within 1e-6 ({ex:.2e}): re-measure on the full workload (bench.py extra.ekf_contracted) before promoting the mode"
+
+
+def test_contracted_arithmetic_experiment_falls_back_to_the_exact_arithmetic_for_other_dt(crx, oracle_mod):
+    """dt other than the reference's 0.1: the entry point computes in the exact arithmetic — the reference's bits."""
+    Q, R = ekf_QR()
+    u, x0, P0, w, z, ud = _inputs(oracle_mod, 300, 40, seed=5)
+    ex, eP, differ = _contract_err(crx, oracle_mod, x0, P0, z, ud, Q, R, dt=0.05)
+    assert ex == 0.0 and eP == 0.0 and differ == 0.0

@@ -41,3 +41,41 @@ def test_checker_catches_a_missing_wait_state_and_a_split_block():
     # the scheduler moved something into the exec-masked block
     problems, _ = check_isa.check(None, text=ok.replace("\tv_add_f32_e32 v51, v51, v46", "\tv_mov_b32_e32 v9, s19                                     // x\n\tv_add_f32_e32 v51, v51, v46"))
     assert len(problems) == 1 and "exec-masked add" in problems[0]
+
+
+def test_gain_block_check_catches_a_compiler_write_into_the_block():
+    """Round 6: the MPC tile kernels keep their feedback gains in accumulator registers a40 .. a255 between inline-asm statements
+    (csrc/mpc_agpr.inc).  The compiler may use ANY accumulator register for a value of its own between two of them; the build
+    check must accept the accessor runs and refuse everything else that touches the block."""
+    import check_isa
+    base, per, slots = check_isa.agpr_block_params()
+    assert (base, per) == (40, 12) and base + per * slots == 256
+
+    def run(op, first, dst=True):
+        return "".join(f"\t{op} a{first + k}, v{10 + k}\n" if dst else f"\t{op} v{10 + k}, a{first + k}\n" for k in range(per))
+    head = "0000000000001000 <_ZN3crx15mpc_tile_kernelILi24EEEvv>:\n"
+    ok = head + "\tv_accvgpr_write_b32 a3, v1\n" + run("v_accvgpr_write_b32", base + per * 2) + "\tv_accvgpr_read_b32 v5, a39\n" + \
+        run("v_accvgpr_read_b32", base, dst=False)
+    problems, stats = check_isa.check(None, text=ok)
+    assert not problems and stats["mpc_tile_kernels"] == 1 and stats["gain_block_accessor_runs"] == 2 and stats["highest_compiler_agpr_in_tile_kernels"] == 39
+    # a stray compiler spill into the block
+    problems, _ = check_isa.check(None, text=ok + "\tv_accvgpr_write_b32 a41, v7\n")
+    assert problems and "gain block" in problems[0]
+    # a run cut short (the scheduler moved one accessor instruction away)
+    cut = head + "".join(run("v_accvgpr_write_b32", base).splitlines(keepends=True)[:-1])
+    problems, _ = check_isa.check(None, text=cut)
+    assert problems
+    # a misaligned run, and a non-accessor instruction naming a block register
+    problems, _ = check_isa.check(None, text=head + run("v_accvgpr_write_b32", base + 1))
+    assert problems
+    problems, _ = check_isa.check(None, text=head + "\tv_accvgpr_mov_b32 a100, a2\n")
+    assert problems
+    # the same instructions in a kernel that is not a tile kernel are none of this check's business
+    problems, _ = check_isa.check(None, text="0000000000001000 <_ZN3crx10mpc_kernelILi24ELb1EEEvv>:\n\tv_accvgpr_write_b32 a41, v7\n")
+    assert not problems
+
+
+def test_generated_accessor_file_is_current():
+    """csrc/mpc_agpr.inc is generated (register names must be literals in the asm text): the committed file is what the generator prints."""
+    import gen_mpc_agpr
+    assert open(os.path.join(ROOT, "cpprobotics_amd", "csrc", "mpc_agpr.inc")).read() == gen_mpc_agpr.text()

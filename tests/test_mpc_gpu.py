@@ -334,3 +334,53 @@ def test_tile_layout_on_the_speed_bound_problems(crx):
         a = mpc_solve_store(x0, xref, 21, 0)
         b = mpc_solve_store(x0, xref, 21, 1)
         assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+@pytest.mark.parametrize("n,apw,hold", [(65536, 1024, 16), (70001, 512, 8), (20000, 128, 64), (4096, 64, 1)])
+def test_tile_layout_with_refilled_lanes_gives_the_same_bits(crx, n, apw, hold):
+    """crx::mpc_tile_refill_kernel: the tile layout with finished lanes refilled from the wave's range and the line search scheduled
+    asynchronously.  Per agent the same sweeps in the same order as crx::mpc_kernel: status, solution and cost bit for bit."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_store, mpc_solve_tile_refill
+    x0, xref = mpc_problem(n, 21, 17)
+    x0, xref = _t(x0), _t(xref)
+    a = mpc_solve_store(x0, xref, 21, 0)
+    b = mpc_solve_tile_refill(x0, xref, 21, apw, hold)
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+def test_thirteenth_private_memory_stream_is_refused_not_aborted():
+    """Every hardware queue the private-memory solver has run on keeps a full-device scratch reservation and 16 of them abort the process
+    (profiles/r05/scratch_queues_probe.jsonl): crx_mpc_solve_batch_dev counts the distinct streams it has been launched on and returns
+    CRX_ERR_INVALID with an explanation on the 13th.  In a process of its own: the count is per process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import torch
+import cpprobotics_amd as crx
+from common import mpc_problem
+x0, xref = mpc_problem(256, 21, 4)
+x0, xref = torch.from_numpy(x0).cuda(), torch.from_numpy(xref).cuda()
+streams = [torch.cuda.Stream() for _ in range(14)]
+ok = 0
+for j, s in enumerate(streams):
+    with torch.cuda.stream(s):
+        try:
+            crx.mpc_solve(x0, xref, 21); ok += 1
+        except crx.CrxError as e:
+            print("refused", j + 1, str(e)[:200]); break
+for s in streams[:4]:                       # streams already admitted keep working
+    with torch.cuda.stream(s):
+        crx.mpc_solve(x0, xref, 21)
+torch.cuda.synchronize()
+print("admitted", ok)
+'''
+    r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "admitted 12" in r.stdout and "refused 13" in r.stdout and "13th distinct stream" in r.stdout, r.stdout

@@ -49,6 +49,12 @@ class FrenetConfig(C.Structure):
                 [(k, C.c_double) for k in ("robot_radius", "kj", "kt", "kd", "klat", "klon")])
 
 
+class SwarmConfig(C.Structure):
+    _fields_ = [("n", C.c_int), ("T", C.c_int), ("Tm", C.c_int), ("plan_every", C.c_int), ("depth", C.c_int), ("v_cmd", C.c_float),
+                ("dl", C.c_float), ("dt_ref", C.c_double), ("nsearch", C.c_int), ("allow_shared_queues", C.c_int), ("planner_streams", C.POINTER(C.c_void_p)), ("ekf", EkfParams),
+                ("mpc", MpcParams)]
+
+
 class PfParams(C.Structure):
     _fields_ = [("rsim0", C.c_float), ("rsim1", C.c_float), ("Q", C.c_float), ("dt", C.c_double), ("nth", C.c_float)]
 
@@ -133,6 +139,20 @@ _SIGNATURES = {
     "crx_mpc_closed_loop_flags_batch_dev": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P,
                                                  _P, _P]),
     "crx_mpc_closed_loop_batch": (_I, [_I, _I, _P, _CP, _F, _I, C.POINTER(MpcParams), C.POINTER(LoopParams), _P, _P, _P, _P]),
+    "crx_hw_queues": (_I, []),
+    "crx_swarm_default_config": (None, [C.POINTER(SwarmConfig)]),
+    "crx_swarm_create": (_I, [C.POINTER(_P), C.POINTER(SwarmConfig), _CP, _P, _P, _P, _P]),
+    "crx_swarm_round_dev": (_I, [_P, _P, _P, _P, _P, C.POINTER(C.c_longlong)]),
+    "crx_swarm_plans": (_I, [_P, C.c_longlong, C.POINTER(_I), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "crx_swarm_state": (_P, [_P]),
+    "crx_swarm_wait": (_I, [_P, _P]),
+    "crx_swarm_destroy": (_I, [_P]),
+    "crx_comm_unique_id": (_I, [_P]),
+    "crx_comm_init_rank": (_I, [C.POINTER(_P), _P, _I, _I]),
+    "crx_comm_rank": (_I, [_P]),
+    "crx_comm_world": (_I, [_P]),
+    "crx_allgather_dev": (_I, [_P, _P, _P, C.c_size_t, _P]),
+    "crx_comm_destroy": (_I, [_P]),
 }
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
 
@@ -278,7 +298,13 @@ def disassemble_code_object(lib):
         subprocess.check_call([objcopy, "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
         subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o",
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}"])
-        return subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+        text = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+        # the MPC tile kernels are a second code object, embedded raw in the section .crx_tile_hsaco (csrc/Makefile)
+        tile = os.path.join(d, "tile.hsaco")
+        subprocess.check_call([objcopy, "-O", "binary", "--only-section=.crx_tile_hsaco", lib, tile])
+        if os.path.exists(tile) and os.path.getsize(tile) > 0:
+            text += subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", tile], capture_output=True, text=True, check=True).stdout
+        return text
 
 
 def _functions_of_disassembly(text):

@@ -67,18 +67,18 @@ static int mpc_solve_refill(int n, int T, const float* x0, const float* xref, co
 }
 // The tile layout (mpc_tile_kernels.hip.h): controls in LDS, feedback gains in accumulator registers; T <= 21.
 static int mpc_solve_tile(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                          double* cost, void* stream) {
+                          double* cost, void* stream, int store = 1) {
   if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve (tile layout): bad argument (2 <= T <= 21)");
   if (int rc = check_device()) return rc;
   if (n == 0) return CRX_OK;
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
-  const hipError_t e = crx::mpc_tile_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream);
+  const hipError_t e = crx::mpc_tile_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, store);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile launch");
 }
 static int mpc_solve_tile_refill(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
-                                 double* cost, void* stream, int agents_per_wave, int hold_lanes) {
+                                 double* cost, void* stream, int agents_per_wave, int hold_lanes, int store = 1) {
   if (n < 0 || T < 2 || T - 1 > crx::kMpcTileStages || (n && (!x0 || !xref || !sol)))
     return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): bad argument (2 <= T <= 21)");
   if (agents_per_wave < 64 || agents_per_wave > (1 << 20) || hold_lanes < 1 || hold_lanes > 64)
@@ -88,7 +88,8 @@ static int mpc_solve_tile_refill(int n, int T, const float* x0, const float* xre
   crx_mpc_params p;
   if (prm) p = *prm; else crx_mpc_default_params(&p);
   if (p.max_iter < 1) return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): max_iter must be at least 1");
-  const hipError_t e = crx::mpc_tile_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes);
+  if (store != 1 && store != 2) return fail(CRX_ERR_INVALID, "mpc_solve (tile layout, refilled lanes): store must be 1 or 2");
+  const hipError_t e = crx::mpc_tile_refill_launch(n, T, x0, xref, p, sol, status, cost, (hipStream_t)stream, agents_per_wave, hold_lanes, store);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc tile refill launch");
 }
 // lanes_per_agent: 1 = mpc_kernel (one agent per lane), 4 = mpc_quad_kernel (a DPP quad per agent, parallel line search; T <= 24;
@@ -134,6 +135,11 @@ int crx_x_mpc_solve_tile_refill_dev(int n, int T, const float* x0, const float* 
   CRX_TRACE();
   return mpc_solve_tile_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes);
 }
+int crx_x_mpc_solve_store_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                     double* cost, void* stream, int store, int agents_per_wave, int hold_lanes) {
+  CRX_TRACE();
+  return mpc_solve_tile_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes, store);
+}
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
   CRX_TRACE();
@@ -143,8 +149,8 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
 int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int store) {
   CRX_TRACE();
-  if (store == 1) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream);
-  if (store != 0) return fail(CRX_ERR_INVALID, "mpc_solve (store): store must be 0 (private memory) or 1 (tile layout)");
+  if (store == 1 || store == 2) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream, store);
+  if (store != 0) return fail(CRX_ERR_INVALID, "mpc_solve (store): store must be 0 (private memory), 1 (tile layout) or 2 (checkpointed tile layout)");
   return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 }
 // mpc_solve for n agents with the four-variant portfolio (mpc_kernels.hip.h: mpc_variant): the same NLP, every agent answered by the

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -34,6 +35,11 @@
 #include "mpc_quad_kernels.hip.h"
 #endif
 
+// the MPC tile kernels' code object (csrc/Makefile builds it from mpc_tile_module.hip; host data only)
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include "build/mpc_tile_hsaco.inc"
+#endif
+
 // One translation unit, kept in parts by family (a variant of the library is still one `hipcc ... -shared crx_api.hip`):
 #include "api_internal.inl"
 #include "api_core.inl"
@@ -44,3 +50,4 @@
 #include "api_planners.inl"
 #include "api_frenet.inl"
 #include "api_probes.inl"
+#include "api_swarm.inl"

@@ -268,6 +268,15 @@ constexpr int kMpcLeanFromShared = 16384;
 //      wave's 40 KB of LDS, the float feedback gains of stages 1 .. 18 in accumulator registers a40 .. a255 (mpc_agpr.inc; stage 0's
 //      gains multiply dx = 0 and are never stored; stage 19's stay private), knots and feed-forward steps still private.  The same operations on the same
 //      doubles in the same order as STORE = 0: bit-identical outputs (tests/test_mpc_gpu.py compares the two on the device).
+//   2  the CHECKPOINTED tile layout (round 6, second step): STORE = 1 with the knots cut to ONE buffer of every SECOND knot.
+//        * a candidate rollout no longer reads the accepted trajectory: it re-rolls it from the accepted controls beside the candidate
+//          (x_cur(i+1) = step(x_cur(i), U[cur][i]) — the function of the doubles that produced the stored knot, hence the stored bits)
+//          and writes its own even knots straight into the one buffer; a line search that fails at every step length re-rolls the
+//          accepted controls once to restore it;
+//        * the backward sweep takes the stages in pairs: the odd knot 2m+1 is one model step from the even knot 2m, and the trig that
+//          step needs is the trig stage 2m needs anyway (LEAN recomputes it) — the odd knots cost four fused multiply-adds each.
+//      Private memory left: 10 knots + 20 feed-forward steps + stage 19's gains = 688 B per lane (3.8 KB in STORE 0, 1.9 KB in STORE 1).
+//      Again the same operations on the same doubles in the same order: bit-identical outputs.
 constexpr int kMpcTileStages = 20;                     // T <= 21: the BASELINE horizon (configs[3], configs[4]) and the reference's own T 6
 typedef double mpc_d2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mpc_d2_t lds_double2_t;
@@ -277,7 +286,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
                                                const MpcFeed feed = MpcFeed{}, const MpcTile tile = MpcTile{}) {
   static_assert(!(PORTFOLIO && REFILL), "the portfolio runs in the latency regime");
-  constexpr bool TILE = STORE == 1;
+  constexpr bool TILE = STORE >= 1;
+  constexpr bool CKPT = STORE == 2;
   static_assert(!TILE || (LEAN && MAXT <= kMpcTileStages + 4), "the tile layout recomputes the trig and holds at most kMpcTileStages stages");
   bool live = live_in;
   float4 xi = xi_in;
@@ -289,9 +299,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   const double trust_steer = kMpcTrustSteer * var.trust_scale, trust_accel = kMpcTrustAccel * var.trust_scale;
 
   // per-lane problem storage (private memory)
-  double S[2][MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate)
+  double S[CKPT ? 1 : 2][CKPT ? kMpcTileStages / 2 : MAXT][4];   // knots: x, y, yaw, v        (two buffers: accepted / candidate; CKPT: ONE buffer, S[0][j] = knot 2(j+1))
   double U[TILE ? 1 : 2][TILE ? 1 : MAXT][2];   // stages: delta, a   (TILE: in LDS, tile.u)
-  double kf[MAXT][2];     // feed-forward
+  double kf[TILE ? kMpcTileStages : MAXT][2];     // feed-forward
   // feedback, K[a + 2*b], b over (x,y,yaw,v,d_prev,a_prev) — kept in FLOAT (round 5): the gains only steer the candidate rollouts
   // (u + alpha k + K dx), the fixed point is decided by the feed-forward k (double) alone, and they are 41 % of the solver's memory
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
@@ -358,28 +368,58 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     return v;
   };
   auto track = [&](const double* s, int i) -> double { return track_cost(xr4[i], s); };
-  auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
-    double sn_, cs_;
-    mpc_sincos(s[2], &sn_, &cs_);
-    const double tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
-    if constexpr (!LEAN) { tr[0] = sn_; tr[1] = cs_; tr[2] = tn_; }
+  // the trig of a stage (knot yaw, steering d) and the model step given it: step() = the two in a row, for every layout
+  auto trig3 = [&](double yaw, double d, double& sn_, double& cs_, double& tn_) {
+    mpc_sincos(yaw, &sn_, &cs_);
+    tn_ = small_steer ? mpc_tan_small(d) : mpc_tan(d);
+  };
+  auto step_tr = [&](const double* s, double a, double sn_, double cs_, double tn_, double* sn) {
     sn[0] = fma(s[3] * cs_, dt, s[0]);
     sn[1] = fma(s[3] * sn_, dt, s[1]);
     sn[2] = fma(s[3] * tn_, dt_wb, s[2]);
     sn[3] = fma(a, dt, s[3]);
   };
+  auto step = [&](const double* s, double d, double a, double* sn, double* tr) {
+    double sn_, cs_, tn_;
+    trig3(s[2], d, sn_, cs_, tn_);
+    if constexpr (!LEAN) { tr[0] = sn_; tr[1] = cs_; tr[2] = tn_; }
+    step_tr(s, a, sn_, cs_, tn_, sn);
+  };
+  // CKPT: the even knot j (wave-uniform, 0 <= j <= N): knot 0 is the start state, knot 2(m+1) is S[0][m].  The load is unconditional
+  // (clamped slot) so that the number of loads in flight does not depend on j.
+  auto knot_even = [&](int j, double (&e)[4]) {
+    if constexpr (CKPT) {
+      const int m = j >= 2 ? (j >> 1) - 1 : 0;
+      const bool first = j == 0;
+      e[0] = first ? (double)xi.x : S[0][m][0];
+      e[1] = first ? (double)xi.y : S[0][m][1];
+      e[2] = first ? (double)xi.z : S[0][m][2];
+      e[3] = first ? (double)xi.w : S[0][m][3];
+    }
+  };
+  auto put_knot = [&](int j, const double* x) {      // CKPT: knot j of the trajectory being rolled, kept if it is an even one
+    if constexpr (CKPT) {
+      if (j >= 2 && !(j & 1)) {
+        const int m = (j >> 1) - 1;
+        S[0][m][0] = x[0]; S[0][m][1] = x[1]; S[0][m][2] = x[2]; S[0][m][3] = x[3];
+      }
+    }
+  };
 
   struct StageIn { double s0, s1, s2, s3, sn, cs, tn; float4 r; };
   auto load_stage = [&](int c, int i) -> StageIn {
-    if constexpr (LEAN) return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
+    if constexpr (CKPT) return StageIn{};      // (unused: the checkpointed sweep has its own loads)
+    else if constexpr (LEAN) return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], 0.0, 0.0, 0.0, xr4[i]};
     else return StageIn{S[c][i][0], S[c][i][1], S[c][i][2], S[c][i][3], TR[c][i][0], TR[c][i][1], TR[c][i][2], xr4[i]};
   };
 
   struct RollIn { double s[4], u0, u1, k0, k1, K[12]; float4 r; };
   auto load_roll = [&](int c, int i) -> RollIn {
     RollIn q;
+    if constexpr (!CKPT) {                     // CKPT: the rollout re-rolls the accepted trajectory itself
 #pragma unroll
-    for (int a = 0; a < 4; ++a) q.s[a] = S[c][i][a];
+      for (int a = 0; a < 4; ++a) q.s[a] = S[c][i][a];
+    }
     ldU(c, i, q.u0, q.u1); q.k0 = kf[i][0]; q.k1 = kf[i][1];
     float g[12];
     ldKf(i, g);
@@ -401,24 +441,58 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // the start of a solve from (xi, xr4): zero initial guess (:266-269), rolled out; projected on the acceleration box of each knot
   // (which moves it only if the start speed violates the speed bounds)
   auto start = [&]() {
-    cur = 0;
-    S[0][0][0] = S[1][0][0] = (double)xi.x;
-    S[0][0][1] = S[1][0][1] = (double)xi.y;
-    S[0][0][2] = S[1][0][2] = (double)xi.z;
-    S[0][0][3] = S[1][0][3] = (double)xi.w;
-    J = 0.0;
-    double a_prev = 0.0;
-    for (int i = 0; i < N; ++i) {
-      const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
-      const double a0 = clampd(0.0, ab.lo, ab.hi);
-      stU(0, i, 0.0, a0);
-      J += ctrl_cost(i >= 1, 0.0, a0, 0.0, a_prev);      // the controls of stages i, i - 1
-      a_prev = a0;
-      if (i >= 1) J += track(S[0][i], i);
-      step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
+    if constexpr (CKPT) {
+      cur = 0;
+      double xs[4] = {(double)xi.x, (double)xi.y, (double)xi.z, (double)xi.w};
+      J = 0.0;
+      double a_prev = 0.0;
+      for (int i = 0; i < N; ++i) {
+        const AccelBox ab = accel_box(p, inv_dt, xs[3]);
+        const double a0 = clampd(0.0, ab.lo, ab.hi);
+        stU(0, i, 0.0, a0);
+        J += ctrl_cost(i >= 1, 0.0, a0, 0.0, a_prev);
+        a_prev = a0;
+        if (i >= 1) J += track(xs, i);
+        double xn[4];
+        step(xs, 0.0, a0, xn, nullptr);
+        put_knot(i + 1, xn);
+        xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
+      }
+      J += track(xs, N);
+    } else {
+      cur = 0;
+      S[0][0][0] = S[1][0][0] = (double)xi.x;
+      S[0][0][1] = S[1][0][1] = (double)xi.y;
+      S[0][0][2] = S[1][0][2] = (double)xi.z;
+      S[0][0][3] = S[1][0][3] = (double)xi.w;
+      J = 0.0;
+      double a_prev = 0.0;
+      for (int i = 0; i < N; ++i) {
+        const AccelBox ab = accel_box(p, inv_dt, S[0][i][3]);
+        const double a0 = clampd(0.0, ab.lo, ab.hi);
+        stU(0, i, 0.0, a0);
+        J += ctrl_cost(i >= 1, 0.0, a0, 0.0, a_prev);      // the controls of stages i, i - 1
+        a_prev = a0;
+        if (i >= 1) J += track(S[0][i], i);
+        step(S[0][i], 0.0, a0, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
+      }
+      J += track(S[0][N], N);
     }
-    J += track(S[0][N], N);
     mu = 0.0; gn_left = n_gn; gn_run = n_gn; status = 0; it = 0;
+  };
+  // CKPT: the one knot buffer holds a refused candidate — re-roll the accepted controls into it (the same function of the same
+  // doubles as when they were accepted: the same bits)
+  auto restore_knots = [&]() {
+    if constexpr (CKPT) {
+      double xc[4] = {(double)xi.x, (double)xi.y, (double)xi.z, (double)xi.w};
+      for (int i = 0; i < N; ++i) {
+        double ud_, ua_, xn[4];
+        ldU(cur, i, ud_, ua_);
+        step(xc, ud_, ua_, xn, nullptr);
+        put_knot(i + 1, xn);
+        xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+      }
+    }
   };
   if (!REFILL) start();
   bool done = REFILL ? true : !live;
@@ -429,14 +503,34 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   const size_t nv_ = 4 * (size_t)T + 2 * ((size_t)T - 1);
   // the agent's answer in the reference's layout (:341-345) and the speed-bound check of every knot
   auto write_solution = [&](float* __restrict__ so_) {
-    for (int i = 0; i < T; ++i) {
-      const double v = S[cur][i][3];
-      if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
-      if (so_) {
-        so_[i] = (float)S[cur][i][0];
-        so_[T + i] = (float)S[cur][i][1];
-        so_[2 * T + i] = (float)S[cur][i][2];
-        so_[3 * T + i] = (float)v;
+    if constexpr (CKPT) {                          // the knots of the accepted controls, re-rolled
+      double xc[4] = {(double)xi.x, (double)xi.y, (double)xi.z, (double)xi.w};
+      for (int i = 0; i < T; ++i) {
+        const double v = xc[3];
+        if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
+        if (so_) {
+          so_[i] = (float)xc[0];
+          so_[T + i] = (float)xc[1];
+          so_[2 * T + i] = (float)xc[2];
+          so_[3 * T + i] = (float)v;
+        }
+        if (i < N) {
+          double ud_, ua_, xn[4];
+          ldU(cur, i, ud_, ua_);
+          step(xc, ud_, ua_, xn, nullptr);
+          xc[0] = xn[0]; xc[1] = xn[1]; xc[2] = xn[2]; xc[3] = xn[3];
+        }
+      }
+    } else {
+      for (int i = 0; i < T; ++i) {
+        const double v = S[cur][i][3];
+        if (v > p.max_speed + 1e-9 || v < p.min_speed - 1e-9) status |= 2;
+        if (so_) {
+          so_[i] = (float)S[cur][i][0];
+          so_[T + i] = (float)S[cur][i][1];
+          so_[2 * T + i] = (float)S[cur][i][2];
+          so_[3 * T + i] = (float)v;
+        }
       }
     }
     if (so_)
@@ -462,9 +556,8 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     // ------------------------------------------------------------------ backward sweep
     double lx[4], lp0, lp1;          // V_s
     double Wxx[4][4], Wxp[4][2], Wpp00, Wpp01, Wpp11;  // V_ss (symmetric)
-    {
+    auto terminal = [&](const double* s) {     // V_s, V_ss of the terminal cost at knot N
       const float4 r = rN;
-      const double* s = S[cur][N];
       lx[0] = c2qx * (s[0] - (double)r.x);
       lx[1] = c2qy * (s[1] - (double)r.y);
       lx[2] = c2qyaw * (s[2] - (double)r.z);
@@ -478,34 +571,22 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       }
       Wxx[0][0] = c2qx; Wxx[1][1] = c2qy; Wxx[2][2] = c2qyaw; Wxx[3][3] = c2qv;
       Wpp00 = 0.0; Wpp01 = 0.0; Wpp11 = 0.0;
-    }
+    };
     dV1 = 0.0; dV2 = 0.0; gnorm = 0.0;
     // The sweep's operands live in private memory (L2 / HBM latency once only a few waves are still iterating): stage
     // i - 1's knot, trig and reference and stage i - 2's control are requested at the top of stage i and consumed one
     // iteration later.
-    StageIn nx = load_stage(cur, N - 1);
-    double uc0, uc1, up0, up1;
+    double uc0, uc1, up0, up1;                 // the controls of the stage about to be swept and of the one below it
     ldU(cur, N - 1, uc0, uc1);
     ldU(cur, N >= 2 ? N - 2 : 0, up0, up1);
 #if CRX_MPC_TICKS >= 2
     const long long tk_b0 = clock64();
 #endif
-    for (int i = N - 1; i >= 0; --i) {
-      const StageIn in = nx;
-      const double ud = uc0, ua = uc1;
+    // stage i of the sweep, given its knot s, the trig of (s.yaw, ud), the reference row, its control (ud, ua) and the control below (pd, pa)
+    auto stage = [&](const int i, const double s_0, const double s_1, const double s_2, const double s_3, const double sn_, const double cs_,
+                     const double tn, const float4 r_in, const double ud, const double ua, const double pd, const double pa) {
       const bool inner = i >= 1;
-      const double pd = inner ? up0 : 0.0, pa = inner ? up1 : 0.0;
-      // unconditional (clamped index) so that the number of loads in flight is the same on every path: with a branch
-      // around them the compiler has to drain the memory queue (vmcnt(0)) before the first use of `in`
-      nx = load_stage(cur, i >= 1 ? i - 1 : 0);
-      uc0 = up0; uc1 = up1;
-      ldU(cur, i >= 2 ? i - 2 : 0, up0, up1);
-      const double s[4] = {in.s0, in.s1, in.s2, in.s3};
-      double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
-      if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
-        mpc_sincos(in.s2, &sn_, &cs_);
-        tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
-      }
+      const double s[4] = {s_0, s_1, s_2, s_3};
       const double v = s[3];
       const double sec2 = fma(tn, tn, 1.0);
       const double vdt = v * dt, vdw = v * dt_wb;
@@ -517,7 +598,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       double l_uu0 = c2r_d, l_uu1 = c2r_a;
       double l_p0 = 0.0, l_p1 = 0.0, l_pp0 = 0.0, l_pp1 = 0.0, l_up0 = 0.0, l_up1 = 0.0;
       if (inner) {
-        const float4 r = in.r;
+        const float4 r = r_in;
         q2[0] = c2qx; q2[1] = c2qy; q2[2] = c2qyaw; q2[3] = c2qv;
         l_x[0] = c2qx * (s[0] - (double)r.x);
         l_x[1] = c2qy * (s[1] - (double)r.y);
@@ -708,6 +789,71 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       }
       lp0 = Vs[4]; lp1 = Vs[5];
       Wpp00 = Vss[4][4]; Wpp01 = Vss[4][5]; Wpp11 = Vss[5][5];
+    };
+    if constexpr (!CKPT) {
+      terminal(S[cur][N]);
+      StageIn nx = load_stage(cur, N - 1);
+      for (int i = N - 1; i >= 0; --i) {
+        const StageIn in = nx;
+        const double ud = uc0, ua = uc1;
+        const bool inner = i >= 1;
+        const double pd = inner ? up0 : 0.0, pa = inner ? up1 : 0.0;
+        // unconditional (clamped index) so that the number of loads in flight is the same on every path: with a branch
+        // around them the compiler has to drain the memory queue (vmcnt(0)) before the first use of `in`
+        nx = load_stage(cur, i >= 1 ? i - 1 : 0);
+        uc0 = up0; uc1 = up1;
+        ldU(cur, i >= 2 ? i - 2 : 0, up0, up1);
+        double sn_ = in.sn, cs_ = in.cs, tn = in.tn;
+        if constexpr (LEAN) {            // what step() computed when this knot was rolled out: the same functions of the same doubles
+          mpc_sincos(in.s2, &sn_, &cs_);
+          tn = small_steer ? mpc_tan_small(ud) : mpc_tan(ud);
+        }
+        stage(i, in.s0, in.s1, in.s2, in.s3, sn_, cs_, tn, in.r, ud, ua, pd, pa);
+      }
+    } else {
+      // The checkpointed sweep: stages in pairs (odd i, then i - 1).  E = the even knot at or below the stage about to be swept; tE =
+      // the trig of (E.yaw, steering of E's stage), computed when the odd stage above E needs it for its model step and used again by
+      // E's own stage.  The even knot below is requested at the top of an even stage and consumed by the odd stage after it.
+      double E[4], tE0 = 0.0, tE1 = 0.0, tE2 = 0.0, sN[4];
+      if (N & 1) {                       // the terminal knot is odd: one step from knot N - 1, whose stage comes first
+        knot_even(N - 1, E);
+        trig3(E[2], uc0, tE0, tE1, tE2);
+        step_tr(E, uc1, tE0, tE1, tE2, sN);
+      } else {
+        knot_even(N, sN);
+        knot_even(N - 2, E);
+      }
+      terminal(sN);
+      float4 rn = xr4[N - 1];
+      auto even_stage = [&](const int i) {          // E = knot i, tE valid
+        const double ud = uc0, ua = uc1;
+        const bool inner = i >= 1;
+        const double pd = inner ? up0 : 0.0, pa = inner ? up1 : 0.0;
+        const float4 r = rn;
+        rn = xr4[i >= 1 ? i - 1 : 0];
+        double En[4];
+        knot_even(i >= 2 ? i - 2 : 0, En);
+        uc0 = up0; uc1 = up1;
+        ldU(cur, i >= 2 ? i - 2 : 0, up0, up1);
+        stage(i, E[0], E[1], E[2], E[3], tE0, tE1, tE2, r, ud, ua, pd, pa);
+        E[0] = En[0]; E[1] = En[1]; E[2] = En[2]; E[3] = En[3];
+      };
+      auto odd_stage = [&](const int i) {           // E = knot i - 1 (i >= 1)
+        const double ud = uc0, ua = uc1, pd = up0, pa = up1;
+        const float4 r = rn;
+        rn = xr4[i - 1];
+        uc0 = up0; uc1 = up1;
+        ldU(cur, i >= 2 ? i - 2 : 0, up0, up1);
+        trig3(E[2], pd, tE0, tE1, tE2);             // the trig of stage i - 1 ...
+        double s[4];
+        step_tr(E, pa, tE0, tE1, tE2, s);           // ... whose model step gives knot i: what the rollout stored in the other layouts
+        double sn_, cs_, tn;
+        trig3(s[2], ud, sn_, cs_, tn);
+        stage(i, s[0], s[1], s[2], s[3], sn_, cs_, tn, r, ud, ua, pd, pa);
+      };
+      int i = N - 1;
+      if (N & 1) { even_stage(i); --i; }
+      for (; i >= 1; i -= 2) { odd_stage(i); even_stage(i - 1); }
     }
 #if CRX_MPC_TICKS >= 2
     tk_b += clock64() - tk_b0; tk_nb++;
@@ -722,7 +868,12 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     // The candidate rollout carries its state and previous control in registers (they are also written to S[nxt],
     // U[nxt] for the next backward sweep, but never read back here: a store-to-load round trip through private memory
     // per stage would sit on the critical path), and requests stage i + 1's operands while stage i computes.
-    double xs[4] = {S[cur][0][0], S[cur][0][1], S[cur][0][2], S[cur][0][3]};
+    double xs[4], xc[4];                                     // the candidate's knot i; CKPT: the accepted trajectory's knot i beside it
+    if constexpr (CKPT) {
+      xs[0] = xc[0] = (double)xi.x; xs[1] = xc[1] = (double)xi.y; xs[2] = xc[2] = (double)xi.z; xs[3] = xc[3] = (double)xi.w;
+    } else {
+      xs[0] = S[cur][0][0]; xs[1] = S[cur][0][1]; xs[2] = S[cur][0][2]; xs[3] = S[cur][0][3];
+    }
     double pnd = 0.0, pna = 0.0, pcd = 0.0, pca = 0.0;       // previous stage's new / current controls
     // (TILE, round 6: requesting the private-memory part — knot, feed-forward step, reference row — TWO stages ahead and reading the
     // gains from their registers at the point of use was built and measured: 1 M agents 15.0 -> 16.4 ms lockstep, 11.7 -> 12.0 refilled,
@@ -732,7 +883,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       const RollIn in = nx;
       nx = load_roll(cur, i + 1 < N ? i + 1 : N - 1);      // unconditional, clamped: see the backward sweep (two stages in
                                                            // flight were measured too: 4 % slower)
-      const double d0 = xs[0] - in.s[0], d1 = xs[1] - in.s[1], d2 = xs[2] - in.s[2], d3 = xs[3] - in.s[3];
+      double d0, d1, d2, d3;
+      if constexpr (CKPT) { d0 = xs[0] - xc[0]; d1 = xs[1] - xc[1]; d2 = xs[2] - xc[2]; d3 = xs[3] - xc[3]; }
+      else { d0 = xs[0] - in.s[0]; d1 = xs[1] - in.s[1]; d2 = xs[2] - in.s[2]; d3 = xs[3] - in.s[3]; }
       const double d4 = (i >= 1) ? pnd - pcd : 0.0;
       const double d5 = (i >= 1) ? pna - pca : 0.0;
       double du0 = alpha * in.k0;
@@ -747,7 +900,16 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       if (i >= 1) Jn += track_cost(in.r, xs);                     // track(xs, i)
       double xn[4];
       step(xs, nd, na, xn, LEAN ? TR[0][0] : TR[nxt][i]);
-      S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
+      if constexpr (CKPT) {
+        put_knot(i + 1, xn);
+        double xcn[4];                                              // the accepted trajectory's next knot: what S[cur][i + 1] holds in the other layouts
+        if (i + 1 < N) {                                            // (the last stage's successor is never compared with)
+          step(xc, in.u0, in.u1, xcn, nullptr);
+          xc[0] = xcn[0]; xc[1] = xcn[1]; xc[2] = xcn[2]; xc[3] = xcn[3];
+        }
+      } else {
+        S[nxt][i + 1][0] = xn[0]; S[nxt][i + 1][1] = xn[1]; S[nxt][i + 1][2] = xn[2]; S[nxt][i + 1][3] = xn[3];
+      }
       xs[0] = xn[0]; xs[1] = xn[1]; xs[2] = xn[2]; xs[3] = xn[3];
       pnd = nd; pna = na; pcd = in.u0; pca = in.u1;
     }
@@ -797,7 +959,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
         if (Jn < J || (trust && Jn <= J + noise)) { accept_step(alpha, Jn, nxt); accepted = true; break; }
         alpha *= 0.5;
       }
-      if (!accepted) reject_step(exact);
+      if (!accepted) { reject_step(exact); restore_knots(); }
       if (iter == p.max_iter - 1) it = p.max_iter;
     }
   } else {
@@ -865,7 +1027,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
         if (Jn < J || (trust && Jn <= J + noise)) { accept_step(alpha, Jn, nxt); end = true; }
         else {
           alpha *= 0.5;
-          if (++ls == (exact ? 4 : 10)) { reject_step(exact); end = true; }   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
+          if (++ls == (exact ? 4 : 10)) { reject_step(exact); restore_knots(); end = true; }   // a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones
         }
         if (end) {
           fwd = false;
@@ -907,6 +1069,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   }
 }
 
+#ifndef CRX_MPC_TILE_MODULE      // (mpc_tile_module.hip takes mpc_solve_lane only: the kernels and launchers below belong to the library's own code object)
 // `live_lanes` agents in the low lanes of every wave, `blockDim.x / 64` waves per workgroup.  Production: full waves (64) in
 // single-wave workgroups.  The launch lasts as long as its slowest wave, and a wave pays in every sweep for the agent of
 // its lanes that needs the most line-search rollouts, so while the batch leaves SIMDs idle (BASELINE configs[3]: 128 full
@@ -972,6 +1135,8 @@ mpc_portfolio_kernel(int n, int T, const float* __restrict__ x0g, const float* _
   if (costg) costg[agent] = J;
 }
 
+#endif  // CRX_MPC_TILE_MODULE
+
 inline MpcP mpc_pack(const crx_mpc_params& q) {
   MpcP p;
   p.dt = q.dt; p.wb = q.wb; p.max_steer = q.max_steer; p.max_accel = q.max_accel;
@@ -981,6 +1146,7 @@ inline MpcP mpc_pack(const crx_mpc_params& q) {
   return p;
 }
 
+#ifndef CRX_MPC_TILE_MODULE
 inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                        int* status, double* cost, hipStream_t stream) {
   const MpcP p = mpc_pack(q);
@@ -1033,6 +1199,7 @@ inline hipError_t mpc_launch(int n, int T, const float* x0, const float* xref, c
   else mpc_launch_T<false>(n, T, live, grid, block, stream, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
+#endif  // CRX_MPC_TILE_MODULE
 
 }  // namespace crx
 

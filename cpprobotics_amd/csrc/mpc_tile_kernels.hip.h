@@ -17,24 +17,41 @@
 // Horizons of at most kMpcTileStages = 20 stages (T <= 21: BASELINE configs[3] / configs[4] and the reference's own T 6); longer ones
 // take mpc_kernel.
 //
-// Safety of the register block: every statement that touches a40 .. a255 names its registers literally; mpc_agpr_reserve() lists all
-// of them as clobbers, which makes the kernel descriptor allocate them.  It does NOT keep the compiler out: its register allocator
-// may place a short-lived value of its own in any accumulator register between two of those statements (it takes them in ascending
-// order — the first build of this kernel, with the block at a28, had it in a28 .. a32).  So the block starts above what the
-// allocator needs (a0 .. a32 today) and the BUILD checks it: scripts/check_isa.py disassembles the tile kernels and demands that
-// a40 .. a255 appear only in complete, slot-aligned runs of twelve v_accvgpr_write / v_accvgpr_read — a compiler bump or an edit
-// that raises the register pressure into the block fails __graft_entry__.build(), it does not corrupt a solve.
+// Safety of the register block: every statement that touches the block names its registers literally; mpc_agpr_reserve() lists all
+// of them as clobbers, which makes the kernel descriptor allocate them.  That alone does NOT keep the compiler out: its register
+// allocator is free to place a value of its own in any accumulator register between two of those statements, and it does so
+// opportunistically — the first build of the checkpointed layout, with the block at a40, had loads landing in a130 .. a137; moved to
+// a52 and a64, the allocator followed.  The fence is the LLVM function attribute "amdgpu-agpr-alloc"="B,B" (B = the block's base):
+// the allocator may then use a0 .. a(B-1) only and spills anything beyond to private memory.  clang has no spelling for that
+// attribute, so the tile kernels are their own translation unit (mpc_tile_module.hip), compiled to LLVM IR, patched
+// (scripts/patch_agpr_alloc.py), compiled to a gfx950 code object and embedded in libcrx.so (section .crx_tile_hsaco; csrc/Makefile);
+// the library loads it with hipModuleLoadData on first use.  The BUILD still checks the result: scripts/check_isa.py disassembles
+// the tile kernels and demands that the block appear only in complete, slot-aligned runs of twelve v_accvgpr_write / v_accvgpr_read.
 #pragma once
 #include "mpc_kernels.hip.h"
 
 namespace crx {
 
-template <int MAXT>
-__global__ void __launch_bounds__(64)       // one wave per workgroup: four workgroups (one per SIMD) share a CU's 160 KB of LDS
-mpc_tile_kernel(int n, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
-                float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+// the argument block of every tile kernel (= its kernarg segment: the kernels take it by value, the host hands it to
+// hipModuleLaunchKernel as a buffer); chunk / hold: the refilled launch's geometry, unused by the lockstep kernels
+struct MpcTileArgs {
+  int n, T, chunk, hold;
+  const float* x0g; const float* xrefg;
+  MpcP p;
+  float* solg; int* statusg; double* costg;
+};
+
+#ifdef CRX_MPC_TILE_MODULE     // ---- device side: compiled by mpc_tile_module.hip only ----------------------------------------------
+
+// STORE 1: knots private, two buffers; 2: every second knot, one buffer (mpc_kernels.hip.h).  One wave per workgroup: four workgroups
+// (one per SIMD) share a CU's 160 KB of LDS.
+template <int MAXT, int STORE>
+__device__ __forceinline__ void mpc_tile_body(const MpcTileArgs& a) {
   __shared__ mpc_d2_t tile_u[2 * kMpcTileStages * 64];          // 40,960 B
   mpc_agpr_reserve();
+  const int n = a.n, T = a.T;
+  const float* __restrict__ x0g = a.x0g; const float* __restrict__ xrefg = a.xrefg;
+  float* __restrict__ solg = a.solg; int* __restrict__ statusg = a.statusg; double* __restrict__ costg = a.costg;
   const size_t agent = (size_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = agent < (size_t)n;
   const size_t ag = live ? agent : 0;
@@ -42,14 +59,14 @@ mpc_tile_kernel(int n, int T, const float* __restrict__ x0g, const float* __rest
   const float4 xi = reinterpret_cast<const float4*>(x0g)[ag];
   const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, false, true, 1>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0, MpcFeed{},
-                                              MpcTile{(lds_double2_t*)tile_u});
+  mpc_solve_lane<MAXT, false, false, true, STORE>(live, T, xi, xr4, a.p, live ? solg + agent * nv : nullptr, status, J, a0, d0, MpcFeed{},
+                                                  MpcTile{(lds_double2_t*)tile_u});
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
 }
 
-// The tile layout with the lanes REFILLED (mpc_solve_lane<.., REFILL, .., STORE = 1>): wave w owns the agents [w * chunk, (w + 1) * chunk);
+// The tile layout with the lanes REFILLED (mpc_solve_lane<.., REFILL, .., STORE>): wave w owns the agents [w * chunk, (w + 1) * chunk);
 // a lane whose agent has converged holds it until `hold` lanes of the wave hold one, then they write their solutions and take the
 // wave's next agents; the line search is scheduled asynchronously across the lanes (mpc_kernels.hip.h).  A lockstep wave lasts as long
 // as the slowest of its 64 agents — mean of the wave maximum 11.8 sweeps against a mean of 6.8 — and the launch as long as its unluckiest
@@ -57,18 +74,19 @@ mpc_tile_kernel(int n, int T, const float* __restrict__ x0g, const float* __rest
 // measured this schedule on the private-memory layout and dropped it (1.14x, then 0.89-1.00x: where waves queue, the memory system was
 // the limit, and a long-lived wave never hands its share of the caches on).  With the working set mostly on the chip that limit is gone.
 // Per agent the same sweeps in the same order: bit-identical to mpc_kernel.
-template <int MAXT>
-__global__ void __launch_bounds__(64)
-mpc_tile_refill_kernel(int n, int T, int chunk, int hold, const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p,
-                       float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+template <int MAXT, int STORE>
+__device__ __forceinline__ void mpc_tile_refill_body(const MpcTileArgs& a) {
   __shared__ mpc_d2_t tile_u[2 * kMpcTileStages * 64];
   mpc_agpr_reserve();
-  const int lo = (int)blockIdx.x * chunk;
-  const MpcFeed feed{lo, (n - lo < chunk) ? n : lo + chunk, hold, x0g, xrefg, solg, statusg, costg};
+  const int lo = (int)blockIdx.x * a.chunk;
+  const MpcFeed feed{lo, (a.n - lo < a.chunk) ? a.n : lo + a.chunk, a.hold, a.x0g, a.xrefg, a.solg, a.statusg, a.costg};
   int status; double J; float a0, d0;
-  mpc_solve_lane<MAXT, false, true, true, 1>(false, T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, p, nullptr, status, J, a0, d0, feed,
-                                             MpcTile{(lds_double2_t*)tile_u});
+  mpc_solve_lane<MAXT, false, true, true, STORE>(false, a.T, float4{0.f, 0.f, 0.f, 0.f}, nullptr, a.p, nullptr, status, J, a0, d0, feed,
+                                                 MpcTile{(lds_double2_t*)tile_u});
 }
+
+#else                          // ---- host side: the library's launchers (crx_api.hip) -----------------------------------------------
+
 // crx_mpc_solve_batch_dev takes the tile layout from this many agents on (csrc/api_mpc.inl has the numbers)
 constexpr int kMpcTileFrom = 131072;
 // a geometry for the refilled launch: as many waves as the chip has SIMDs (one persistent wave each), at least 128 agents per wave
@@ -76,23 +94,55 @@ inline int mpc_tile_refill_chunk(int n) {
   const int c = (n + 1023) / 1024;
   return c < 128 ? 128 : c;
 }
-inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                                         int* status, double* cost, hipStream_t stream, int chunk, int hold) {
-  const MpcP p = mpc_pack(q);
-  const dim3 grid((unsigned)(((size_t)n + chunk - 1) / chunk)), block(64);
-  hipLaunchKernelGGL((mpc_tile_refill_kernel<24>), grid, block, 0, stream, n, T, chunk, hold, x0, xref, p, sol, status, cost);
-  return hipGetLastError();
+
+// the embedded code object (csrc/Makefile: mpc_tile_hsaco.inc) and its kernels, loaded once per device
+extern "C" __attribute__((section(".crx_tile_hsaco"))) const unsigned char crx_tile_hsaco[];
+extern "C" const unsigned int crx_tile_hsaco_len;
+enum { kTileLockstep1 = 0, kTileLockstep2, kTileRefill1, kTileRefill2, kTileKernels };
+struct MpcTileModule { hipModule_t mod = nullptr; hipFunction_t fn[kTileKernels] = {}; hipError_t err = hipSuccess; bool tried = false; };
+inline hipError_t mpc_tile_function(int which, hipFunction_t* out) {
+  static std::mutex mu;
+  static MpcTileModule mods[64];                      // by device ordinal
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> l(mu);
+  MpcTileModule& m = mods[dev];
+  if (!m.tried) {
+    m.tried = true;
+    static const char* const names[kTileKernels] = {"crx_mpc_tile_kernel_s1", "crx_mpc_tile_kernel_s2", "crx_mpc_tile_refill_kernel_s1",
+                                                    "crx_mpc_tile_refill_kernel_s2"};
+    m.err = hipModuleLoadData(&m.mod, crx_tile_hsaco);
+    for (int k = 0; k < kTileKernels && m.err == hipSuccess; ++k) m.err = hipModuleGetFunction(&m.fn[k], m.mod, names[k]);
+  }
+  if (m.err != hipSuccess) return m.err;
+  *out = m.fn[which];
+  return hipSuccess;
+}
+inline hipError_t mpc_tile_module_launch(int which, unsigned grid, MpcTileArgs args, hipStream_t stream) {
+  hipFunction_t f;
+  hipError_t e = mpc_tile_function(which, &f);
+  if (e != hipSuccess) return e;
+  size_t size = sizeof(args);
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(f, grid, 1, 1, 64, 1, 1, 0, stream, nullptr, config);
 }
 
-// T - 1 <= kMpcTileStages
-inline hipError_t mpc_tile_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
-                                  int* status, double* cost, hipStream_t stream) {
-  const MpcP p = mpc_pack(q);
-  const dim3 grid((unsigned)(((size_t)n + 63) / 64)), block(64);
-  // one instantiation for every horizon it takes: the <8> build of mpc_solve_lane (fully unrolled short loops) needs more accumulator
-  // registers of its own than the block leaves free (scripts/check_isa.py caught it)
-  hipLaunchKernelGGL((mpc_tile_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
-  return hipGetLastError();
+inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                         int* status, double* cost, hipStream_t stream, int chunk, int hold, int store = 1) {
+  const MpcTileArgs args{n, T, chunk, hold, x0, xref, mpc_pack(q), sol, status, cost};
+  return mpc_tile_module_launch(store == 2 ? kTileRefill2 : kTileRefill1, (unsigned)(((size_t)n + chunk - 1) / chunk), args, stream);
 }
+
+// T - 1 <= kMpcTileStages.  One instantiation (MAXT = 24) for every horizon it takes: the <8> build of mpc_solve_lane (fully unrolled
+// short loops) needs more accumulator registers of its own than the block leaves free.
+inline hipError_t mpc_tile_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
+                                  int* status, double* cost, hipStream_t stream, int store = 1) {
+  const MpcTileArgs args{n, T, 0, 0, x0, xref, mpc_pack(q), sol, status, cost};
+  return mpc_tile_module_launch(store == 2 ? kTileLockstep2 : kTileLockstep1, (unsigned)(((size_t)n + 63) / 64), args, stream);
+}
+
+#endif
 
 }  // namespace crx

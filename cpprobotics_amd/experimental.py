@@ -12,6 +12,7 @@ _X_SIGNATURES = {
     "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_tile_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_mpc_solve_store_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_lqr_closed_loop_lanes_dev": (_I, [_I, _I, _P, L._CP, _P, _P, _P, C.POINTER(L.LqrParams), C.POINTER(L.VehicleParams),
@@ -232,8 +233,9 @@ def mpc_solve_store(x0, xref, T, store, params=None, out=None):
     return sol, status, cost
 
 
-def mpc_solve_tile_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, out=None):
-    """mpc_solve through crx::mpc_tile_refill_kernel (tile layout, lanes refilled).  -> sol, status, cost."""
+def mpc_solve_tile_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, params=None, out=None, store=1):
+    """mpc_solve through crx::mpc_tile_refill_kernel (tile layout, lanes refilled; store = 1, or 2: the checkpointed tile layout).
+    -> sol, status, cost."""
     import torch
     from .mpc import default_params, mpc_n_vars
     L.require_cuda(x0, xref)
@@ -246,8 +248,8 @@ def mpc_solve_tile_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, para
         sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
         status = torch.empty((n,), dtype=torch.int32, device=x0.device)
         cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
-    L.check(xlib().crx_x_mpc_solve_tile_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
-                                                   L.stream_ptr(), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_tile_refill_dev")
+    L.check(xlib().crx_x_mpc_solve_store_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                    L.stream_ptr(), int(store), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_store_refill_dev")
     return sol, status, cost
 
 

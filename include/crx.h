@@ -407,6 +407,71 @@ int crx_frenet_run_batch_dev(int n, int max_ticks, float* state, const float* co
                              int* status, int* best_idx, int* n_valid, float* path_cf, int* path_ok, int path_cap,
                              void* stream);
 
+
+/* ---- a mixed EKF + MPC swarm round and the multi-GPU gather, from C (BASELINE.json configs[4]) -------
+ * What cpprobotics_amd/swarm.py does from Python, behind the C boundary, so that a C++ host of the reference's loops
+ * (src/extended_kalman_filter.cpp:171-188, src/model_predictive_control.cpp:371-385) can run the swarm and concatenate the
+ * per-GPU results without Python or torch.
+ *
+ * crx_hw_queues(): the hardware queues the HIP runtime will multiplex this process's streams onto (GPU_MAX_HW_QUEUES, default 4;
+ * read by the runtime when it first touches the device).  Streams that share a queue run their kernels one after the other: a round
+ * pipelined `depth` deep wants depth + 2 (measured: 0.74 ms per round on 4 queues, 0.49 on 8+, profiles/r05/swarm_hw_queues.txt).
+ * Export the variable before the first HIP call of the process. */
+int crx_hw_queues(void);
+
+/* One rank's shard of the swarm: n vehicles run T fused EKF steps per round from (x0, P0); every plan_every-th vehicle then plans
+ * from its final estimate at the commanded speed (full-scan calc_nearest_index, calc_ref_trajectory, mpc_solve over Tm knots).
+ * The planners of `depth` consecutive rounds are in flight together, each on its own slot (stream, events, buffers), overlapping the
+ * EKF launches of the following rounds.  All pointers are device pointers of the current device; the object copies what it needs at
+ * creation (x0, P0, Q, R, the course struct — NOT the course arrays, which must outlive it). */
+typedef struct crx_swarm crx_swarm;
+typedef struct crx_swarm_config {
+  int n;                  /* vehicles of this shard */
+  int T;                  /* EKF steps per round */
+  int Tm;                 /* MPC knots (crx_mpc_solve_batch_dev's T; 21 in configs[4]) */
+  int plan_every;         /* every plan_every-th vehicle plans (8) */
+  int depth;              /* planner slots (1 .. 12: the solver's per-queue private-memory reservation) */
+  float v_cmd;            /* the commanded speed the planners start from (the filter's 4th state is a random walk) */
+  float dl;               /* calc_ref_trajectory: course tick (1.0) */
+  double dt_ref;          /* calc_ref_trajectory: DT (0.2) */
+  int nsearch;            /* calc_ref_trajectory: N_IND_SEARCH (10) */
+  int allow_shared_queues;/* 0: creation fails if depth + 1 streams exceed crx_hw_queues(); 1: accept the serialisation */
+  void* const* planner_streams; /* NULL: the object creates (and owns) its `depth` slot streams; else `depth` streams of the caller's —
+                                   a process that already runs the solver on streams of its own hands those in: every distinct stream
+                                   the private-memory solver has run on counts against the 12 the library admits */
+  crx_ekf_params ekf;
+  crx_mpc_params mpc;     /* shared_gpu is set by the library when depth > 1 */
+} crx_swarm_config;
+void crx_swarm_default_config(crx_swarm_config* c);
+int crx_swarm_create(crx_swarm** out, const crx_swarm_config* cfg, const crx_course* course_dev, const float* x0_dev,
+                     const float* P0_dev, const float* Q, const float* R /* host: 16 + 4 floats, column-major */);
+/* Issue one round on `stream` (nothing is waited for): reset (x, P) to (x0, P0), T EKF steps over z, u ([T][n][2]), xEst history
+ * into x_hist ([T][n][4], may be NULL), then — on the round's slot stream — the planners.  Returns the round's index through
+ * round_out (may be NULL).  A slot's buffers are reused `depth` rounds later; the launch stream waits for that round's planners
+ * by event, the host never blocks. */
+int crx_swarm_round_dev(crx_swarm* s, const float* z_dev, const float* u_dev, float* x_hist_dev, void* stream, long long* round_out);
+/* The buffers of round `round` (one of the last `depth` rounds): device pointers, valid to READ after crx_swarm_wait.  Any of the
+ * out-pointers may be NULL.  sol [n_plan][4 Tm + 2 (Tm - 1)], status [n_plan], cost [n_plan], xref [n_plan][4 Tm], est [n_plan][4]. */
+int crx_swarm_plans(crx_swarm* s, long long round, int* n_plan, const float** sol, const int** status, const double** cost,
+                    const float** xref, const float** est);
+const float* crx_swarm_state(crx_swarm* s);            /* [n][4]: the filter state after the most recent round's EKF launch */
+int crx_swarm_wait(crx_swarm* s, void* stream);         /* make `stream` wait for every planner in flight (events; the host does not block) */
+int crx_swarm_destroy(crx_swarm* s);                    /* synchronises the slot streams first */
+
+/* The trajectory / final-state concat over GPUs (the one collective the path has): RCCL's all-gather over xGMI,
+ * one process (or thread) per GPU.  librccl is loaded on the first of these calls (no link-time dependency).
+ *   rank 0: crx_comm_unique_id(id) -> hand the CRX_COMM_ID_BYTES bytes to every rank (MPI, a socket, a file: examples/ekf_fleet_mgpu.cpp)
+ *   every rank: crx_comm_init_rank(&comm, id, rank, world) on its device, then crx_allgather_dev(comm, send, recv, bytes, stream):
+ *   recv[r * bytes .. (r + 1) * bytes) = rank r's send buffer — for contiguous equal agent shards, the swarm in global agent order. */
+#define CRX_COMM_ID_BYTES 128
+typedef struct crx_comm crx_comm;
+int crx_comm_unique_id(void* id_out /* CRX_COMM_ID_BYTES */);
+int crx_comm_init_rank(crx_comm** out, const void* id, int rank, int world);
+int crx_comm_rank(const crx_comm* c);
+int crx_comm_world(const crx_comm* c);
+int crx_allgather_dev(crx_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int crx_comm_destroy(crx_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,8 @@ int crx_x_ekf_run_contracted_dev(int n, int T, float* x, float* P, const float* 
                                  const float* Q, const float* R, const crx_ekf_params* prm, void* stream);
 
 /* The MPC solve with the lane's working-set layout forced: store = 0 private memory (crx::mpc_kernel), 1 the tile layout of round 6
- * (crx::mpc_tile_kernel: controls in LDS, feedback gains in accumulator registers; T <= 21).  Both give the same bits in every
+ * (crx::mpc_tile_kernel: controls in LDS, feedback gains in accumulator registers; T <= 21), 2 the same with every second knot kept in
+ * one buffer (the odd knots and the accepted trajectory of a rollout are re-rolled).  Both give the same bits in every
  * output; crx_mpc_solve_batch_dev picks by horizon and batch size (csrc/api_mpc.inl). */
 int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int store);
@@ -45,6 +46,11 @@ int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, 
  * finished lanes hand their agents back hold_lanes (1 .. 64) at a time and take the next ones.  Bit-identical per agent. */
 int crx_x_mpc_solve_tile_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                     double* cost, void* stream, int agents_per_wave, int hold_lanes);
+
+/* ... with the layout chosen: store = 1 (crx_x_mpc_solve_tile_refill_dev) or 2 (the checkpointed tile layout: every second knot, one
+ * buffer — csrc/mpc_kernels.hip.h).  Bit-identical per agent. */
+int crx_x_mpc_solve_store_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                     double* cost, void* stream, int store, int agents_per_wave, int hold_lanes);
 
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */

@@ -31,11 +31,13 @@ for n in sizes:
     res["sweeps"] = {"mean": float(sw.mean()), "max": int(sw.max()), "mean_of_wave_max": float(sw[: n // 64 * 64].reshape(-1, 64).max(axis=1).mean()),
                      "at_cap_50": int((sw >= 50).sum()), "converged_frac": float((st0 & 1).mean())}
     ref = None
-    variants = [("private", lambda: mpc_solve_store(x0, xref, T, 0, out=out)), ("tile", lambda: mpc_solve_store(x0, xref, T, 1, out=out))]
+    variants = [("private", lambda: mpc_solve_store(x0, xref, T, 0, out=out)), ("tile", lambda: mpc_solve_store(x0, xref, T, 1, out=out)),
+                ("tile2", lambda: mpc_solve_store(x0, xref, T, 2, out=out))]
     if n >= 65536:
-        for apw, hold in ((n // 1024, 16), (n // 1024, 32), (n // 2048, 16), (n // 2048, 32), (max(64, n // 4096), 32), (max(64, n // 8192), 32)):
+        for apw, hold in ((n // 1024, 16), (n // 2048, 16), (max(64, n // 4096), 32)):
             if apw >= 128:
-                variants.append((f"tile_refill_{apw}_{hold}", (lambda a, h: (lambda: mpc_solve_tile_refill(x0, xref, T, a, h, out=out)))(apw, hold)))
+                for st in (1, 2):
+                    variants.append((f"tile{st}_refill_{apw}_{hold}", (lambda a, h, q: (lambda: mpc_solve_tile_refill(x0, xref, T, a, h, out=out, store=q)))(apw, hold, st)))
     for name, fn in variants:
         fn()
         torch.cuda.synchronize()

@@ -26,6 +26,10 @@ for v in variants:
             X.mpc_solve_refill(x0, xref, 21, 512, 16, poison=False)
         elif v == "tile":
             X.mpc_solve_store(x0, xref, 21, 1)
+        elif v == "tile2":
+            X.mpc_solve_store(x0, xref, 21, 2)
+        elif v == "tile2_refill":
+            X.mpc_solve_tile_refill(x0, xref, 21, max(128, (n + 1023) // 1024), 32 if (n + 1023) // 1024 <= 512 else 16, store=2)
         else:
             X.mpc_solve_store(x0, xref, 21, 0)
     torch.cuda.synchronize()

@@ -169,6 +169,93 @@ def shared_planner_streams(crx, o):
     assert len(seen) == 6
 
 
+def c_round(crx, o, depth, rounds, n=8192, T=100):
+    """crx_swarm_round_dev (csrc/api_swarm.inl), the round issued by one C call, against the Python round (swarm.SwarmShard, itself held
+    to the oracle by mixed_rounds): same start states, same measurement sets round by round, `depth` planner launches in flight — every
+    byte of the EKF history, the final state and of every plan buffer (est, xref, sol, status, cost) must be equal."""
+    import torch
+    from cpprobotics_amd import cswarm, swarm
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    dev = torch.device("cuda", 0)
+    shard = swarm.SwarmShard(n, T, course, Q, R, dev, depth=depth, input_sets=3, seed=7)
+    _queues_ok(shard, depth)
+    assert cswarm.hw_queues() == int(os.environ["GPU_MAX_HW_QUEUES"])
+    ref = []
+    for r in range(rounds):
+        shard.run()
+        h = shard.rnd.trajectory_time_major(); xf = shard.x.clone()
+        slot = r % depth
+        with torch.cuda.stream(shard.rnd.plan_streams[slot]):
+            ref.append((h, xf, {k: v.clone() for k, v in shard.slots[slot].items()}))
+    shard.wait()
+    torch.cuda.synchronize()
+    # depth 1: the object's own slot stream; deeper: the caller's streams (crx_swarm_config.planner_streams), here the Python round's
+    cs = cswarm.CSwarm(shard.x0, shard.P0, shard.dc, Q, R, T, Tm=TM, plan_every=8, depth=depth, v_cmd=shard.v_cmd,
+                       streams=swarm.planner_streams(dev, depth) if depth > 1 else None)
+    got = []
+    hist = [torch.empty((T, n, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    for r in range(rounds):
+        rr = cs.round(shard.z[r % 3], shard.ud[r % 3], hist[r % 2])
+        assert rr == r
+        got.append([hist[r % 2].clone(), cs.state(), None])
+        if r >= depth - 1:                       # round r - depth + 1 is the oldest still in its slot: fetch it before the next round reuses the slot
+            k = r - depth + 1
+            cs.wait()
+            got[k][2] = cs.plans(k)
+    cs.wait()
+    for k in range(max(0, rounds - depth + 1), rounds):
+        got[k][2] = cs.plans(k)
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        h, xf, b = ref[r]
+        gh, gx, gb = got[r]
+        assert torch.equal(gh.view(torch.int32), h.view(torch.int32)), f"round {r}: history"
+        assert torch.equal(gx.view(torch.int32), xf.view(torch.int32)), f"round {r}: final state"
+        for key in ("sol", "xref"):
+            assert torch.equal(gb[key].view(torch.int32), b[key].view(torch.int32)), f"round {r}: {key}"
+        assert torch.equal(gb["status"], b["status"]) and torch.equal(gb["cost"].view(torch.int64), b["cost"].view(torch.int64)), f"round {r}: status / cost"
+    assert not torch.equal(got[0][1], got[1][1])
+    cs.close()
+
+
+def c_round_refuses_too_few_queues(crx, o):
+    """crx_swarm_create says no (CRX_ERR_INVALID + an explanation) when depth + 1 streams exceed the hardware queues, unless told to accept it."""
+    import torch
+    from cpprobotics_amd import Course, cswarm
+    from cpprobotics_amd._lib import CrxError
+    Q, R = ekf_QR()
+    course, goal = mpc_course_f32()
+    dev = torch.device("cuda", 0)
+    dc = Course.from_numpy(course, device=dev)
+    x0 = torch.zeros((256, 4), device=dev); P0 = torch.eye(4, device=dev).reshape(1, 16).repeat(256, 1).contiguous()
+    q = cswarm.hw_queues()
+    try:
+        cswarm.CSwarm(x0, P0, dc, Q, R, 10, depth=q)
+        raise AssertionError("crx_swarm_create accepted depth + 1 > hardware queues")
+    except CrxError as e:
+        assert "GPU_MAX_HW_QUEUES" in str(e)
+    cs = cswarm.CSwarm(x0, P0, dc, Q, R, 10, depth=q, allow_shared_queues=True)
+    cs.close()
+
+
+def comm_one_rank(crx, o):
+    """crx_comm_* / crx_allgather_dev on a one-rank communicator (the GPU box has one GPU): RCCL is found, the communicator comes up, the
+    gather returns the send buffer — the trajectory concat of a one-process swarm."""
+    import torch
+    from cpprobotics_amd import cswarm
+    uid = cswarm.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = cswarm.Comm(uid, 0, 1)
+    assert (c.rank, c.world) == (0, 1)
+    for shape, dt in (((100, 8192, 4), torch.float32), ((131072, 4), torch.float32), ((3,), torch.int32), ((7, 5), torch.float64)):
+        t = (torch.rand(shape, device="cuda") * 100).to(dt)
+        out = c.allgather(t)
+        torch.cuda.synchronize()
+        assert out.shape == (1,) + tuple(shape) and torch.equal(out[0], t)
+    c.close()
+
+
 def main(argv):
     warnings.filterwarnings("error", message=".*hardware queues.*")      # SwarmShard's warning must not fire here
     import oracle
@@ -184,6 +271,12 @@ def main(argv):
         one_ekf_launch(crx, oracle)
     elif check == "shared_planner_streams":
         shared_planner_streams(crx, oracle)
+    elif check == "c_round":
+        c_round(crx, oracle, int(argv[1]), int(argv[2]))
+    elif check == "c_round_refuses_too_few_queues":
+        c_round_refuses_too_few_queues(crx, oracle)
+    elif check == "comm_one_rank":
+        comm_one_rank(crx, oracle)
     else:
         raise SystemExit(f"unknown check {check}")
     import torch

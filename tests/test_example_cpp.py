@@ -109,3 +109,27 @@ def test_tracking_example_runs(tracking_exe):
     assert m and 100 < int(m.group(1)) < 1000 and int(m.group(2)) > 450, r.stdout
     m = re.search(r"MPC: .* agent 0 is at course index (\d+)", r.stdout)
     assert m and int(m.group(1)) > 30, r.stdout
+
+
+@pytest.fixture(scope="module")
+def mgpu_exe(tmp_path_factory, crx):
+    return _build(tmp_path_factory, "ekf_fleet_mgpu")
+
+
+def test_mgpu_example_builds_and_fails_loudly_without_gpu(mgpu_exe, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([mgpu_exe, "0", "1", str(tmp_path / "id")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_mgpu_example_runs_as_a_one_rank_fleet(mgpu_exe, tmp_path):
+    """examples/ekf_fleet_mgpu.cpp: one process per GPU, the final estimates concatenated by crx_allgather_dev (RCCL behind the C ABI) —
+    here with world = 1, the only world a one-GPU box offers; the N > 1 launch is the shell loop in the file's header."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([mgpu_exe, "0", "1", str(tmp_path / "id"), "8192", "200"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 of 1" in r.stdout and "gathered 8192 final estimates" in r.stdout

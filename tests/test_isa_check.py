@@ -49,17 +49,17 @@ def test_gain_block_check_catches_a_compiler_write_into_the_block():
     check must accept the accessor runs and refuse everything else that touches the block."""
     import check_isa
     base, per, slots = check_isa.agpr_block_params()
-    assert (base, per) == (40, 12) and base + per * slots == 256
+    assert per == 12 and base + per * slots == 256 and base >= 40
 
     def run(op, first, dst=True):
         return "".join(f"\t{op} a{first + k}, v{10 + k}\n" if dst else f"\t{op} v{10 + k}, a{first + k}\n" for k in range(per))
     head = "0000000000001000 <_ZN3crx15mpc_tile_kernelILi24EEEvv>:\n"
-    ok = head + "\tv_accvgpr_write_b32 a3, v1\n" + run("v_accvgpr_write_b32", base + per * 2) + "\tv_accvgpr_read_b32 v5, a39\n" + \
+    ok = head + "\tv_accvgpr_write_b32 a3, v1\n" + run("v_accvgpr_write_b32", base + per * 2) + f"\tv_accvgpr_read_b32 v5, a{base - 1}\n" + \
         run("v_accvgpr_read_b32", base, dst=False)
     problems, stats = check_isa.check(None, text=ok)
-    assert not problems and stats["mpc_tile_kernels"] == 1 and stats["gain_block_accessor_runs"] == 2 and stats["highest_compiler_agpr_in_tile_kernels"] == 39
+    assert not problems and stats["mpc_tile_kernels"] == 1 and stats["gain_block_accessor_runs"] == 2 and stats["highest_compiler_agpr_in_tile_kernels"] == base - 1
     # a stray compiler spill into the block
-    problems, _ = check_isa.check(None, text=ok + "\tv_accvgpr_write_b32 a41, v7\n")
+    problems, _ = check_isa.check(None, text=ok + f"\tv_accvgpr_write_b32 a{base + 1}, v7\n")
     assert problems and "gain block" in problems[0]
     # a run cut short (the scheduler moved one accessor instruction away)
     cut = head + "".join(run("v_accvgpr_write_b32", base).splitlines(keepends=True)[:-1])
@@ -71,7 +71,7 @@ def test_gain_block_check_catches_a_compiler_write_into_the_block():
     problems, _ = check_isa.check(None, text=head + "\tv_accvgpr_mov_b32 a100, a2\n")
     assert problems
     # the same instructions in a kernel that is not a tile kernel are none of this check's business
-    problems, _ = check_isa.check(None, text="0000000000001000 <_ZN3crx10mpc_kernelILi24ELb1EEEvv>:\n\tv_accvgpr_write_b32 a41, v7\n")
+    problems, _ = check_isa.check(None, text="0000000000001000 <_ZN3crx10mpc_kernelILi24ELb1EEEvv>:\n\tv_accvgpr_write_b32 a" + str(base + 1) + ", v7\n")
     assert not problems
 
 

@@ -323,6 +323,25 @@ def test_tile_layout_gives_the_same_bits_as_private_memory(crx, n, T, seed):
     assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
 
 
+@pytest.mark.parametrize("n,T,seed", [(8192, 21, 4), (8192, 21, 7), (8192, 6, 3), (1000, 13, 9), (65536, 21, 11), (70001, 21, 12), (777, 2, 5), (777, 3, 6),
+                                      (3000, 20, 8), (3000, 14, 2)])
+def test_checkpointed_tile_layout_gives_the_same_bits_as_private_memory(crx, n, T, seed):
+    """Round 6, second step (store = 2): ONE buffer of every second knot.  The rollout re-rolls the accepted trajectory beside its
+    candidate, the backward sweep takes an odd knot as one model step from the even knot below it, a failed line search re-rolls the
+    accepted controls into the buffer, the solution's knots are re-rolled on the way out — each the function of the doubles that
+    produced the stored knot in the other layouts, so status, every solution float and the double cost must equal crx::mpc_kernel's
+    bit for bit.  Odd and even horizons (the terminal knot is stored or computed), T = 2 and 3 (no stored knot / one)."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_store
+    x0, xref = mpc_problem(n, T, seed)
+    x0, xref = _t(x0), _t(xref)
+    a = mpc_solve_store(x0, xref, T, 0)
+    b = mpc_solve_store(x0, xref, T, 2)
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
 def test_tile_layout_on_the_speed_bound_problems(crx):
     """The rare branches of the backward sweep (speed-bound feedback rows, regularised sweeps) through the tile layout."""
     import torch
@@ -332,12 +351,14 @@ def test_tile_layout_on_the_speed_bound_problems(crx):
         x0, xref = speed_bound_problems(512, 21, 5, fast=fast)
         x0, xref = _t(x0), _t(xref)
         a = mpc_solve_store(x0, xref, 21, 0)
-        b = mpc_solve_store(x0, xref, 21, 1)
-        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+        for store in (1, 2):
+            b = mpc_solve_store(x0, xref, 21, store)
+            assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
 
 
+@pytest.mark.parametrize("store", [1, 2])
 @pytest.mark.parametrize("n,apw,hold", [(65536, 1024, 16), (70001, 512, 8), (20000, 128, 64), (4096, 64, 1)])
-def test_tile_layout_with_refilled_lanes_gives_the_same_bits(crx, n, apw, hold):
+def test_tile_layout_with_refilled_lanes_gives_the_same_bits(crx, n, apw, hold, store):
     """crx::mpc_tile_refill_kernel: the tile layout with finished lanes refilled from the wave's range and the line search scheduled
     asynchronously.  Per agent the same sweeps in the same order as crx::mpc_kernel: status, solution and cost bit for bit."""
     import torch
@@ -345,7 +366,7 @@ def test_tile_layout_with_refilled_lanes_gives_the_same_bits(crx, n, apw, hold):
     x0, xref = mpc_problem(n, 21, 17)
     x0, xref = _t(x0), _t(xref)
     a = mpc_solve_store(x0, xref, 21, 0)
-    b = mpc_solve_tile_refill(x0, xref, 21, apw, hold)
+    b = mpc_solve_tile_refill(x0, xref, 21, apw, hold, store=store)
     assert torch.equal(a[1], b[1])
     assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
     assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))

@@ -21,14 +21,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HW_QUEUES = 16          # bench.py: max(16, swarm_depth + 10)
 
 
-def _run(*args, timeout=900):
+def _run(*args, timeout=900, queues=HW_QUEUES):
     env = dict(os.environ)
-    env["GPU_MAX_HW_QUEUES"] = str(HW_QUEUES)
+    env["GPU_MAX_HW_QUEUES"] = str(queues)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "swarm_checks.py")] + [str(a) for a in args], capture_output=True, text=True,
                        timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
-    assert "swarm check ok" in r.stdout and f"GPU_MAX_HW_QUEUES={HW_QUEUES}" in r.stdout
+    assert "swarm check ok" in r.stdout and f"GPU_MAX_HW_QUEUES={queues}" in r.stdout
     assert "hardware queues" not in r.stderr, r.stderr[-2000:]
 
 
@@ -53,3 +53,19 @@ def test_round_is_one_ekf_launch_without_a_gather():
 
 def test_round_objects_of_a_process_share_their_planner_streams():
     _run("shared_planner_streams")
+
+
+@pytest.mark.parametrize("depth,rounds", [(1, 3), (6, 9)])
+def test_c_round_equals_the_python_round(depth, rounds):
+    """crx_swarm_round_dev — the whole round issued by one C call (include/crx.h) — gives the bytes of the Python
+    round (which the tests above hold to the oracle): history, final state, every plan buffer, slots reused."""
+    _run("c_round", depth, rounds)
+
+
+def test_c_round_refuses_more_streams_than_hardware_queues():
+    _run("c_round_refuses_too_few_queues", queues=4)
+
+
+def test_c_allgather_on_a_one_rank_communicator():
+    """crx_comm_unique_id / crx_comm_init_rank / crx_allgather_dev / crx_comm_destroy: RCCL behind the C ABI."""
+    _run("comm_one_rank")

@@ -140,6 +140,52 @@ int crx_x_mpc_solve_store_refill_dev(int n, int T, const float* x0, const float*
   CRX_TRACE();
   return mpc_solve_tile_refill(n, T, x0, xref, prm, sol, status, cost, stream, agents_per_wave, hold_lanes, store);
 }
+// The two-phase solve (mpc_kernels.hip.h; measured and not selected, include/crx_experimental.h): phase 1 = the product launch with the sweep cap lowered to first_sweeps, on `stream`; the
+// agents that ran into the cap are listed and solved from scratch with the caller's cap on `tail_stream` (behind an event; may be the
+// same stream).  Bit for bit crx_mpc_solve_batch_dev's answers.  work: (n + 64) ints of device memory the call owns until both
+// streams have passed it.  Events: a small per-process ring (created once; an event is reused only long after its wait was enqueued).
+static hipEvent_t two_phase_event() {
+  static std::mutex mu;
+  static std::vector<hipEvent_t> ring;
+  static size_t next = 0;
+  std::lock_guard<std::mutex> l(mu);
+  if (ring.empty()) {
+    ring.resize(256, nullptr);
+  }
+  hipEvent_t& e = ring[next++ % ring.size()];
+  if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+int crx_x_mpc_solve_two_phase_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                double* cost, int first_sweeps, int* work, void* stream, void* tail_stream) {
+  CRX_TRACE();
+  if (n < 0 || T < 2 || T > CRX_MPC_MAX_T || (n && (!x0 || !xref || !sol || !status || !work)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (two phases): bad argument (2 <= T <= 64; status and work are required)");
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  if (first_sweeps < 1 || first_sweeps >= p.max_iter)          // nothing to split: the ordinary launch
+    return crx_mpc_solve_batch_dev(n, T, x0, xref, &p, sol, status, cost, stream);
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p1 = p;
+  p1.max_iter = first_sweeps;
+  int* count = work;            // work[0]: the count; work[64 ..]: the list (kept apart from the counter's cache line)
+  int* list = work + 64;
+  CRX_HIP(hipMemsetAsync(count, 0, sizeof(int), (hipStream_t)stream));
+  CRX_TRY(crx_mpc_solve_batch_dev(n, T, x0, xref, &p1, sol, status, cost, stream));
+  hipLaunchKernelGGL(crx::mpc_collect_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, (hipStream_t)stream, n, first_sweeps, status, list, count);
+  CRX_HIP(hipGetLastError());
+  hipStream_t tail = (hipStream_t)tail_stream;
+  if (tail != (hipStream_t)stream) {
+    hipEvent_t ev = two_phase_event();
+    if (!ev) return fail(CRX_ERR_HIP, "mpc_solve (two phases): no event");
+    CRX_HIP(hipEventRecord(ev, (hipStream_t)stream));
+    CRX_HIP(hipStreamWaitEvent(tail, ev, 0));
+  }
+  if (int rc = scratch_stream_admit(tail_stream)) return rc;
+  const hipError_t e = crx::mpc_list_launch(n, T, list, count, x0, xref, p, sol, status, cost, tail);
+  return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc list launch");
+}
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
   CRX_TRACE();

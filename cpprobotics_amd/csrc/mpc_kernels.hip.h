@@ -1096,6 +1096,46 @@ mpc_kernel(int n, int T, int live_lanes, const float* __restrict__ x0g, const fl
   if (costg) costg[agent] = J;
 }
 
+// The TWO-PHASE solve (round 6; csrc/api_mpc.inl: crx_mpc_solve_two_phase_dev).  A launch lasts as long as its slowest agent's chain of
+// sweeps, and the distribution of sweep counts has a thin, long tail (configs[3]: mean 6.8, 2.8 % above 10, 0.03 % above 16, a few at
+// the cap of 50); a pipelined host (configs[4]) can keep only so many launches in flight, so its round time is that latency divided by
+// the depth.  Phase 1 is the ordinary launch with the sweep cap lowered to `first_sweeps`; mpc_collect_kernel lists the agents that
+// ran into that cap; mpc_list_kernel solves those FROM SCRATCH with the caller's cap — the solver is deterministic, so an agent's
+// answer is bit for bit what the single launch gives it (its phase-1 sweeps are thrown away: first_sweeps x a few per cent of the
+// agents).  The second launch is a handful of waves and can run on a stream of its own, behind the first one's.
+__global__ void __launch_bounds__(256)
+mpc_collect_kernel(int n, int cap, const int* __restrict__ statusg, int* __restrict__ list, int* __restrict__ count) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  bool un = false;
+  if (i < n) { const int st = statusg[i]; un = !(st & 1) && (st >> 8) >= cap; }
+  const lanemask_t m = lanes_where(un);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == __builtin_ctzll(m)) base = atomicAdd(count, __builtin_popcountll(m));
+  base = __builtin_amdgcn_readlane(base, __builtin_ctzll(m));
+  if (un) list[base + __builtin_popcountll(m & ((lanemask_t(1) << lane) - 1))] = i;
+}
+// entries [64 w, 64 w + 64) of the list on wave w (waves past the count leave at once: the grid is sized for the worst case)
+template <int MAXT>
+__global__ void __launch_bounds__(64)
+mpc_list_kernel(const int* __restrict__ list, const int* __restrict__ count, int T, const float* __restrict__ x0g, const float* __restrict__ xrefg,
+                MpcP p, float* __restrict__ solg, int* __restrict__ statusg, double* __restrict__ costg) {
+  const int cnt = *count;
+  const int entry = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if ((int)blockIdx.x * 64 >= cnt) return;
+  const bool live = entry < cnt;
+  const size_t agent = (size_t)list[live ? entry : 0];
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + agent * (size_t)T;
+  const float4 xi = reinterpret_cast<const float4*>(x0g)[agent];
+  const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, false, false, false>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0);
+  if (!live) return;
+  if (statusg) statusg[agent] = status;
+  if (costg) costg[agent] = J;
+}
+
 // The lane-refilling launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>): a wave
 // of mpc_kernel lasts as long as the slowest of its 64 agents (mean of the wave maximum ~12 sweeps against a mean of 6.8), here a finished
 // lane takes the wave's next agent, and the line search is scheduled asynchronously.  Per agent the same sweeps in the same order:
@@ -1157,6 +1197,17 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
     hipLaunchKernelGGL((mpc_portfolio_kernel<24>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
   else
     hipLaunchKernelGGL((mpc_portfolio_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, n, T, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
+}
+
+// phase 2 of the two-phase solve: n = the size of the batch the list was collected from (the grid's worst case)
+inline hipError_t mpc_list_launch(int n, int T, const int* list, const int* count, const float* x0, const float* xref, const crx_mpc_params& q,
+                                  float* sol, int* status, double* cost, hipStream_t stream) {
+  const MpcP p = mpc_pack(q);
+  const dim3 grid((unsigned)(((size_t)n + 63) / 64)), block(64);
+  if (T <= 8) hipLaunchKernelGGL((mpc_list_kernel<8>), grid, block, 0, stream, list, count, T, x0, xref, p, sol, status, cost);
+  else if (T <= 24) hipLaunchKernelGGL((mpc_list_kernel<24>), grid, block, 0, stream, list, count, T, x0, xref, p, sol, status, cost);
+  else hipLaunchKernelGGL((mpc_list_kernel<CRX_MPC_MAX_T>), grid, block, 0, stream, list, count, T, x0, xref, p, sol, status, cost);
   return hipGetLastError();
 }
 

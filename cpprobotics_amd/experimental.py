@@ -12,6 +12,7 @@ _X_SIGNATURES = {
     "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_tile_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_mpc_solve_two_phase_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _I, _P, _P, _P]),
     "crx_x_mpc_solve_store_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_mpc_solve_lanes_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
@@ -251,6 +252,32 @@ def mpc_solve_tile_refill(x0, xref, T, agents_per_wave=1024, hold_lanes=16, para
     L.check(xlib().crx_x_mpc_solve_store_refill_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                                     L.stream_ptr(), int(store), int(agents_per_wave), int(hold_lanes)), "crx_x_mpc_solve_store_refill_dev")
     return sol, status, cost
+
+
+def mpc_solve_two_phase(x0, xref, T, first_sweeps, params=None, out=None, work=None, tail_stream=None):
+    """crx_x_mpc_solve_two_phase_dev (measured and not selected, include/crx_experimental.h): the launch with its sweep cap lowered to `first_sweeps` on the current stream, then the agents that
+    ran into the cap solved from scratch on `tail_stream` (a torch stream; None = the current one).  Bit for bit mpc_solve's answers,
+    complete once both streams have passed the call.  -> (sol, status, cost, work); work: int32 [n + 64], reusable by the next call on
+    the same pair of streams."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    if out is not None:
+        sol, status, cost = out
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    if work is None:
+        work = torch.empty((n + 64,), dtype=torch.int32, device=x0.device)
+    L.expect("work", work, "i", n + 64)
+    tail = C.c_void_p(tail_stream.cuda_stream) if tail_stream is not None else L.stream_ptr()
+    L.check(xlib().crx_x_mpc_solve_two_phase_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
+                                                int(first_sweeps), L.ptr(work), L.stream_ptr(), tail), "crx_x_mpc_solve_two_phase_dev")
+    return sol, status, cost, work
 
 
 def ekf_run_contracted(xEst, PEst, z, u, Q, R, dt=0.1, x_hist=None):

@@ -45,3 +45,4 @@ def mpc_solve(x0, xref, T, params=None, return_status=False, portfolio=False, ou
     if return_status:
         return sol, status, cost
     return sol
+

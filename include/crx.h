@@ -430,7 +430,8 @@ typedef struct crx_swarm_config {
   int T;                  /* EKF steps per round */
   int Tm;                 /* MPC knots (crx_mpc_solve_batch_dev's T; 21 in configs[4]) */
   int plan_every;         /* every plan_every-th vehicle plans (8) */
-  int depth;              /* planner slots (1 .. 12: the solver's per-queue private-memory reservation) */
+  int depth;              /* planner slots in flight, each with a stream, events and buffers of its own (1 .. 12: every queue the
+                             solver has run on keeps a private-memory reservation) */
   float v_cmd;            /* the commanded speed the planners start from (the filter's 4th state is a random walk) */
   float dl;               /* calc_ref_trajectory: course tick (1.0) */
   double dt_ref;          /* calc_ref_trajectory: DT (0.2) */

@@ -52,6 +52,17 @@ int crx_x_mpc_solve_tile_refill_dev(int n, int T, const float* x0, const float* 
 int crx_x_mpc_solve_store_refill_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                      double* cost, void* stream, int store, int agents_per_wave, int hold_lanes);
 
+/* crx_mpc_solve_batch_dev in TWO PHASES (round 6, measured and not selected): the ordinary launch with the sweep cap lowered to first_sweeps
+ * on `stream`, then — behind an event, on tail_stream (may be the same stream) — the few agents that ran into that cap, solved from
+ * scratch with prm's cap.  The solver is deterministic: every output is bit for bit what crx_mpc_solve_batch_dev writes, complete once
+ * BOTH streams have passed the call.  status is required; work: (n + 64) ints of device memory owned by the call until then.
+ * The idea: a launch lasts as long as its slowest agent, so a pipelined host gets its stream back sooner.  The measurement
+ * (profiles/r06/swarm_two_phase_ab*.jsonl, mpc_store_ab_two_phase.jsonl): configs[4]'s round is bound by the solver's THROUGHPUT under
+ * load, not by launch latency / depth — 0.48-0.53 ms with 7-9 straggler streams against 0.42-0.45 single-phase; and a lone batch LOSES,
+ * because the single launch runs its straggler chains from t = 0 beside everything else, the second phase starts them after the first. */
+int crx_x_mpc_solve_two_phase_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                  double* cost, int first_sweeps, int* work, void* stream, void* tail_stream);
+
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,

@@ -33,6 +33,10 @@ for n in sizes:
     ref = None
     variants = [("private", lambda: mpc_solve_store(x0, xref, T, 0, out=out)), ("tile", lambda: mpc_solve_store(x0, xref, T, 1, out=out)),
                 ("tile2", lambda: mpc_solve_store(x0, xref, T, 2, out=out))]
+    from cpprobotics_amd.experimental import mpc_solve_two_phase
+    wk = torch.empty(n + 64, dtype=torch.int32, device=dev)
+    for K in (8, 9, 10, 12):
+        variants.append((f"two_phase_{K}", (lambda k: (lambda: mpc_solve_two_phase(x0, xref, T, k, out=out, work=wk)))(K)))
     if n >= 65536:
         for apw, hold in ((n // 1024, 16), (n // 2048, 16), (max(64, n // 4096), 32)):
             if apw >= 128:

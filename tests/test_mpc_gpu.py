@@ -405,3 +405,42 @@ print("admitted", ok)
     r = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "admitted 12" in r.stdout and "refused 13" in r.stdout and "13th distinct stream" in r.stdout, r.stdout
+
+
+@pytest.mark.parametrize("n,T,seed,first,own_tail", [(8192, 21, 4, 8, True), (8192, 21, 4, 3, False), (16384, 21, 7, 12, True), (1000, 6, 3, 4, True),
+                                                    (140000, 21, 11, 10, True), (777, 13, 9, 1, False), (4096, 21, 5, 49, True), (4096, 21, 5, 50, True)])
+def test_two_phase_solve_gives_the_same_bits(crx, n, T, seed, first, own_tail):
+    """crx_x_mpc_solve_two_phase_dev: the launch capped at `first` sweeps, the agents that hit the cap solved again from scratch — on a
+    stream of their own or the same one.  The solver is deterministic: status (sweep counts included), every solution float and the
+    double cost must equal crx_mpc_solve_batch_dev's bit for bit, whatever the cap (1: every unconverged agent is a straggler; 49:
+    only the agents at the cap of 50; 50: the ordinary launch), also where the batch size selects the tile kernel for phase 1."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_two_phase
+    x0, xref = mpc_problem(n, T, seed)
+    x0, xref = _t(x0), _t(xref)
+    a = crx.mpc_solve(x0, xref, T, return_status=True)
+    tail = torch.cuda.Stream() if own_tail else None
+    b = mpc_solve_two_phase(x0, xref, T, first, tail_stream=tail)
+    if tail is not None:
+        torch.cuda.current_stream().wait_stream(tail)
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+    if first < 50:
+        cnt = int(b[3][0].item())
+        sw = (a[1] >> 8)
+        assert cnt == int((sw >= first).sum().item()), "the straggler list is exactly the agents whose solve goes past the cap"
+
+
+def test_two_phase_solve_on_the_speed_bound_problems(crx):
+    import torch
+    from common import speed_bound_problems
+    from cpprobotics_amd.experimental import mpc_solve_two_phase
+    for fast in (False, True):
+        x0, xref = speed_bound_problems(512, 21, 5, fast=fast)
+        x0, xref = _t(x0), _t(xref)
+        a = crx.mpc_solve(x0, xref, 21, return_status=True)
+        b = mpc_solve_two_phase(x0, xref, 21, 6)
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))

@@ -8,7 +8,7 @@ sweep counts, 1e-6 floored on the solution, 1e-9 on the cost); consecutive round
 read another round's estimates (a race on the slot ring) would fail the comparison.
 
 Every check runs in a process of its own (tests/swarm_checks.py) that exports GPU_MAX_HW_QUEUES=16 before HIP initialises — the
-configuration bench.py measures (depth 6 on 16 hardware queues) — and asserts that the shard really got `depth + 2` queues; in
+configuration bench.py measures (depth 7 on 16 hardware queues since round 6; 6 before) — and asserts that the shard really got `depth + 2` queues; in
 round 5 these tests ran inside the pytest process on the runtime's default 4 queues and never at depth 6."""
 import os
 import subprocess
@@ -32,7 +32,7 @@ def _run(*args, timeout=900, queues=HW_QUEUES):
     assert "hardware queues" not in r.stderr, r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("depth", [1, 2, 4, 6])
+@pytest.mark.parametrize("depth", [1, 2, 4, 6, 7])
 def test_mixed_swarm_rounds_match_the_oracle(depth):
     """8,192 vehicles x 100 EKF steps, 1,024 planners, consecutive rounds on three different measurement sets with `depth` planner
     launches in flight (depth + 3 rounds at least: every slot is reused): every round's history / final state / covariance bit for
@@ -40,10 +40,10 @@ def test_mixed_swarm_rounds_match_the_oracle(depth):
     _run("mixed_rounds", depth, max(5, depth + 3))
 
 
-@pytest.mark.parametrize("depth,rounds", [(4, 3), (6, 9)])
+@pytest.mark.parametrize("depth,rounds", [(4, 3), (6, 9), (7, 10)])
 def test_full_shard_on_a_strided_sample(depth, rounds):
     """One GPU's shard of the 1,048,576-agent swarm, 131,072 vehicles and 16,384 planners; (6, 9) is the configuration of bench.py's
-    `swarm_configs4` line: depth 6 on 16 hardware queues, slots reused."""
+    `swarm_configs4` line up to round 5 (depth 6 on 16 hardware queues, slots reused), (7, 10) the one since round 6."""
     _run("full_shard", depth, rounds)
 
 
@@ -55,7 +55,7 @@ def test_round_objects_of_a_process_share_their_planner_streams():
     _run("shared_planner_streams")
 
 
-@pytest.mark.parametrize("depth,rounds", [(1, 3), (6, 9)])
+@pytest.mark.parametrize("depth,rounds", [(1, 3), (6, 9), (7, 10)])
 def test_c_round_equals_the_python_round(depth, rounds):
     """crx_swarm_round_dev — the whole round issued by one C call (include/crx.h) — gives the bytes of the Python
     round (which the tests above hold to the oracle): history, final state, every plan buffer, slots reused."""

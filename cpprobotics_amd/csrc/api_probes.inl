@@ -118,6 +118,48 @@ int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int
 }
 }  // extern "C"
 
+// What FETCH_SIZE / WRITE_SIZE count for NARROW accesses (scripts/experiments/gpu_fetch_size_units.py; VERDICT r5: the x 2 on FETCH_SIZE
+// was calibrated on 16-byte-per-lane streaming reads only, the MPC solver's private memory is read 4 and 8 bytes per lane):
+//   mode 0: every lane reads 4 bytes, coalesced (256 B per wave instruction), each byte of src once
+//   mode 1: 8 bytes per lane
+//   mode 2: a PRIVATE array of 512 doubles per lane (4 KiB, like the solver's knots: scratch_store / scratch_load_dwordx2 with a
+//           wave-uniform dynamic index), written once and read back once per pass, `passes` passes; dst[tid] gets the sum.
+//           Known bytes: passes x 4 KiB written and read per lane.
+namespace crx {
+__global__ void __launch_bounds__(256) fetch_units_kernel(int mode, size_t n, const unsigned* __restrict__ src, double* __restrict__ dst, int passes) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  if (mode == 0) {
+    unsigned acc = 0;
+    for (size_t i = tid; i < n; i += stride) acc += src[i];
+    if (acc == 0x12345678u) dst[tid] = 1.0;
+  } else if (mode == 1) {
+    const uint2* s2 = reinterpret_cast<const uint2*>(src);
+    unsigned acc = 0;
+    for (size_t i = tid; i < n / 2; i += stride) { const uint2 v = s2[i]; acc += v.x ^ v.y; }
+    if (acc == 0x12345678u) dst[tid] = 1.0;
+  } else {
+    double a[512];
+    double sum = 0.0;
+    for (int p = 0; p < passes; ++p) {
+#pragma unroll 1
+      for (int k = 0; k < 512; ++k) a[k] = (double)(k + p) + (double)threadIdx.x;
+#pragma unroll 1
+      for (int k = 0; k < 512; ++k) sum += a[(k * 37 + p) & 511];
+    }
+    dst[tid] = sum;
+  }
+}
+}  // namespace crx
+extern "C" int crx_x_fetch_units_dev(int mode, const void* src, size_t bytes, double* dst, int workgroups, int passes, void* stream) {
+  CRX_TRACE();
+  if (mode < 0 || mode > 2 || !dst || workgroups < 1 || (mode < 2 && (!src || bytes % 8)) || (mode == 2 && passes < 1))
+    return fail(CRX_ERR_INVALID, "fetch_units: bad arguments");
+  if (int rc = check_device()) return rc;
+  hipLaunchKernelGGL(crx::fetch_units_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, mode, bytes / 4, (const unsigned*)src, dst, passes);
+  CRX_HIP(hipGetLastError());
+  return CRX_OK;
+}
+
 // The reciprocal of the fused EKF step (csrc/ekf_math.h: recip_fast — v_rcp_f32 and one Newton step) against the compiler's IEEE 1.0f / d
 // on EVERY float of its domain, 2^-60 <= |d| <= 2^60: counts[0] = inputs walked, counts[1] = inputs where recip_fast's two fma differ from
 // 1.0f / d, counts[2] = inputs where the six-fma form of rounds 2-4 does.  The claim rests on this device's v_rcp_f32, so the GPU tests

@@ -24,6 +24,7 @@ _X_SIGNATURES = {
     "crx_x_datan2_sweep_dev": (_I, [C.c_double, _P, _P, _P, _P]),
     "crx_x_dare_from_v_refill_dev": (_I, [_I, _I, _P, C.POINTER(L.LqrParams), _P, _P, _P, _P, _I, _I]),
     "crx_x_hbm_stream_dev": (_I, [_I, _P, _P, C.c_size_t, _I, _P]),
+    "crx_x_fetch_units_dev": (_I, [_I, _P, C.c_size_t, _P, _I, _I, _P]),
     "crx_x_recip_sweep_dev": (_I, [_P, _P]),
     "crx_x_ekf_run_addr64_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
     "crx_x_ekf_run_contracted_dev": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, C.POINTER(L.EkfParams), _P]),
@@ -361,6 +362,12 @@ def hbm_stream(mode, dst, src=None, workgroups=8192):
     nbytes = dst.numel() * dst.element_size()
     L.check(xlib().crx_x_hbm_stream_dev(int(mode), L.ptr(dst), L.ptr(src) if src is not None else None, nbytes, int(workgroups), L.stream_ptr()),
             "crx_x_hbm_stream_dev")
+
+
+def fetch_units(mode, src, dst, workgroups, passes=1):
+    """crx_x_fetch_units_dev: 4-byte (mode 0) / 8-byte (mode 1) per-lane reads of src, or private-memory round trips (mode 2)."""
+    L.check(xlib().crx_x_fetch_units_dev(int(mode), L.ptr(src) if src is not None else None, 0 if src is None else src.numel() * src.element_size(),
+                                         C.c_void_p(dst.data_ptr()), int(workgroups), int(passes), L.stream_ptr()), "crx_x_fetch_units_dev")
 
 
 def closed_loop_prediction_lanes(state, course, goal, lanes_per_agent, dim=5, max_ticks=500, goal_dis=None, dt=0.1, L_wheelbase=0.5, eps=0.01,

@@ -120,6 +120,9 @@ int crx_x_dare_from_v_refill_dev(int n, int dim, const float* v, const crx_lqr_p
  * of the buffer; `workgroups` a multiple of 8); mode 1 / 2 + 16 (+ 8): the read-only / write-only kernel with plain instead of nontemporal accesses.
  * scripts/gpu_hbm_calib.py and bench.py (`extra.hbm_calibration`) time it next to the
  * HBM-bound EKF launches. */
+/* What the FETCH_SIZE / WRITE_SIZE counters count for narrow accesses: mode 0 / 1 read `bytes` of src once, 4 / 8 bytes per lane; mode 2
+ * writes and reads back a private array of 4 KiB per lane `passes` times (dst: one double per launched lane).  csrc/api_probes.inl. */
+int crx_x_fetch_units_dev(int mode, const void* src, size_t bytes, double* dst, int workgroups, int passes, void* stream);
 int crx_x_hbm_stream_dev(int mode, void* dst, const void* src, size_t bytes, int workgroups, void* stream);
 
 /* The fused EKF step's reciprocal (v_rcp_f32 + one Newton step, csrc/ekf_math.h: recip_fast) against the IEEE quotient 1.0f / d on every

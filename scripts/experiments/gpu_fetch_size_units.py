@@ -21,3 +21,14 @@ for mode, wgs in ((1, 65536), (17, 65544), (2, 65552), (18, 65560)):
     hbm_stream(mode, dst, src, workgroups=wgs)
     torch.cuda.synchronize()
 print("bytes per launch", nbytes)
+# round 6: narrow accesses.  Told apart by workgroup count: 32,768 = 4 B per lane, 32,776 = 8 B per lane (each reads the 256 MiB once);
+# 1,024 / 4,096 workgroups of the private-memory probe = 262,144 / 1,048,576 lanes x 4 KiB written and read back, 2 passes each
+from cpprobotics_amd.experimental import fetch_units  # noqa: E402
+out = torch.zeros(4096 * 256, dtype=torch.float64, device="cuda")
+for mode, wgs in ((0, 32768), (1, 32776)):
+    fetch_units(mode, src, out, wgs)
+    torch.cuda.synchronize()
+for wgs in (1024, 4096):
+    fetch_units(2, None, out, wgs, passes=2)
+    torch.cuda.synchronize()
+    print("private probe:", wgs * 256, "lanes x 2 passes x 4096 B =", wgs * 256 * 2 * 4096, "bytes written, as many read back")

@@ -24,6 +24,10 @@ const int DEPTH = 6;
 extern int m, rounds; extern crx_course course;
 extern float *est[DEPTH], *err[DEPTH], *xref[DEPTH], *sol[DEPTH]; extern int *tind[DEPTH], *status[DEPTH]; extern double* cost[DEPTH];
 void gather_every_eighth(float*, const float*, hipStream_t);
+// ... and the C round / multi-GPU snippets (section 5c)
+#include <cstdlib>
+extern crx_course course_dev; extern float *x0_dev, *P0_dev, **z_dev, **ud_dev, *hxEst_dev, *xEst_dev, *all_xEst_dev; extern int rank, world;
+void consume(const float*, const int*, int, void*);
 '''
 
 

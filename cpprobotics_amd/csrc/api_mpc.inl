@@ -186,6 +186,57 @@ int crx_x_mpc_solve_two_phase_dev(int n, int T, const float* x0, const float* xr
   const hipError_t e = crx::mpc_list_launch(n, T, list, count, x0, xref, p, sol, status, cost, tail);
   return e == hipSuccess ? CRX_OK : hip_fail(e, "mpc list launch");
 }
+// The phased solve (mpc_kernels.hip.h: mpc_phase_kernel): caps[0] < caps[1] < ... sweep indices at which the agents still unconverged
+// are suspended, compacted into full waves and resumed.  work: crx_x_mpc_phased_work_bytes(n, T) bytes of device memory (the counter,
+// the list, one state record per agent), owned by the call until the stream has passed it.  T <= 24.
+size_t crx_x_mpc_phased_work_bytes(int n, int T) {
+  if (n < 0 || T < 2) return 0;
+  return 256 + (((size_t)n * 4 + 255) / 256) * 256 + (size_t)n * 8 * (size_t)crx::mpc_phase_record_doubles(T);
+}
+static int mpc_solve_phased(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                            double* cost, const int* caps, int ncaps, void* work, void* stream, int store) {
+  if (n < 0 || T < 2 || T > 24 || ncaps < 0 || ncaps > 16 || (ncaps && !caps) || (n && (!x0 || !xref || !sol || !status || !work)))
+    return fail(CRX_ERR_INVALID, "mpc_solve (phased): bad argument (2 <= T <= 24; status and work are required; at most 16 caps)");
+  for (int k = 0; k < ncaps; ++k)
+    if (caps[k] < 1 || (k && caps[k] <= caps[k - 1])) return fail(CRX_ERR_INVALID, "mpc_solve (phased): caps must be positive and increasing");
+  if (int rc = check_device()) return rc;
+  if (n == 0) return CRX_OK;
+  crx_mpc_params p;
+  if (prm) p = *prm; else crx_mpc_default_params(&p);
+  if (store != 0 && store != 1) return fail(CRX_ERR_INVALID, "mpc_solve (phased): store must be 0 (private memory) or 1 (tile layout)");
+  if (store == 1 && T - 1 > crx::kMpcTileStages) return fail(CRX_ERR_INVALID, "mpc_solve (phased, tile layout): T <= 21");
+  if (store == 0) if (int rc = scratch_stream_admit(stream)) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  int* count = (int*)work;
+  int* list = (int*)((char*)work + 256);
+  double* state = (double*)((char*)work + 256 + (((size_t)n * 4 + 255) / 256) * 256);
+  const bool lean = n >= crx::kMpcLeanFrom || (p.shared_gpu != 0 && n >= crx::kMpcLeanFromShared);
+  int resume = -1;
+  for (int k = 0; k <= ncaps; ++k) {
+    const int cap = (k < ncaps && caps[k] < p.max_iter) ? caps[k] : 0;      // the last phase runs to the solver's own cap
+    if (k > 0) {
+      CRX_HIP(hipMemsetAsync(count, 0, sizeof(int), s));
+      hipLaunchKernelGGL(crx::mpc_collect_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, n, -1, status, list, count);
+      CRX_HIP(hipGetLastError());
+    }
+    const hipError_t e = store == 1 ? crx::mpc_tile_phase_launch(n, T, k ? list : nullptr, count, resume, cap, state, x0, xref, p, sol, status, cost, s)
+                                    : crx::mpc_phase_launch(n, T, k ? list : nullptr, count, resume, cap, state, x0, xref, p, sol, status, cost, s, lean, n);
+    if (e != hipSuccess) return hip_fail(e, "mpc phase launch");
+    if (cap == 0) break;
+    resume = cap;
+  }
+  return CRX_OK;
+}
+int crx_x_mpc_solve_phased_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                               double* cost, const int* caps, int ncaps, void* work, void* stream) {
+  CRX_TRACE();
+  return mpc_solve_phased(n, T, x0, xref, prm, sol, status, cost, caps, ncaps, work, stream, 0);
+}
+int crx_x_mpc_solve_phased_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                     double* cost, const int* caps, int ncaps, void* work, void* stream, int store) {
+  CRX_TRACE();
+  return mpc_solve_phased(n, T, x0, xref, prm, sol, status, cost, caps, ncaps, work, stream, store);
+}
 int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm,
                             float* sol, int* status, double* cost, void* stream) {
   CRX_TRACE();

@@ -281,11 +281,20 @@ constexpr int kMpcTileStages = 20;                     // T <= 21: the BASELINE 
 typedef double mpc_d2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mpc_d2_t lds_double2_t;
 struct MpcTile { lds_double2_t* u; };                  // the wave's [2][kMpcTileStages][64] double2 of LDS: (delta, a) of buffer c, stage i, lane l
-template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false, int STORE = 0>
+// PHASED (round 6; mpc_phase_kernel below): the lockstep solve cut at sweep boundaries.  ph.cap > 0: a lane still sweeping when the
+// wave reaches sweep index ph.cap SUSPENDS — its solver state (J, mu, the Gauss-Newton counters, status, the accepted controls as
+// doubles) goes to ph.st and status_out is kMpcSuspended; ph.resume >= 0: the lane does not start from the zero guess but RESUMES
+// such a record at sweep index ph.resume (the knots, and the stored trig, are re-rolled from the controls: the function of the
+// doubles that produced them, hence their bits).  A suspended-and-resumed agent runs exactly the sweeps of an uninterrupted one.
+constexpr int kMpcSuspended = -1;
+struct MpcPhase { int cap = 0; int resume = -1; double* st = nullptr; };
+__host__ __device__ inline int mpc_phase_record_doubles(int T) { return 6 + 2 * (T - 1); }
+template <int MAXT, bool PORTFOLIO = false, bool REFILL = false, bool LEAN = false, int STORE = 0, bool PHASED = false>
 __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, const float4 xi_in, const float4* __restrict__ xr4_in, const MpcP& p,
                                                float* __restrict__ so_in, int& status_out, double& cost_out, float& a0_out, float& d0_out,
-                                               const MpcFeed feed = MpcFeed{}, const MpcTile tile = MpcTile{}) {
+                                               const MpcFeed feed = MpcFeed{}, const MpcTile tile = MpcTile{}, const MpcPhase ph = MpcPhase{}) {
   static_assert(!(PORTFOLIO && REFILL), "the portfolio runs in the latency regime");
+  static_assert(!PHASED || (!PORTFOLIO && !REFILL && STORE <= 1), "the phased solve is the lockstep solve (private-memory or tile layout), cut at sweep boundaries");
   constexpr bool TILE = STORE >= 1;
   constexpr bool CKPT = STORE == 2;
   static_assert(!TILE || (LEAN && MAXT <= kMpcTileStages + 4), "the tile layout recomputes the trig and holds at most kMpcTileStages stages");
@@ -494,8 +503,24 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
       }
     }
   };
-  if (!REFILL) start();
+  bool resumed = false;
+  if constexpr (PHASED) {
+    if (ph.resume >= 0) {                      // wave-uniform: every lane of a resumed wave was suspended at the same sweep
+      resumed = true;
+      cur = 0;
+      J = ph.st[0]; mu = ph.st[1]; gn_left = (int)ph.st[2]; gn_run = (int)ph.st[3]; status = (int)ph.st[4]; it = ph.resume;
+      S[0][0][0] = S[1][0][0] = (double)xi.x; S[0][0][1] = S[1][0][1] = (double)xi.y;
+      S[0][0][2] = S[1][0][2] = (double)xi.z; S[0][0][3] = S[1][0][3] = (double)xi.w;
+      for (int i = 0; i < N; ++i) {
+        const double ud_ = ph.st[6 + 2 * i], ua_ = ph.st[7 + 2 * i];
+        stU(0, i, ud_, ua_);
+        step(S[0][i], ud_, ua_, S[0][i + 1], LEAN ? TR[0][0] : TR[0][i]);
+      }
+    }
+  }
+  if (!REFILL && !resumed) start();
   bool done = REFILL ? true : !live;
+  bool suspended = false;
   // REFILL bookkeeping: the lane's agent (-1: none; a done lane with an agent holds a finished solve), the trip of the loop below at
   // which that agent started, the wave's cursor into its range, the lanes asking for an agent
   int agent_l = -1, next = feed.lo;
@@ -939,9 +964,19 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   if constexpr (!REFILL) {
     // The latency regime (mpc_kernel, the portfolio, the closed loop): the lanes of a wave sweep in lockstep, a sweep = the backward pass
     // and the whole line search (a Newton step that fails down to alpha = 1/8 is dropped for Gauss-Newton ones: 4 tries, otherwise 10).
-    for (int iter = 0; iter < p.max_iter; ++iter) {
+    for (int iter = (PHASED && resumed) ? ph.resume : 0; iter < p.max_iter; ++iter) {
       if (PORTFOLIO) { if (quad_converged()) done = true; }    // a sibling variant has the answer: every lane of the quad stops
       if (__all(done)) break;
+      if constexpr (PHASED) {
+        if (ph.cap > 0 && iter == ph.cap) {                    // the phase ends here: the lanes still sweeping hand their state over
+          if (!done) {
+            suspended = true;
+            ph.st[0] = J; ph.st[1] = mu; ph.st[2] = (double)gn_left; ph.st[3] = (double)gn_run; ph.st[4] = (double)status; ph.st[5] = 0.0;
+            for (int i = 0; i < N; ++i) { double ud_, ua_; ldU(cur, i, ud_, ua_); ph.st[6 + 2 * i] = ud_; ph.st[7 + 2 * i] = ua_; }
+          }
+          break;
+        }
+      }
       if (done) continue;
       it = iter;
       const bool exact = gn_left <= 0;
@@ -1048,6 +1083,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
     if (live) status |= winner << 2;
   }
   if (!live) return;
+  if constexpr (PHASED) {
+    if (suspended) { status_out = kMpcSuspended; return; }
+  }
   if (!(status & 1) && !done) it = p.max_iter;
   write_solution(so);
   status_out = status | (it << 8);
@@ -1107,7 +1145,7 @@ __global__ void __launch_bounds__(256)
 mpc_collect_kernel(int n, int cap, const int* __restrict__ statusg, int* __restrict__ list, int* __restrict__ count) {
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   bool un = false;
-  if (i < n) { const int st = statusg[i]; un = !(st & 1) && (st >> 8) >= cap; }
+  if (i < n) { const int st = statusg[i]; un = cap < 0 ? st == kMpcSuspended : (!(st & 1) && (st >> 8) >= cap); }   // cap < 0: the phased solve's suspended agents
   const lanemask_t m = lanes_where(un);
   if (!m) return;
   const int lane = threadIdx.x & 63;
@@ -1134,6 +1172,33 @@ mpc_list_kernel(const int* __restrict__ list, const int* __restrict__ count, int
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
+}
+
+// The PHASED solve (round 6; csrc/api_mpc.inl: crx_x_mpc_solve_phased_dev).  A lockstep wave runs as many sweeps as the slowest of its 64
+// agents — 11.9 on average on the configs[3] distribution against a mean of 6.8 per agent: 43 % of the lane-sweeps are masked off.
+// Here the batch is swept in PHASES: phase k runs every agent still unconverged up to sweep index caps[k]; the agents that reach the
+// cap suspend (MpcPhase), are compacted into full waves (mpc_collect_kernel on status == kMpcSuspended) and resumed by the next
+// phase's launch.  Per agent the same sweeps in the same order on the same doubles: bit-identical outputs.  list == nullptr: phase 0
+// (agent = wave * 64 + lane, start from the zero guess).
+template <int MAXT, bool LEAN>
+__global__ void __launch_bounds__(64)
+mpc_phase_kernel(int n, const int* __restrict__ list, const int* __restrict__ count, int T, int resume, int cap, double* __restrict__ state,
+                 const float* __restrict__ x0g, const float* __restrict__ xrefg, MpcP p, float* __restrict__ solg, int* __restrict__ statusg,
+                 double* __restrict__ costg) {
+  const int cnt = list ? *count : n;
+  const int entry = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if ((int)blockIdx.x * 64 >= cnt) return;
+  const bool live = entry < cnt;
+  const size_t agent = live ? (size_t)(list ? list[entry] : entry) : (size_t)(list ? list[0] : 0);
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(xrefg) + agent * (size_t)T;
+  const float4 xi = reinterpret_cast<const float4*>(x0g)[agent];
+  const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, false, false, LEAN, 0, true>(live, T, xi, xr4, p, live ? solg + agent * nv : nullptr, status, J, a0, d0, MpcFeed{}, MpcTile{},
+                                                    MpcPhase{cap, resume, state + agent * (size_t)mpc_phase_record_doubles(T)});
+  if (!live) return;
+  statusg[agent] = status;                       // kMpcSuspended for the agents the next phase resumes
+  if (status != kMpcSuspended && costg) costg[agent] = J;
 }
 
 // The lane-refilling launch: wave w owns the agents [w * chunk, (w + 1) * chunk) and refills its lanes (mpc_solve_lane<.., REFILL>): a wave
@@ -1200,6 +1265,16 @@ inline hipError_t mpc_portfolio_launch(int n, int T, const float* x0, const floa
   return hipGetLastError();
 }
 
+inline hipError_t mpc_phase_launch(int n, int T, const int* list, const int* count, int resume, int cap, double* state, const float* x0,
+                                   const float* xref, const crx_mpc_params& q, float* sol, int* status, double* cost, hipStream_t stream, bool lean,
+                                   int grid_agents) {
+  const MpcP p = mpc_pack(q);
+  const dim3 grid((unsigned)(((size_t)grid_agents + 63) / 64)), block(64);
+  if (T > 24) return hipErrorInvalidValue;
+  if (lean) hipLaunchKernelGGL((mpc_phase_kernel<24, true>), grid, block, 0, stream, n, list, count, T, resume, cap, state, x0, xref, p, sol, status, cost);
+  else hipLaunchKernelGGL((mpc_phase_kernel<24, false>), grid, block, 0, stream, n, list, count, T, resume, cap, state, x0, xref, p, sol, status, cost);
+  return hipGetLastError();
+}
 // phase 2 of the two-phase solve: n = the size of the batch the list was collected from (the grid's worst case)
 inline hipError_t mpc_list_launch(int n, int T, const int* list, const int* count, const float* x0, const float* xref, const crx_mpc_params& q,
                                   float* sol, int* status, double* cost, hipStream_t stream) {

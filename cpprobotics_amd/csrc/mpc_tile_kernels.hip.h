@@ -39,6 +39,9 @@ struct MpcTileArgs {
   const float* x0g; const float* xrefg;
   MpcP p;
   float* solg; int* statusg; double* costg;
+  // the phased launch (mpc_kernels.hip.h: MpcPhase): the agents of this phase (list == nullptr: all n, from the zero guess), the sweep
+  // index they resume at / suspend at, the state records
+  const int* list; const int* count; int resume, cap; double* state;
 };
 
 #ifdef CRX_MPC_TILE_MODULE     // ---- device side: compiled by mpc_tile_module.hip only ----------------------------------------------
@@ -64,6 +67,29 @@ __device__ __forceinline__ void mpc_tile_body(const MpcTileArgs& a) {
   if (!live) return;
   if (statusg) statusg[agent] = status;
   if (costg) costg[agent] = J;
+}
+
+// the tile layout in PHASES (mpc_phase_kernel's twin): entries [64 w, 64 w + 64) of the phase's list on wave w
+template <int MAXT>
+__device__ __forceinline__ void mpc_tile_phase_body(const MpcTileArgs& a) {
+  __shared__ mpc_d2_t tile_u[2 * kMpcTileStages * 64];
+  mpc_agpr_reserve();
+  const int T = a.T;
+  const int cnt = a.list ? *a.count : a.n;
+  const int entry = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if ((int)blockIdx.x * 64 >= cnt) return;
+  const bool live = entry < cnt;
+  const size_t agent = live ? (size_t)(a.list ? a.list[entry] : entry) : (size_t)(a.list ? a.list[0] : 0);
+  const float4* __restrict__ xr4 = reinterpret_cast<const float4*>(a.xrefg) + agent * (size_t)T;
+  const float4 xi = reinterpret_cast<const float4*>(a.x0g)[agent];
+  const size_t nv = 4 * (size_t)T + 2 * ((size_t)T - 1);
+  int status; double J; float a0, d0;
+  mpc_solve_lane<MAXT, false, false, true, 1, true>(live, T, xi, xr4, a.p, live ? a.solg + agent * nv : nullptr, status, J, a0, d0, MpcFeed{},
+                                                    MpcTile{(lds_double2_t*)tile_u},
+                                                    MpcPhase{a.cap, a.resume, a.state + agent * (size_t)mpc_phase_record_doubles(T)});
+  if (!live) return;
+  a.statusg[agent] = status;
+  if (status != kMpcSuspended && a.costg) a.costg[agent] = J;
 }
 
 // The tile layout with the lanes REFILLED (mpc_solve_lane<.., REFILL, .., STORE>): wave w owns the agents [w * chunk, (w + 1) * chunk);
@@ -98,7 +124,7 @@ inline int mpc_tile_refill_chunk(int n) {
 // the embedded code object (csrc/Makefile: mpc_tile_hsaco.inc) and its kernels, loaded once per device
 extern "C" __attribute__((section(".crx_tile_hsaco"))) const unsigned char crx_tile_hsaco[];
 extern "C" const unsigned int crx_tile_hsaco_len;
-enum { kTileLockstep1 = 0, kTileLockstep2, kTileRefill1, kTileRefill2, kTileKernels };
+enum { kTileLockstep1 = 0, kTileLockstep2, kTileRefill1, kTileRefill2, kTilePhase1, kTileKernels };
 struct MpcTileModule { hipModule_t mod = nullptr; hipFunction_t fn[kTileKernels] = {}; hipError_t err = hipSuccess; bool tried = false; };
 inline hipError_t mpc_tile_function(int which, hipFunction_t* out) {
   static std::mutex mu;
@@ -112,7 +138,7 @@ inline hipError_t mpc_tile_function(int which, hipFunction_t* out) {
   if (!m.tried) {
     m.tried = true;
     static const char* const names[kTileKernels] = {"crx_mpc_tile_kernel_s1", "crx_mpc_tile_kernel_s2", "crx_mpc_tile_refill_kernel_s1",
-                                                    "crx_mpc_tile_refill_kernel_s2"};
+                                                    "crx_mpc_tile_refill_kernel_s2", "crx_mpc_tile_phase_kernel_s1"};
     m.err = hipModuleLoadData(&m.mod, crx_tile_hsaco);
     for (int k = 0; k < kTileKernels && m.err == hipSuccess; ++k) m.err = hipModuleGetFunction(&m.fn[k], m.mod, names[k]);
   }
@@ -131,7 +157,7 @@ inline hipError_t mpc_tile_module_launch(int which, unsigned grid, MpcTileArgs a
 
 inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                          int* status, double* cost, hipStream_t stream, int chunk, int hold, int store = 1) {
-  const MpcTileArgs args{n, T, chunk, hold, x0, xref, mpc_pack(q), sol, status, cost};
+  const MpcTileArgs args{n, T, chunk, hold, x0, xref, mpc_pack(q), sol, status, cost, nullptr, nullptr, -1, 0, nullptr};
   return mpc_tile_module_launch(store == 2 ? kTileRefill2 : kTileRefill1, (unsigned)(((size_t)n + chunk - 1) / chunk), args, stream);
 }
 
@@ -139,8 +165,14 @@ inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const fl
 // short loops) needs more accumulator registers of its own than the block leaves free.
 inline hipError_t mpc_tile_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                   int* status, double* cost, hipStream_t stream, int store = 1) {
-  const MpcTileArgs args{n, T, 0, 0, x0, xref, mpc_pack(q), sol, status, cost};
+  const MpcTileArgs args{n, T, 0, 0, x0, xref, mpc_pack(q), sol, status, cost, nullptr, nullptr, -1, 0, nullptr};
   return mpc_tile_module_launch(store == 2 ? kTileLockstep2 : kTileLockstep1, (unsigned)(((size_t)n + 63) / 64), args, stream);
+}
+
+inline hipError_t mpc_tile_phase_launch(int n, int T, const int* list, const int* count, int resume, int cap, double* state, const float* x0,
+                                        const float* xref, const crx_mpc_params& q, float* sol, int* status, double* cost, hipStream_t stream) {
+  const MpcTileArgs args{n, T, 0, 0, x0, xref, mpc_pack(q), sol, status, cost, list, count, resume, cap, state};
+  return mpc_tile_module_launch(kTilePhase1, (unsigned)(((size_t)n + 63) / 64), args, stream);
 }
 
 #endif

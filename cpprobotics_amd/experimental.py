@@ -12,6 +12,9 @@ _X_SIGNATURES = {
     "crx_x_mpc_solve_trig_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I]),
     "crx_x_mpc_solve_tile_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
+    "crx_x_mpc_phased_work_bytes": (C.c_size_t, [_I, _I]),
+    "crx_x_mpc_solve_phased_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _P, _P]),
+    "crx_x_mpc_solve_phased_store_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _P, _P, _I]),
     "crx_x_mpc_solve_two_phase_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _I, _P, _P, _P]),
     "crx_x_mpc_solve_store_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I, _I]),
     "crx_x_mpc_solve_refill_dev": (_I, [_I, _I, _P, _P, C.POINTER(L.MpcParams), _P, _P, _P, _P, _I, _I]),
@@ -278,6 +281,31 @@ def mpc_solve_two_phase(x0, xref, T, first_sweeps, params=None, out=None, work=N
     tail = C.c_void_p(tail_stream.cuda_stream) if tail_stream is not None else L.stream_ptr()
     L.check(xlib().crx_x_mpc_solve_two_phase_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost),
                                                 int(first_sweeps), L.ptr(work), L.stream_ptr(), tail), "crx_x_mpc_solve_two_phase_dev")
+    return sol, status, cost, work
+
+
+def mpc_solve_phased(x0, xref, T, caps, params=None, out=None, work=None, store=0):
+    """crx_x_mpc_solve_phased_dev: the lockstep solve cut at the sweep indices `caps`, unconverged agents compacted into full waves between
+    the phases.  Bit for bit mpc_solve's answers.  -> (sol, status, cost, work); work: uint8 [crx_x_mpc_phased_work_bytes], reusable."""
+    import torch
+    from .mpc import default_params, mpc_n_vars
+    L.require_cuda(x0, xref)
+    n = x0.shape[0]
+    L.expect("x0", x0, "f", n, 4); L.expect("xref", xref, "f", n, 4 * T)
+    p = params if params is not None else default_params()
+    if out is not None:
+        sol, status, cost = out
+    else:
+        sol = torch.empty((n, mpc_n_vars(T)), dtype=torch.float32, device=x0.device)
+        status = torch.empty((n,), dtype=torch.int32, device=x0.device)
+        cost = torch.empty((n,), dtype=torch.float64, device=x0.device)
+    nbytes = xlib().crx_x_mpc_phased_work_bytes(n, T)
+    if work is None:
+        work = torch.empty((nbytes,), dtype=torch.uint8, device=x0.device)
+    assert work.numel() >= nbytes and work.is_contiguous()
+    arr = (C.c_int * len(caps))(*[int(c) for c in caps])
+    L.check(xlib().crx_x_mpc_solve_phased_store_dev(n, T, L.ptr(x0), L.ptr(xref), C.byref(p), L.ptr(sol), L.ptr(status), L.ptr(cost), arr, len(caps),
+                                                    C.c_void_p(work.data_ptr()), L.stream_ptr(), int(store)), "crx_x_mpc_solve_phased_store_dev")
     return sol, status, cost, work
 
 

@@ -63,6 +63,19 @@ int crx_x_mpc_solve_store_refill_dev(int n, int T, const float* x0, const float*
 int crx_x_mpc_solve_two_phase_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                                   double* cost, int first_sweeps, int* work, void* stream, void* tail_stream);
 
+/* crx_mpc_solve_batch_dev in PHASES (round 6): every agent still unconverged is swept up to sweep index caps[0]; the ones that get there
+ * are suspended (their solver state saved), compacted into full waves and resumed up to caps[1], and so on; after the last cap to the
+ * solver's own.  Per agent the same sweeps on the same doubles: bit for bit crx_mpc_solve_batch_dev's outputs.  A lockstep wave runs
+ * as many sweeps as the slowest of its 64 agents (11.9 on average against a mean of 6.8); compaction takes most of that back.
+ * status required; work: crx_x_mpc_phased_work_bytes(n, T) bytes of device memory; T <= 24. */
+size_t crx_x_mpc_phased_work_bytes(int n, int T);
+int crx_x_mpc_solve_phased_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                               double* cost, const int* caps, int ncaps, void* work, void* stream);
+
+/* ... with the layout of the lane's working set chosen: store 0 private memory, 1 the tile layout (T <= 21). */
+int crx_x_mpc_solve_phased_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
+                                     double* cost, const int* caps, int ncaps, void* work, void* stream, int store);
+
 /* crx_mpc_solve_batch_dev with the launch geometry forced: agents_per_wave in 1..64 (the low lanes of every wave), 1..4 waves per
  * workgroup.  The product entry point uses 64 and 1. */
 int crx_x_mpc_solve_geometry_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,

@@ -18,7 +18,9 @@ from cpprobotics_amd.mpc import mpc_n_vars
 sizes = [int(a) for a in sys.argv[1:]] or [8192, 16384, 65536, 262144, 1048576]
 dev = torch.device("cuda", 0)
 T = 21
+pw = None
 for n in sizes:
+    pw = None
     # the configs[3] distribution at this size, NOT a tiled copy of a smaller draw: the largest draws hold the rare agents that need
     # the full 50 sweeps, and those set the tail of a launch whose lanes are refilled
     hx0, hxref = mpc_problem(n, T, 4)
@@ -37,6 +39,14 @@ for n in sizes:
     wk = torch.empty(n + 64, dtype=torch.int32, device=dev)
     for K in (8, 9, 10, 12):
         variants.append((f"two_phase_{K}", (lambda k: (lambda: mpc_solve_two_phase(x0, xref, T, k, out=out, work=wk)))(K)))
+    from cpprobotics_amd.experimental import mpc_solve_phased
+    pw = None
+    for st in (0, 1):
+        for caps in ((6, 8, 10, 13), (7, 10), (6, 9, 12), (6, 7, 8, 9, 10, 12, 16)) + (((5, 6, 7, 8, 9, 10, 11, 12, 14, 17, 22, 30), (6, 8, 10, 13, 20, 30), (8,), (8, 12)) if st else ()):
+            def f(c=caps, q=st):
+                global pw
+                pw = mpc_solve_phased(x0, xref, T, c, out=out, work=pw, store=q)[3]
+            variants.append((("phased_" if st == 0 else "phased_tile_") + "_".join(str(c) for c in caps), f))
     if n >= 65536:
         for apw, hold in ((n // 1024, 16), (n // 2048, 16), (max(64, n // 4096), 32)):
             if apw >= 128:

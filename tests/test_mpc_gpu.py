@@ -444,3 +444,36 @@ def test_two_phase_solve_on_the_speed_bound_problems(crx):
         b = mpc_solve_two_phase(x0, xref, 21, 6)
         torch.cuda.synchronize()
         assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+@pytest.mark.parametrize("n,T,seed,caps", [(8192, 21, 4, (6, 8, 10, 13)), (8192, 21, 7, (1,)), (16384, 21, 7, (5, 6, 7, 8, 9, 10, 12, 16, 30)), (1000, 6, 3, (2, 4)),
+                                           (140000, 21, 11, (6, 9)), (777, 13, 9, (3, 49)), (4096, 21, 5, (50,)), (4096, 21, 5, ()), (300, 2, 1, (2,))])
+@pytest.mark.parametrize("store", [0, 1])
+def test_phased_solve_gives_the_same_bits(crx, n, T, seed, caps, store):
+    """crx_x_mpc_solve_phased_dev: the lockstep solve suspended at the sweep indices `caps`, the unconverged agents compacted into full
+    waves and resumed from their saved state (J, mu, the Gauss-Newton counters, the controls as doubles; knots re-rolled).  A
+    suspended-and-resumed agent runs the sweeps of an uninterrupted one: status (sweep counts included), every solution float and the
+    double cost equal crx_mpc_solve_batch_dev's bit for bit — for one cut, many cuts, a cut at every early sweep, cuts past the cap."""
+    import torch
+    from cpprobotics_amd.experimental import mpc_solve_phased
+    x0, xref = mpc_problem(n, T, seed)
+    x0, xref = _t(x0), _t(xref)
+    a = crx.mpc_solve(x0, xref, T, return_status=True)
+    b = mpc_solve_phased(x0, xref, T, caps, store=store)
+    torch.cuda.synchronize()
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+    assert torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))
+
+
+def test_phased_solve_on_the_speed_bound_problems(crx):
+    import torch
+    from common import speed_bound_problems
+    from cpprobotics_amd.experimental import mpc_solve_phased
+    for fast in (False, True):
+        x0, xref = speed_bound_problems(512, 21, 5, fast=fast)
+        x0, xref = _t(x0), _t(xref)
+        a = crx.mpc_solve(x0, xref, 21, return_status=True)
+        b = mpc_solve_phased(x0, xref, 21, (3, 6, 10))
+        torch.cuda.synchronize()
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)) and torch.equal(a[2].view(torch.int64), b[2].view(torch.int64))

@@ -12,8 +12,8 @@ extern "C" {
 // HSA_STATUS_ERROR_OUT_OF_RESOURCES whatever the batch size (profiles/r05/scratch_queues_probe.jsonl) — an abort no caller of a C
 // function expects.  The library therefore counts the distinct (device, stream) pairs the private-memory solver has been launched
 // on and refuses the 13th with CRX_ERR_INVALID instead.  Streams are counted, not hardware queues (the runtime
-// does not say which queue a stream lands on): conservative when several streams share a queue.  The tile kernel
-// (mpc_tile_kernels.hip.h) has no private memory and is not counted.
+// does not say which queue a stream lands on): conservative when several streams share a queue.  The tile kernels
+// (mpc_tile_kernels.hip.h: 1.9 KB of private memory per lane instead of 3.8-5) pass the probe on 32 streams and are not counted.
 static const int kMaxPrivateMemoryStreams = 12;
 static int scratch_stream_admit(void* stream) {
   static std::mutex mu;
@@ -100,15 +100,16 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
     return fail(CRX_ERR_INVALID, "mpc_solve: lanes_per_agent must be 0 (auto), 1 or 4");
   // the product's choice (round 6): one lane per agent, lockstep sweeps, everywhere; from kMpcTileFrom agents on — the throughput regime,
   // where the private-memory kernel is bound by the HBM traffic of its own scratch — the TILE layout (controls in LDS, feedback gains in
-  // accumulator registers: 82 -> 43 KB of HBM traffic per solve): 131,072 agents 3.80 -> 3.41 ms, 262,144 6.72 -> 5.88, 524,288 9.89 ->
-  // 8.51, 1 M 17.2 -> 14.4 = 73 M solves/s (profiles/r06/mpc_store_ab.jsonl; bit-identical per agent).  Not below: a launch that leaves
+  // accumulator registers: 82 -> 43 KB of HBM traffic per solve): 131,072 agents 3.72 -> 3.41 ms, 262,144 6.1-6.3 -> 5.7, 524,288 9.9 ->
+  // 8.6, 1 M 17.3-17.7 -> 14.7 = 71 M solves/s (profiles/r06/mpc_store_ab*.jsonl; bit-identical per agent).  Not below: a launch that leaves
   // SIMDs idle is a latency chain, where the tile kernel's register switch costs 15 % (8,192 agents 1.18 -> 1.33 ms).  Not for a caller
   // whose launches share the GPU (crx_mpc_params.shared_gpu — configs[4]): a tile wave owns all 512 registers of its SIMD, the
   // private-memory wave (256 + ~31) leaves room for an EKF wave beside it, and the round is 0.50 ms with it against 0.85
   // (profiles/r06/swarm_store_ab.jsonl).  The tile layout with REFILLED lanes (crx_x_mpc_solve_tile_refill_dev) is 1.57x the
   // private-memory kernel at 1 M agents on a distribution without stragglers and 1.25x / 0.98x / 1.24x at 1 M / 524 k / 262 k on the
   // configs[3] distribution, whose few agents at the 50-sweep cap — each a 2 ms chain started whenever its wave reaches it — set the
-  // launch's tail: measured, kept as an entry point, not selected.  (The quad variant lost its A/B at every batch size,
+  // launch's tail; the PHASED solve on the tile layout (crx_x_mpc_solve_phased_store_dev) 13.7 ms at 1 M against 14.7: both measured,
+  // kept as entry points, not selected (three schedulers within 2 % of each other).  (The quad variant lost its A/B at every batch size,
   // profiles/r03/mpc_lanes_ab.txt.)
   if (lanes_per_agent == 0) {
     const bool shared = prm && prm->shared_gpu != 0;

@@ -275,8 +275,11 @@ constexpr int kMpcLeanFromShared = 16384;
 //          accepted controls once to restore it;
 //        * the backward sweep takes the stages in pairs: the odd knot 2m+1 is one model step from the even knot 2m, and the trig that
 //          step needs is the trig stage 2m needs anyway (LEAN recomputes it) — the odd knots cost four fused multiply-adds each.
-//      Private memory left: 10 knots + 20 feed-forward steps + stage 19's gains = 688 B per lane (3.8 KB in STORE 0, 1.9 KB in STORE 1).
-//      Again the same operations on the same doubles in the same order: bit-identical outputs.
+//      Private memory left: 10 knots + 20 feed-forward steps = 656 B per lane (3.8 KB in STORE 0, 1.9 KB in STORE 1) + what the fenced
+//      register allocator spills (~100 registers).  Again the same operations on the same doubles in the same order: bit-identical
+//      outputs.  MEASURED AND NOT SELECTED: 0.70-0.77x of STORE 1 at every batch size (1 M agents 14.7 -> 21.1 ms) — the second
+//      sincos / tan per rollout stage and the spills cost more than the traffic saved, the tile kernel not being bandwidth-bound
+//      (profiles/r06/mpc_store_ab*.jsonl: `tile2`).  Reachable through crx_x_mpc_solve_store_dev(store = 2).
 constexpr int kMpcTileStages = 20;                     // T <= 21: the BASELINE horizon (configs[3], configs[4]) and the reference's own T 6
 typedef double mpc_d2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) mpc_d2_t lds_double2_t;

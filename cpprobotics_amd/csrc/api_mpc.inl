@@ -109,7 +109,7 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   // private-memory kernel at 1 M agents on a distribution without stragglers and 1.25x / 0.98x / 1.24x at 1 M / 524 k / 262 k on the
   // configs[3] distribution, whose few agents at the 50-sweep cap — each a 2 ms chain started whenever its wave reaches it — set the
   // launch's tail; the PHASED solve on the tile layout (crx_x_mpc_solve_phased_store_dev) 13.7 ms at 1 M against 14.7: both measured,
-  // kept as entry points, not selected (three schedulers within 2 % of each other).  (The quad variant lost its A/B at every batch size,
+  // kept as entry points, not selected (the two compacting schedulers within 1 % of each other, 7 % ahead).  (The quad variant lost its A/B at every batch size,
   // profiles/r03/mpc_lanes_ab.txt.)
   if (lanes_per_agent == 0) {
     const bool shared = prm && prm->shared_gpu != 0;

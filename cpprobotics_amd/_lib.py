@@ -254,7 +254,7 @@ def host_floats(values, n):
 KERNEL_FAMILIES = {
     "ekf": ("ekf_run_kernel",),
     "side": ("dare_", "mpc_kernel", "mpc_portfolio_kernel", "ekf_step_kernel", "lqr_closed_loop"),
-    "mpc": ("mpc_kernel", "mpc_tile_kernel", "mpc_tile_refill_kernel"),
+    "mpc": ("mpc_kernel", "mpc_tile_kernel", "mpc_tile_refill_kernel", "mpc_tile_lite_kernel"),
 }
 
 

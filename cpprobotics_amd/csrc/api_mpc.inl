@@ -111,10 +111,17 @@ static int mpc_solve_lanes(int n, int T, const float* x0, const float* xref, con
   // launch's tail; the PHASED solve on the tile layout (crx_x_mpc_solve_phased_store_dev) 13.7 ms at 1 M against 14.7: both measured,
   // kept as entry points, not selected (the two compacting schedulers within 1 % of each other, 7 % ahead).  (The quad variant lost its A/B at every batch size,
   // profiles/r03/mpc_lanes_ab.txt.)
+  // The LITE tile layout (store 3: controls in LDS, the gains of stages 1 .. 7 in a40 .. a123 — a 384-register wave, which leaves a
+  // 128-register wave of another kernel room on the SIMD): between the two — 49,152 agents 1.70 -> 1.55 ms, 65,536 2.60 -> 2.45, 98,304
+  // 3.06 -> 2.98 against the private-memory kernel, level with the full tile layout at 131,072 - 262,144 and 1-3 % behind it beyond
+  // (profiles/r06/mpc_store_ab_lite*.jsonl) — and the one tile form a caller whose launches share the GPU can use: configs[4]'s round
+  // 0.475 -> 0.456 ms at depth 6, 0.447 -> 0.439 at depth 7 (profiles/r06/swarm_store_ab_lite_depth*.jsonl).
   if (lanes_per_agent == 0) {
     const bool shared = prm && prm->shared_gpu != 0;
-    if (n >= crx::kMpcTileFrom && T - 1 <= crx::kMpcTileStages && !shared)
-      return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream);
+    if (T - 1 <= crx::kMpcTileStages) {
+      if (n >= crx::kMpcTileFrom && !shared) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream);
+      if (n >= (shared ? crx::kMpcTileLiteFromShared : crx::kMpcTileLiteFrom)) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream, 3);
+    }
     lanes_per_agent = 1;
   }
   if (lanes_per_agent == 1) return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
@@ -247,8 +254,8 @@ int crx_mpc_solve_batch_dev(int n, int T, const float* x0, const float* xref, co
 int crx_x_mpc_solve_store_dev(int n, int T, const float* x0, const float* xref, const crx_mpc_params* prm, float* sol, int* status,
                               double* cost, void* stream, int store) {
   CRX_TRACE();
-  if (store == 1 || store == 2) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream, store);
-  if (store != 0) return fail(CRX_ERR_INVALID, "mpc_solve (store): store must be 0 (private memory), 1 (tile layout) or 2 (checkpointed tile layout)");
+  if (store >= 1 && store <= 3) return mpc_solve_tile(n, T, x0, xref, prm, sol, status, cost, stream, store);
+  if (store != 0) return fail(CRX_ERR_INVALID, "mpc_solve (store): store must be 0 (private memory), 1 (tile layout), 2 (checkpointed tile layout) or 3 (lite tile layout)");
   return mpc_solve_launch(n, T, x0, xref, prm, sol, status, cost, stream, 64, 1);
 }
 // mpc_solve for n agents with the four-variant portfolio (mpc_kernels.hip.h: mpc_variant): the same NLP, every agent answered by the

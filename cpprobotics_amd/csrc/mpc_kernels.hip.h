@@ -300,6 +300,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   static_assert(!PHASED || (!PORTFOLIO && !REFILL && STORE <= 1), "the phased solve is the lockstep solve (private-memory or tile layout), cut at sweep boundaries");
   constexpr bool TILE = STORE >= 1;
   constexpr bool CKPT = STORE == 2;
+  // gain slots in accumulator registers: 18 (a40 .. a255) — or 7 (a40 .. a123) in the LITE tile layout (STORE = 3), whose wave then
+  // takes 384 of its SIMD's 512 registers and leaves room for a 128-register wave of another kernel beside it
+  constexpr int kSlots = STORE == 3 ? CRX_MPC_AGPR_SLOTS_LITE : CRX_MPC_AGPR_SLOTS;
   static_assert(!TILE || (LEAN && MAXT <= kMpcTileStages + 4), "the tile layout recomputes the trig and holds at most kMpcTileStages stages");
   bool live = live_in;
   float4 xi = xi_in;
@@ -318,7 +321,7 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   // (u + alpha k + K dx), the fixed point is decided by the feed-forward k (double) alone, and they are 41 % of the solver's memory
   // traffic as doubles.  The twin rounds them the same way (oracle/mpc_ref.cpp); on 4 x 8,192 problems the sweep counts of 2 agents move by
   // one and no float of any solution by more than one ulp (profiles/r05/mpc_experiments.txt).
-  float Kf[TILE ? (kMpcTileStages > CRX_MPC_AGPR_SLOTS + 1 ? kMpcTileStages - CRX_MPC_AGPR_SLOTS - 1 : 1) : MAXT][12];   // (TILE: stages 1 .. 18 in accumulator registers)
+  float Kf[TILE ? (kMpcTileStages > kSlots + 1 ? kMpcTileStages - kSlots - 1 : 1) : MAXT][12];   // (TILE: stages 1 .. kSlots in accumulator registers)
   // ---- accessors of the controls and the gains (the only places that know where they live) --------------------------------------
   const int tile_lane = (int)(threadIdx.x & 63);
   auto ldU = [&](int c, int i, double& d, double& a) {
@@ -331,9 +334,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   };
   auto stKf = [&](int i, const float (&g)[12]) {        // i: wave-uniform (the stage loops run in lockstep)
     if constexpr (TILE) {
-      if (i > CRX_MPC_AGPR_SLOTS) {
+      if (i > kSlots) {
 #pragma unroll
-        for (int a = 0; a < 12; ++a) Kf[i - CRX_MPC_AGPR_SLOTS - 1][a] = g[a];
+        for (int a = 0; a < 12; ++a) Kf[i - kSlots - 1][a] = g[a];
       } else if (i >= 1) mpc_agpr_store12(i - 1, g);
     } else {
 #pragma unroll
@@ -342,9 +345,9 @@ __device__ __forceinline__ void mpc_solve_lane(const bool live_in, const int T, 
   };
   auto ldKf = [&](int i, float (&g)[12]) {
     if constexpr (TILE) {
-      if (i > CRX_MPC_AGPR_SLOTS) {
+      if (i > kSlots) {
 #pragma unroll
-        for (int a = 0; a < 12; ++a) g[a] = Kf[i - CRX_MPC_AGPR_SLOTS - 1][a];
+        for (int a = 0; a < 12; ++a) g[a] = Kf[i - kSlots - 1][a];
       } else mpc_agpr_load12(i - 1, g);                 // stage 0 (slot -1): zeros — its gains multiply dx = 0
     } else {
 #pragma unroll

@@ -51,7 +51,7 @@ struct MpcTileArgs {
 template <int MAXT, int STORE>
 __device__ __forceinline__ void mpc_tile_body(const MpcTileArgs& a) {
   __shared__ mpc_d2_t tile_u[2 * kMpcTileStages * 64];          // 40,960 B
-  mpc_agpr_reserve();
+  if constexpr (STORE == 3) mpc_agpr_reserve_lite(); else mpc_agpr_reserve();
   const int n = a.n, T = a.T;
   const float* __restrict__ x0g = a.x0g; const float* __restrict__ xrefg = a.xrefg;
   float* __restrict__ solg = a.solg; int* __restrict__ statusg = a.statusg; double* __restrict__ costg = a.costg;
@@ -115,6 +115,9 @@ __device__ __forceinline__ void mpc_tile_refill_body(const MpcTileArgs& a) {
 
 // crx_mpc_solve_batch_dev takes the tile layout from this many agents on (csrc/api_mpc.inl has the numbers)
 constexpr int kMpcTileFrom = 131072;
+// ... and the LITE tile layout (mpc_kernels.hip.h: STORE = 3) from this many; from this many when the caller's launches share the GPU
+constexpr int kMpcTileLiteFrom = 49152;
+constexpr int kMpcTileLiteFromShared = 16384;
 // a geometry for the refilled launch: as many waves as the chip has SIMDs (one persistent wave each), at least 128 agents per wave
 inline int mpc_tile_refill_chunk(int n) {
   const int c = (n + 1023) / 1024;
@@ -124,7 +127,7 @@ inline int mpc_tile_refill_chunk(int n) {
 // the embedded code object (csrc/Makefile: mpc_tile_hsaco.inc) and its kernels, loaded once per device
 extern "C" __attribute__((section(".crx_tile_hsaco"))) const unsigned char crx_tile_hsaco[];
 extern "C" const unsigned int crx_tile_hsaco_len;
-enum { kTileLockstep1 = 0, kTileLockstep2, kTileRefill1, kTileRefill2, kTilePhase1, kTileKernels };
+enum { kTileLockstep1 = 0, kTileLockstep2, kTileRefill1, kTileRefill2, kTilePhase1, kTileLite, kTileKernels };
 struct MpcTileModule { hipModule_t mod = nullptr; hipFunction_t fn[kTileKernels] = {}; hipError_t err = hipSuccess; bool tried = false; };
 inline hipError_t mpc_tile_function(int which, hipFunction_t* out) {
   static std::mutex mu;
@@ -138,7 +141,7 @@ inline hipError_t mpc_tile_function(int which, hipFunction_t* out) {
   if (!m.tried) {
     m.tried = true;
     static const char* const names[kTileKernels] = {"crx_mpc_tile_kernel_s1", "crx_mpc_tile_kernel_s2", "crx_mpc_tile_refill_kernel_s1",
-                                                    "crx_mpc_tile_refill_kernel_s2", "crx_mpc_tile_phase_kernel_s1"};
+                                                    "crx_mpc_tile_refill_kernel_s2", "crx_mpc_tile_phase_kernel_s1", "crx_mpc_tile_lite_kernel"};
     m.err = hipModuleLoadData(&m.mod, crx_tile_hsaco);
     for (int k = 0; k < kTileKernels && m.err == hipSuccess; ++k) m.err = hipModuleGetFunction(&m.fn[k], m.mod, names[k]);
   }
@@ -166,7 +169,7 @@ inline hipError_t mpc_tile_refill_launch(int n, int T, const float* x0, const fl
 inline hipError_t mpc_tile_launch(int n, int T, const float* x0, const float* xref, const crx_mpc_params& q, float* sol,
                                   int* status, double* cost, hipStream_t stream, int store = 1) {
   const MpcTileArgs args{n, T, 0, 0, x0, xref, mpc_pack(q), sol, status, cost, nullptr, nullptr, -1, 0, nullptr};
-  return mpc_tile_module_launch(store == 2 ? kTileLockstep2 : kTileLockstep1, (unsigned)(((size_t)n + 63) / 64), args, stream);
+  return mpc_tile_module_launch(store == 2 ? kTileLockstep2 : (store == 3 ? kTileLite : kTileLockstep1), (unsigned)(((size_t)n + 63) / 64), args, stream);
 }
 
 inline hipError_t mpc_tile_phase_launch(int n, int T, const int* list, const int* count, int resume, int cap, double* state, const float* x0,

@@ -10,3 +10,4 @@ extern "C" __global__ void __launch_bounds__(64) crx_mpc_tile_kernel_s2(const cr
 extern "C" __global__ void __launch_bounds__(64) crx_mpc_tile_refill_kernel_s1(const crx::MpcTileArgs a) { crx::mpc_tile_refill_body<24, 1>(a); }
 extern "C" __global__ void __launch_bounds__(64) crx_mpc_tile_refill_kernel_s2(const crx::MpcTileArgs a) { crx::mpc_tile_refill_body<24, 2>(a); }
 extern "C" __global__ void __launch_bounds__(64) crx_mpc_tile_phase_kernel_s1(const crx::MpcTileArgs a) { crx::mpc_tile_phase_body<24>(a); }
+extern "C" __global__ void __launch_bounds__(64) crx_mpc_tile_lite_kernel(const crx::MpcTileArgs a) { crx::mpc_tile_body<24, 3>(a); }

@@ -34,7 +34,7 @@ for n in sizes:
                      "at_cap_50": int((sw >= 50).sum()), "converged_frac": float((st0 & 1).mean())}
     ref = None
     variants = [("private", lambda: mpc_solve_store(x0, xref, T, 0, out=out)), ("tile", lambda: mpc_solve_store(x0, xref, T, 1, out=out)),
-                ("tile2", lambda: mpc_solve_store(x0, xref, T, 2, out=out))]
+                ("tile2", lambda: mpc_solve_store(x0, xref, T, 2, out=out)), ("tile_lite", lambda: mpc_solve_store(x0, xref, T, 3, out=out))]
     from cpprobotics_amd.experimental import mpc_solve_two_phase
     wk = torch.empty(n + 64, dtype=torch.int32, device=dev)
     for K in (8, 9, 10, 12):

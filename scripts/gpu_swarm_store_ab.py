@@ -20,12 +20,13 @@ variants = {
     "product": None,
     "private": lambda est, xref, Tm, out: X.mpc_solve_store(est, xref, Tm, 0, out=out),
     "tile": lambda est, xref, Tm, out: X.mpc_solve_store(est, xref, Tm, 1, out=out),
+    "tile_lite": lambda est, xref, Tm, out: X.mpc_solve_store(est, xref, Tm, 3, out=out),
     "tile_refill_64_16": lambda est, xref, Tm, out: X.mpc_solve_tile_refill(est, xref, Tm, 64 * 4, 16, out=out),
     "tile_refill_128_16": lambda est, xref, Tm, out: X.mpc_solve_tile_refill(est, xref, Tm, 64 * 8, 16, out=out),
 }
 want = sys.argv[1:] or list(variants)
 for name in want:
-    r = bench.measure_swarm_configs4(dev, 0, 1, depth=6, rounds=40, warmup=12, blocks=3, mpc_fn=variants[name], mpc_label=name)
+    r = bench.measure_swarm_configs4(dev, 0, 1, depth=int(os.environ.get('DEPTH', '6')), rounds=40, warmup=12, blocks=3, mpc_fn=variants[name], mpc_label=name)
     print(json.dumps({"variant": name, "round_ms": r["round_ms"], "blocks": r["round_ms_of_every_block"], "ekf_frac_sharing": r["roofline"]["frac"],
                       "ekf_frac_alone": r["roofline"]["launch_alone"]["frac"], "mpc_solves_per_s": r["mpc_solves_per_s"],
                       "host_issue_ms": r["host_issue_ms_per_round"], "converged": r["mpc_sweeps"]["converged_frac"]}), flush=True)

@@ -26,6 +26,8 @@ for v in variants:
             X.mpc_solve_refill(x0, xref, 21, 512, 16, poison=False)
         elif v == "tile":
             X.mpc_solve_store(x0, xref, 21, 1)
+        elif v == "tile_lite":
+            X.mpc_solve_store(x0, xref, 21, 3)
         elif v == "tile2":
             X.mpc_solve_store(x0, xref, 21, 2)
         elif v == "tile2_refill":
